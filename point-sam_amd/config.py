@@ -1,0 +1,75 @@
+"""Architecture hyper-parameters of the Point-SAM hot path, restated as plain dataclasses.
+
+Source of truth in the reference (hydra YAML, not importable here because hydra is absent):
+  configs/model/base.yaml:1-26, configs/model/default.yaml:1-27 (= "large"), configs/model/giant.yaml:1-26.
+The ViT dimensions come from timm's model registry (eva02_base_patch14_448, eva02_large_patch14_448,
+eva_giant_patch14_560); timm is not vendored in the reference, so these numbers are *our spec* of that
+dependency.
+"""
+from dataclasses import dataclass, field, replace
+
+
+@dataclass(frozen=True)
+class ViTConfig:
+    name: str
+    dim: int            # transformer width D
+    depth: int
+    heads: int
+    mlp_hidden: int     # SwiGLU hidden (eva02) or GELU-MLP hidden (eva_giant)
+    swiglu: bool        # eva02: separate q/k/v proj + SwiGLU with inner LayerNorm; eva_giant: fused qkv + GELU MLP
+    ln_eps: float = 1e-6
+
+    @property
+    def head_dim(self) -> int:
+        return self.dim // self.heads
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    vit: ViTConfig
+    num_groups: int = 512        # G, KNNGrouper.num_groups  (pc_encoder.py:26-31)
+    group_size: int = 64         # K, KNNGrouper.group_size
+    in_channels: int = 6         # xyz-relative + rgb        (configs/model/default.yaml:6)
+    patch_out: int = 512         # PatchEmbed.out_channels   (configs/model/default.yaml:7)
+    patch_hidden: tuple = (128, 512)  # pc_encoder.py:34
+    embed_dim: int = 256         # SAM embed dim             (configs/model/default.yaml:14)
+    dec_depth: int = 2           # TwoWayTransformer.depth   (configs/model/default.yaml:23)
+    dec_heads: int = 8
+    dec_mlp: int = 2048
+    dec_downsample: int = 2      # transformer.py:23
+    num_multimask: int = 3       # mask_decoder.py:26
+    prompt_iters: int = 5
+    ln_eps: float = 1e-5         # torch.nn.LayerNorm default used by every non-timm LayerNorm
+
+    @property
+    def num_mask_tokens(self) -> int:
+        return self.num_multimask + 1
+
+    def with_groups(self, num_groups: int, group_size: int) -> "ModelConfig":
+        return replace(self, num_groups=num_groups, group_size=group_size)
+
+
+VIT_BASE = ViTConfig("eva02_base_patch14_448", 768, 12, 12, 2048, True)
+VIT_LARGE = ViTConfig("eva02_large_patch14_448", 1024, 24, 16, 2730, True)
+VIT_GIANT = ViTConfig("eva_giant_patch14_560", 1408, 40, 16, 6144, False)
+# Tiny transformers used only by tests / golden fixtures (same block arithmetic, small dims).
+VIT_TINY_SWIGLU = ViTConfig("tiny_eva02", 64, 2, 2, int(64 * 8 / 3), True)       # hidden 170: exercises padding
+VIT_TINY_GELU = ViTConfig("tiny_eva_giant", 96, 2, 4, 256, False)                # head_dim 24
+
+CONFIGS = {
+    # configs/model/base.yaml: num_patches 512, patch_size 64, prompt_iters 10
+    "base": ModelConfig(VIT_BASE, 512, 64, prompt_iters=10),
+    # configs/model/default.yaml (selected by configs/large.yaml:2): num_patches 1024, patch_size 256
+    "large": ModelConfig(VIT_LARGE, 1024, 256, prompt_iters=5),
+    # configs/model/giant.yaml
+    "giant": ModelConfig(VIT_GIANT, 512, 64, prompt_iters=10),
+    "tiny": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3),
+    "tiny_gelu": ModelConfig(VIT_TINY_GELU, 32, 16, prompt_iters=3),
+}
+
+
+def get_config(name: str, num_groups: int = None, group_size: int = None) -> ModelConfig:
+    cfg = CONFIGS[name]
+    if num_groups is not None or group_size is not None:
+        cfg = cfg.with_groups(num_groups or cfg.num_groups, group_size or cfg.group_size)
+    return cfg

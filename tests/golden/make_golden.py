@@ -1,0 +1,206 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python modules (imported read-only from
+/root/reference) on seeded inputs.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The reference cannot be imported verbatim: pc_sam/model/common.py:7-9 imports torkit3d and
+pc_sam/model/pc_encoder.py:4-8 imports timm, both absent (empty submodule / no network).  This script
+installs minimal stand-ins for exactly those third-party symbols and nothing else:
+
+  torkit3d.ops.sample_farthest_points  -> oracle FPS (our spec; the real CUDA kernel is unavailable)
+  torkit3d.nn.functional.batch_index_select -> torch.gather along `dim`
+  torkit3d.ops.chamfer_distance        -> brute-force nearest-neighbour distance
+  timm.models.eva.Eva / timm.create_model -> a small nn.Module with timm's Eva parameter names and block
+                                          arithmetic restated from timm's published code (our spec)
+
+Everything else executed below -- KNNGrouper, knn_points (torch.cdist+topk), PatchEncoder, PatchEmbed,
+PointCloudEncoder, PositionEmbeddingRandom, PointEncoder, MaskEncoder, TwoWayTransformer, MaskDecoder,
+compute_interp_weights, interpolate_features, PointCloudSAM.predict_masks -- is the reference's code.
+The random weights come from point_sam_amd.weights.random_state_dict and are loaded with
+``load_state_dict(strict=True)``, which also proves our parameter names equal the reference's.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import pointsam_oracle as O  # noqa: E402
+from point_sam_amd.config import get_config  # noqa: E402
+from point_sam_amd.weights import random_state_dict, state_dict_checksum  # noqa: E402
+
+
+# ---------------------------------------------------------------------------- third-party stand-ins
+def _install_stubs():
+    def batch_index_select(inp, index, dim):
+        view = list(index.shape) + [1] * (inp.dim() - index.dim())
+        expand = list(inp.shape)
+        expand[dim] = -1
+        idx = index.reshape(view).expand(expand[: index.dim()] + list(inp.shape[index.dim():]))
+        return torch.gather(inp, dim, idx)
+
+    def sample_farthest_points(points, num_samples):
+        return O.fps(points, num_samples)
+
+    def chamfer_distance(a, b):
+        d = torch.cdist(a, b)
+        m1, i1 = d.min(dim=2)
+        return m1, i1
+
+    mods = {
+        "torkit3d": types.ModuleType("torkit3d"),
+        "torkit3d.nn": types.ModuleType("torkit3d.nn"),
+        "torkit3d.nn.functional": types.ModuleType("torkit3d.nn.functional"),
+        "torkit3d.ops": types.ModuleType("torkit3d.ops"),
+        "torkit3d.ops.sample_farthest_points": types.ModuleType("torkit3d.ops.sample_farthest_points"),
+        "torkit3d.ops.chamfer_distance": types.ModuleType("torkit3d.ops.chamfer_distance"),
+        "timm": types.ModuleType("timm"),
+        "timm.models": types.ModuleType("timm.models"),
+        "timm.models.eva": types.ModuleType("timm.models.eva"),
+        "timm.models.vision_transformer": types.ModuleType("timm.models.vision_transformer"),
+    }
+    mods["torkit3d.nn.functional"].batch_index_select = batch_index_select
+    mods["torkit3d.ops.sample_farthest_points"].sample_farthest_points = sample_farthest_points
+    mods["torkit3d.ops.chamfer_distance"].chamfer_distance = chamfer_distance
+    mods["timm.models.eva"].Eva = StandInEva
+    mods["timm.models.vision_transformer"].VisionTransformer = StandInEva
+    sys.modules.update(mods)
+
+
+class _Attn(nn.Module):
+    def __init__(self, vit):
+        super().__init__()
+        D = vit.dim
+        self.heads = vit.heads
+        if vit.swiglu:
+            self.q_proj, self.k_proj, self.v_proj = nn.Linear(D, D), nn.Linear(D, D, bias=False), nn.Linear(D, D)
+        else:
+            self.qkv = nn.Linear(D, 3 * D, bias=False)
+            self.q_bias, self.v_bias = nn.Parameter(torch.zeros(D)), nn.Parameter(torch.zeros(D))
+        self.proj = nn.Linear(D, D)
+        self.swiglu = vit.swiglu
+
+    def forward(self, x):
+        B, L, D = x.shape
+        if self.swiglu:
+            q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        else:
+            b = torch.cat([self.q_bias, torch.zeros_like(self.q_bias), self.v_bias])
+            q, k, v = F.linear(x, self.qkv.weight, b).chunk(3, dim=-1)
+        q, k, v = (t.reshape(B, L, self.heads, -1).transpose(1, 2) for t in (q, k, v))
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.proj(o.transpose(1, 2).reshape(B, L, D))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, vit):
+        super().__init__()
+        D, H = vit.dim, vit.mlp_hidden
+        self.swiglu = vit.swiglu
+        if vit.swiglu:
+            self.fc1_g, self.fc1_x = nn.Linear(D, H), nn.Linear(D, H)
+            self.norm = nn.LayerNorm(H, eps=vit.ln_eps)
+        else:
+            self.fc1 = nn.Linear(D, H)
+        self.fc2 = nn.Linear(H, D)
+
+    def forward(self, x):
+        if self.swiglu:
+            return self.fc2(self.norm(F.silu(self.fc1_g(x)) * self.fc1_x(x)))
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Block(nn.Module):
+    def __init__(self, vit):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(vit.dim, eps=vit.ln_eps)
+        self.attn = _Attn(vit)
+        self.norm2 = nn.LayerNorm(vit.dim, eps=vit.ln_eps)
+        self.mlp = _Mlp(vit)
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class StandInEva(nn.Module):
+    """timm Eva as PointCloudEncoder uses it (pc_encoder.py:93,136-142): embed_dim, pos_drop, blocks, norm, fc_norm."""
+
+    def __init__(self, vit):
+        super().__init__()
+        self.embed_dim = vit.dim
+        self.pos_drop = nn.Identity()
+        self.blocks = nn.ModuleList([_Block(vit) for _ in range(vit.depth)])
+        self.norm = nn.Identity()
+        self.fc_norm = nn.LayerNorm(vit.dim, eps=vit.ln_eps)
+
+
+def build_reference_model(cfg, sd):
+    _install_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pc_sam.model.mask_decoder import MaskDecoder
+    from pc_sam.model.pc_encoder import PatchEmbed, PointCloudEncoder
+    from pc_sam.model.pc_sam import PointCloudSAM
+    from pc_sam.model.prompt_encoder import MaskEncoder
+    from pc_sam.model.transformer import TwoWayTransformer
+
+    model = PointCloudSAM(
+        pc_encoder=PointCloudEncoder(
+            PatchEmbed(cfg.in_channels, cfg.patch_out, cfg.num_groups, cfg.group_size), StandInEva(cfg.vit), cfg.embed_dim
+        ),
+        mask_encoder=MaskEncoder(cfg.embed_dim),
+        mask_decoder=MaskDecoder(cfg.embed_dim, TwoWayTransformer(cfg.dec_depth, cfg.embed_dim, cfg.dec_heads, cfg.dec_mlp)),
+        prompt_iters=cfg.prompt_iters,
+    )
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return model.eval()
+
+
+def make_case(name, cfg_name, B, N, M, P, seed):
+    cfg = get_config(cfg_name)
+    sd = random_state_dict(cfg, seed=seed)
+    model = build_reference_model(cfg, sd)
+    xyz, rgb, _, _ = O.synthetic_batch(B, N, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    pidx = torch.randint(0, N, (B * M, P), generator=g)
+    prompt_coords = torch.stack([xyz[i // M][pidx[i]] for i in range(B * M)])
+    prompt_labels = (torch.rand(B * M, P, generator=g) > 0.3).to(torch.int64)
+    prompt_labels[:, 0] = 1
+    out = {}
+    with torch.no_grad():
+        emb, patches = model.pc_encoder(xyz, rgb)
+        out.update(pc_embeddings=emb, centers=patches["centers"], knn_idx=patches["knn_idx"], fps_idx=patches["fps_idx"],
+                   patch_embeddings=patches["embeddings"], group_features=patches["features"])
+        out["pc_pe"] = model.point_encoder.pe_layer(patches["centers"])
+        out["sparse"] = model.point_encoder(prompt_coords, prompt_labels)
+        masks, iou = model.predict_masks(xyz, rgb, prompt_coords, prompt_labels, None, True)
+        out.update(masks_click1=masks, iou_click1=iou)
+        best = torch.gather(masks, 1, iou.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0]
+        out["dense_click2"] = model.mask_encoder(best, xyz, patches["centers"], patches["knn_idx"])
+        masks2, iou2 = model.predict_masks(xyz, rgb, prompt_coords, prompt_labels, best, False)
+        out.update(prompt_masks_click2=best, masks_click2=masks2, iou_click2=iou2)
+        from pc_sam.model.common import compute_interp_weights
+        ii, iw = compute_interp_weights(xyz, patches["centers"])
+        out.update(interp_index=ii, interp_weight=iw)
+    arrays = {k: v.numpy() for k, v in out.items()}
+    arrays.update(xyz=xyz.numpy(), rgb=rgb.numpy(), prompt_coords=prompt_coords.numpy(), prompt_labels=prompt_labels.numpy())
+    meta = dict(cfg=cfg_name, B=B, N=N, M=M, P=P, seed=seed, weights_checksum=state_dict_checksum(sd),
+                torch=torch.__version__)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{name}.npz")
+    np.savez_compressed(path, meta=np.array(repr(meta)), **arrays)
+    print(name, {k: v.shape for k, v in arrays.items()}, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    make_case("ref_tiny_swiglu", "tiny", B=2, N=1024, M=2, P=2, seed=7)
+    make_case("ref_tiny_gelu", "tiny_gelu", B=1, N=777, M=1, P=1, seed=11)
