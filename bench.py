@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the Point-SAM hot path (encode + 1-prompt decode) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one full pass (FPS -> kNN grouping -> mini-PointNet -> ViT-L -> two-way decoder -> per-point mask logits)
+over one batch of synthetic clouds resident in HBM: BASELINE.json configs[1] = ViT-L, N=32768, group_number=512,
+group_size=64, batch=8 per GPU, 1 point prompt, multimask output.  With N>1 every rank processes its own batch
+(weak scaling, clouds are independent) and the per-cloud logits are all-gathered over RCCL each step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+
+
+def cpu_baseline(cfg, sd, N, seed):
+    """The oracle (CPU restatement of the reference, PyTorch fp32 + C tokenizer) on a bounded sample: ONE cloud of the
+    same workload.  Reported next to the GPU number; never the thing measured above."""
+    from oracle import pointsam_oracle as O
+    xyz, rgb, prompt, labels = O.synthetic_batch(1, N, seed=seed)
+    cores = torch.get_num_threads()
+    O.fps(xyz[:, :4096], 16)  # build/load the C library outside the timed region
+    t0 = time.perf_counter()
+    O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="reference")
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "sample": f"1 cloud of the workload (ViT-L, N={N}, 512x64, 1 prompt), oracle mode='reference' (torch.cdist+topk), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="large")
+    ap.add_argument("--points", type=int, default=32768)
+    ap.add_argument("--groups", type=int, default=512)
+    ap.add_argument("--group-size", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=8, help="clouds per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")
+    args = ap.parse_args()
+
+    from point_sam_amd import dist as psdist
+    rank, world, local = psdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from oracle import pointsam_oracle as O  # synthetic input generator + cpu_baseline only
+    from point_sam_amd import get_config, ops
+    from point_sam_amd.model import PointCloudSAM
+    from point_sam_amd.weights import random_state_dict
+
+    cfg = get_config(args.config, args.groups, args.group_size)
+    sd = random_state_dict(cfg, seed=42)
+    model = PointCloudSAM(cfg, sd, dev)
+    B, N = args.batch, args.points
+    xyz, rgb, prompt, labels = O.synthetic_batch(B, N, seed=42 + rank)
+    xyz, rgb, prompt, labels = xyz.to(dev), rgb.to(dev), prompt.to(dev), labels.to(dev)
+    total = B * world
+
+    def step():
+        masks, iou = model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False)
+        if world > 1:
+            masks = psdist.gather_results(masks, total)
+            iou = psdist.gather_results(iou, total)
+        return masks, iou
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = None if args.no_gemm_profile else []
+    ops.GEMM_PROFILE = prof
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    model.check_coordinate_range()
+    assert torch.isfinite(out[0]).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    if prof:
+        # dominant kernel = gemm_nt_kernel (f32-input MFMA): algorithmic flops per launch / measured launch duration
+        ms = [s.elapsed_time(e) for s, e, *_ in prof]
+        fl = [p[2] for p in prof]
+        big = [(m, f) for m, f in zip(ms, fl) if f >= 1e9]  # the ViT / mini-PointNet / upscaling GEMMs (>= 1 GFLOP)
+        tot_ms, tot_fl = sum(m for m, _ in big), sum(f for _, f in big)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "kernel": "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "launches_per_step": len(big) // args.steps,
+                    "avg_launch_ms": round(tot_ms / len(big), 4), "avg_launch_gflop": round(tot_fl / len(big) / 1e9, 3),
+                    "gemm_ms_per_step": round(tot_ms / args.steps, 3), "all_gemm_ms_per_step": round(sum(ms) / args.steps, 3)}
+
+    if rank == 0:
+        res = {
+            "metric": "point-clouds/sec (encode+1-prompt decode)", "value": round(total * args.steps / elapsed, 3), "unit": "point-clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ViT-{args.config} N={N} g={args.groups}x{args.group_size} batch={B}/GPU 1 point prompt multimask",
+                       "global_batch": total, "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoint offline)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, N, 42)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

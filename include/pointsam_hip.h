@@ -1,0 +1,142 @@
+/*
+ * pointsam_hip.h -- C ABI of libpointsam_hip.so (gfx950 / MI355X), the drop-in boundary for the Point-SAM
+ * inference hot path (encode + prompt decode).
+ *
+ * The reference (zyc00/Point-SAM) has no FFI of its own: its "operator API" for this path is the set of Python
+ * call sites into third-party native code and ATen.  Each entry point below names the reference interface it
+ * replaces (file:line under the reference checkout).  The Python host (point-sam_amd/ops.py) binds these with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer valid on `stream`; calls are asynchronous and never allocate;
+ *   - tensors are fp32 row-major unless stated; indices are int64 (torch.long) as in the reference;
+ *   - return value: 0 = ok, < 0 = invalid argument (PSAM_E*), > 0 = hipError_t of the failed launch;
+ *     psam_last_error_string() describes the last failure on the calling thread;
+ *   - thread-safe for distinct streams / workspaces.
+ */
+#ifndef POINTSAM_HIP_H
+#define POINTSAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* psam_stream_t; /* == hipStream_t */
+
+#define PSAM_OK 0
+#define PSAM_EINVAL (-1)
+#define PSAM_EALIGN (-2)
+#define PSAM_EWORKSPACE (-3)
+
+#define PSAM_ACT_NONE 0
+#define PSAM_ACT_GELU 1 /* exact erf GELU (torch.nn.GELU default) */
+#define PSAM_ACT_RELU 2
+
+int32_t psam_version(void);
+const char* psam_last_error_string(void);
+
+/* ---------------------------------------------------------------- point tokenizer */
+
+/* Farthest point sampling + center gather.
+ * Replaces torkit3d.ops.sample_farthest_points(points, num_samples) and torkit3d batch_index_select:
+ * pc_sam/model/common.py:91-92 (also :22-23, :199-200).  Start index 0, fp32 squared distances without FMA,
+ * arg-max with lowest index on ties (bit-exact vs oracle/tokenizer_oracle.c).
+ *   xyz [B,N,3] -> fps_idx [B,G] int64, centers [B,G,3];  ws: psam_fps_workspace_bytes() bytes, 16B aligned. */
+size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G);
+int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws, size_t ws_bytes,
+                 psam_stream_t stream);
+
+/* K nearest points of each center, ascending by (squared distance, index); the [G,N] distance matrix is never
+ * materialised.  Replaces knn_points(centers, xyz, K) = torch.cdist + torch.topk: pc_sam/model/common.py:27-56,97.
+ *   centers [B,G,3], xyz [B,N,3] -> knn_idx [B,G,K] int64.  K <= 1024. */
+int32_t psam_knn(const float* centers, const float* xyz, int32_t B, int32_t G, int32_t N, int32_t K, int64_t* knn_idx, psam_stream_t stream);
+
+/* 3 nearest centers of every point + normalised 1/max(d^2, eps) weights.
+ * Replaces compute_interp_weights(query, key): pc_sam/model/common.py:238-255 (called from mask_decoder.py:151-156).
+ *   xyz [B,N,3], centers [B,G,3] -> idx3 [B,N,3] int64, w3 [B,N,3]. */
+int32_t psam_three_nn(const float* xyz, const float* centers, int32_t B, int32_t N, int32_t G, float eps, int64_t* idx3, float* w3,
+                      psam_stream_t stream);
+
+/* Neighbourhood gather out[bf,g,k,:] = [xyz[idx]-center, feats[bf,idx,:]]  (bf = b*rep + m).
+ * Replaces the gather/centre/concat of KNNGrouper.forward: pc_sam/model/common.py:99-120, and of
+ * group_with_centers_and_knn: pc_sam/model/common.py:126-187 (rep > 1: several feature sets per cloud).
+ *   feats [B*rep,N,C] -> out [B*rep,G,K,3+C]. */
+int32_t psam_group_gather(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B, int32_t rep,
+                          int32_t N, int32_t G, int32_t K, int32_t C, float* out, psam_stream_t stream);
+
+/* Same gather fused with the first mini-PointNet layer: GELU(LayerNorm_128(Linear(3+C -> 128))).
+ * Replaces PatchEncoder.conv1[0:3] on the grouped features: pc_sam/model/common.py:486-489,499. C in {1,3}.
+ *   out [B*rep*G*K, 128]. */
+int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W, const float* bias,
+                      const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
+                      float* out, psam_stream_t stream);
+
+/* Max over the K members of each group: x [groups*K, C] -> y [groups, C].
+ * Replaces torch.max(x, dim=-2): pc_sam/model/common.py:502,505. */
+int32_t psam_group_max(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t groups, int32_t K, int32_t C, psam_stream_t stream);
+
+/* ---------------------------------------------------------------- dense layers (fp32-exact MFMA) */
+
+/* C[z] = act(alpha * A[z] @ W[z]^T + bias + rowbias[row/rowgroup]) + residual[z];  A [M,K], W [N,K] (nn.Linear layout).
+ * Replaces every nn.Linear / F.linear / matmul on the path (cuBLAS in the reference): common.py:486-497,
+ * pc_encoder.py:99-116, timm Eva blocks, transformer.py:199-202,248-249, mask_decoder.py:53-59,176,201-203.
+ * Batch index z = z1*batch2 + z2 with element strides s?1 / s?2.  K, lda, ldw and batch strides multiples of 4. */
+int32_t psam_gemm_f32(const float* A, int64_t lda, int64_t sA1, int64_t sA2, const float* W, int64_t ldw, int64_t sW1, int64_t sW2, float* C,
+                      int64_t ldc, int64_t sC1, int64_t sC2, const float* bias, const float* residual, int64_t ldr, int64_t sR1, int64_t sR2,
+                      const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, int32_t batch1, int32_t batch2,
+                      float alpha, int32_t act, psam_stream_t stream);
+int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
+                    int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
+void psam_gemm_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64, 2=64x64 tiles, -1=auto */
+
+/* y = act(LayerNorm(x (+ res))).  Replaces nn.LayerNorm / apex FusedLayerNorm (pc_sam/utils/torch_utils.py:28-38)
+ * at common.py:488,494, timm blocks, transformer.py:59,128-138, mask_decoder.py:55. */
+int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
+                       int64_t rows, int32_t cols, float eps, int32_t act, psam_stream_t stream);
+
+/* out = LayerNorm_H(SiLU(gx[:,0:H]) * gx[:,xoff:xoff+H]), zero-padded to ldo columns.
+ * Replaces timm SwiGLU (act, mul, norm) inside eva02 blocks (called through pc_encoder.py:138-139). */
+int32_t psam_swiglu_ln(const float* gx, int64_t ldg, int32_t xoff, const float* w, const float* b, float* out, int64_t ldo, int64_t rows,
+                       int32_t H, float eps, psam_stream_t stream);
+
+/* softmax(q k^T * scale) v per (batch, head), flash-style on the matrix cores; q/k/v/o are [B,L,H*hd] views.
+ * Replaces F.scaled_dot_product_attention inside timm EvaAttention (pc_encoder.py:138-139).
+ * hd in {16,24,32,48,64,88,96,128}. */
+int32_t psam_attention_f32(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                           int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                           float scale, psam_stream_t stream);
+
+/* Same contraction for the decoder's token-sized problems (any hd, few queries or few keys).
+ * Replaces Attention.forward's matmul-softmax-matmul: pc_sam/model/transformer.py:226-233. */
+int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                             int64_t sv, float* out, int64_t ldo, int64_t so, int64_t Z, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                             float scale, psam_stream_t stream);
+
+/* ---------------------------------------------------------------- encodings, token assembly, upsampling */
+
+/* y[r,0:128] = GELU(W[128,3] @ centers[r] + bias): first layer of PointCloudEncoder.pos_embed, pc_encoder.py:102-104,130. */
+int32_t psam_pos_l1(const float* centers, const float* W, const float* bias, float* y, int64_t rows, psam_stream_t stream);
+
+/* [sin, cos](2*pi * x @ gauss[3,F]) (+ point_embeddings[label]); row r -> out + (r / rows_per_batch)*batch_stride
+ * + (r % rows_per_batch)*2F.  *flag |= 1 if a coordinate leaves [-1-1e-6, 1+1e-6] (the reference raises ValueError).
+ * Replaces PositionEmbeddingRandom.forward and PointEncoder.forward: pc_sam/model/prompt_encoder.py:27-48,63-77. */
+int32_t psam_fourier_pe(const float* coords, const float* gauss, int32_t F, const int64_t* labels, const float* emb0, const float* emb1,
+                        float* out, int64_t rows, int32_t rows_per_batch, int64_t batch_stride, int32_t* flag, psam_stream_t stream);
+
+/* out[z,r,:] = a[z/rep,r,:] + (b ? b[z*sb + r*ldb + :] : 0).  Replaces repeat_interleave + adds:
+ * pc_sam/model/mask_decoder.py:136-139, pc_sam/model/transformer.py:153-170, prompt_encoder.py:119-122. */
+int32_t psam_add_bcast(const float* a, int64_t sa, int32_t rep, const float* b, int64_t sb, int64_t ldb, float* out, int64_t so, int64_t Z,
+                       int64_t R, int32_t C, psam_stream_t stream);
+
+/* out[z,n,:] = sum_k w3[b,n,k] * src[z, idx3[b,n,k], :], b = z/rep.  Replaces interpolate_features:
+ * pc_sam/model/common.py:258-274 (mask_decoder.py:163). */
+int32_t psam_interp3(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C,
+                     psam_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTSAM_HIP_H */

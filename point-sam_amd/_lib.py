@@ -1,0 +1,70 @@
+"""ctypes binding of csrc/libpointsam_hip.so (C ABI declared in include/pointsam_hip.h).
+
+The product path has NO fallback: if the library has not been built (``python -m point_sam_amd.build``)
+or a kernel launch fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpointsam_hip.so")
+
+i32, i64, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+ptr, size_t = ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pointsam_hip.h one to one
+SIGNATURES = {
+    "psam_version": (i32, []),
+    "psam_last_error_string": (ctypes.c_char_p, []),
+    "psam_fps_workspace_bytes": (size_t, [i32, i32, i32]),
+    "psam_fps": (i32, [ptr, i32, i32, i32, ptr, ptr, ptr, size_t, ptr]),
+    "psam_knn": (i32, [ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
+    "psam_three_nn": (i32, [ptr, ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
+    "psam_group_gather": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, ptr]),
+    "psam_patch_l1": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, ptr, ptr]),
+    "psam_group_max": (i32, [ptr, i64, ptr, i64, i64, i32, i32, ptr]),
+    "psam_gemm_f32": (i32, [ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, ptr, i64, i64, i64, ptr, i64, i32,
+                            i32, i32, i32, i32, i32, f32, i32, ptr]),
+    "psam_linear": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
+    "psam_gemm_force_config": (None, [i32]),
+    "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
+    "psam_swiglu_ln": (i32, [ptr, i64, i32, ptr, ptr, ptr, i64, i64, i32, f32, ptr]),
+    "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
+    "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
+    "psam_pos_l1": (i32, [ptr, ptr, ptr, ptr, i64, ptr]),
+    "psam_fourier_pe": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i64, ptr, ptr]),
+    "psam_add_bcast": (i32, [ptr, i64, i32, ptr, i64, i64, ptr, i64, i64, i64, i32, ptr]),
+    "psam_interp3": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr]),
+}
+
+_lib = None
+
+
+class PointSamHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library once.  Import torch first so that libamdhip64.so.7 resolves to the runtime torch uses
+    (same soname; the loader reuses the already-mapped copy, so streams and device pointers are shared)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PointSamHipError(
+                f"{LIB_PATH} is missing: build it with `python -m point_sam_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback on the product path."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().psam_last_error_string().decode()
+        kind = "invalid argument" if status < 0 else f"hipError {status}"
+        raise PointSamHipError(f"{what}: {kind} ({status}): {msg}")

@@ -1,0 +1,56 @@
+"""Builds csrc/libpointsam_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m point_sam_amd.build [--force]
+
+The library is built IN-TREE so that it travels with the repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libpointsam_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# (source, extra flags).  The tokenizer must not contract a*b+c into fma: FPS / kNN indices are bit-exact
+# against the oracle's fp32 arithmetic (oracle/tokenizer_oracle.c is built with -ffp-contract=off too).
+SOURCES = [
+    ("tokenizer.hip", ["-ffp-contract=off"]),
+    ("gemm.hip", []),
+    ("attention.hip", []),
+    ("rowops.hip", []),
+    ("error.cpp", ["-x", "hip"]),
+]
+
+
+def _stale(out, deps):
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    hdr = os.path.join(CSRC, "common.h")
+    jobs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        if force or _stale(o, [s, hdr, os.path.abspath(__file__)]):
+            jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr)
+        return r.stderr
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(CSRC, os.path.splitext(s)[0] + ".o") for s, _ in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

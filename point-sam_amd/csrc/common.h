@@ -1,0 +1,67 @@
+// Shared helpers for the gfx950 (CDNA4, wave64) kernels of libpointsam_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define PSAM_OK 0
+#define PSAM_EINVAL (-1)     // bad shape / null pointer / unsupported size
+#define PSAM_EALIGN (-2)     // pointer or leading dimension not aligned as the kernel requires
+#define PSAM_EWORKSPACE (-3) // workspace too small
+
+#define PSAM_API extern "C" __attribute__((visibility("default")))
+
+void psam_set_error(const char* msg);
+
+#define PSAM_REQUIRE(cond, code, msg)                 \
+    do {                                              \
+        if (!(cond)) {                                \
+            psam_set_error(msg);                      \
+            return (code);                            \
+        }                                             \
+    } while (0)
+
+// Returns 0 or the positive hipError_t of the launch just issued.
+static inline int32_t psam_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        psam_set_error(what);
+        return (int32_t)e;
+    }
+    return PSAM_OK;
+}
+
+static inline int64_t psam_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// exact (erf) GELU, as torch.nn.GELU() default
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// Squared distance with the oracle's operation order and NO fused multiply-add:
+// ((dx*dx) + dy*dy) + dz*dz, every op rounded to fp32 (oracle/tokenizer_oracle.c: dist2).
+// HIP's __fmul_rn/__fadd_rn are plain operators (contractable), so contraction is switched off by pragma
+// here and by -ffp-contract=off for the whole tokenizer translation unit.
+__device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float s = dx * dx;
+    const float t = dy * dy;
+    s = s + t;
+    const float u = dz * dz;
+    s = s + u;
+    return s;
+}
+#endif

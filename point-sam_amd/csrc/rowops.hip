@@ -1,0 +1,320 @@
+// Row-wise / gather kernels of the Point-SAM hot path for gfx950 (wave64): LayerNorm (+residual, +GELU), SwiGLU
+// gate with inner LayerNorm, per-group max-pool, positional encodings, token assembly, 3-NN feature interpolation
+// and the small prompt-token attentions of the two-way decoder.  All memory-bound: one wave per row, lane-consecutive
+// (coalesced) accesses, shuffle reductions.
+#include "common.h"
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// y = act(LayerNorm(x (+ res)))          nn.LayerNorm / apex FusedLayerNorm (pc_sam/utils/torch_utils.py:28-38)
+// One wave per row; rows of <= 1024 columns are held in registers, longer rows are re-read (L2-resident).
+// ------------------------------------------------------------------------------------------------
+template <int NREG>  // NREG*64 >= cols for the register path; NREG == 0 -> streaming path
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
+                                                        const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                                        int64_t ldy, int64_t rows, int cols, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    const float* rr = res ? res + row * ldr : nullptr;
+    float* yr = y + row * ldy;
+    const float inv = 1.0f / (float)cols;
+    if (NREG > 0) {
+        float v[NREG > 0 ? NREG : 1];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = i * 64 + lane;
+            float t = 0.f;
+            if (c < cols) { t = xr[c]; if (rr) t += rr[c]; }
+            v[i] = t;
+            s += t;
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = i * 64 + lane;
+            const float d = c < cols ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = i * 64 + lane;
+            if (c < cols) {
+                float o = (v[i] - mean) * r * w[c] + b[c];
+                if (act == 1) o = gelu_erf(o);
+                yr[c] = o;
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) { float t = xr[c]; if (rr) t += rr[c]; s += t; }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+        for (int c = lane; c < cols; c += 64) { float t = xr[c]; if (rr) t += rr[c]; const float d = t - mean; q += d * d; }
+        const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+        for (int c = lane; c < cols; c += 64) {
+            float t = xr[c]; if (rr) t += rr[c];
+            float o = (t - mean) * r * w[c] + b[c];
+            if (act == 1) o = gelu_erf(o);
+            yr[c] = o;
+        }
+    }
+}
+
+PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, hipStream_t stream) {
+    PSAM_REQUIRE(x && w && b && y, PSAM_EINVAL, "psam_layernorm: null pointer");
+    PSAM_REQUIRE(rows > 0 && cols > 0, PSAM_EINVAL, "psam_layernorm: bad shape");
+    PSAM_REQUIRE(act == 0 || act == 1, PSAM_EINVAL, "psam_layernorm: act must be 0 or 1 (GELU)");
+    const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
+#define LN_LAUNCH(R) hipLaunchKernelGGL(layernorm_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act)
+    if (cols <= 128) LN_LAUNCH(2);
+    else if (cols <= 256) LN_LAUNCH(4);
+    else if (cols <= 512) LN_LAUNCH(8);
+    else if (cols <= 1024) LN_LAUNCH(16);
+    else LN_LAUNCH(0);
+#undef LN_LAUNCH
+    return psam_launch_status("psam_layernorm: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// timm SwiGLU with inner norm (eva02 blocks): out = LayerNorm_H(SiLU(g) * x); g = gx[:, 0:H], x = gx[:, xoff:xoff+H].
+// out has leading dimension ldo >= H; columns [H, ldo) are written as zeros (K padding of the following fc2 GEMM).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_ln_kernel(const float* __restrict__ gx, int64_t ldg, int xoff, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ out, int64_t ldo, int64_t rows, int H,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const float* g = gx + row * ldg;
+    const float* x = g + xoff;
+    float* o = out + row * ldo;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float u = silu(g[c]) * x[c];
+        o[c] = u;  // same lane re-reads its own columns below
+        s += u;
+    }
+    const float inv = 1.0f / (float)H;
+    const float mean = wave_sum(s) * inv;
+    float q = 0.f;
+    for (int c = lane; c < H; c += 64) { const float d = o[c] - mean; q += d * d; }
+    const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+    for (int c = lane; c < H; c += 64) o[c] = (o[c] - mean) * r * w[c] + b[c];
+    for (int c = H + lane; c < ldo; c += 64) o[c] = 0.f;
+}
+
+PSAM_API int32_t psam_swiglu_ln(const float* gx, int64_t ldg, int32_t xoff, const float* w, const float* b, float* out, int64_t ldo,
+                                int64_t rows, int32_t H, float eps, hipStream_t stream) {
+    PSAM_REQUIRE(gx && w && b && out, PSAM_EINVAL, "psam_swiglu_ln: null pointer");
+    PSAM_REQUIRE(rows > 0 && H > 0 && xoff >= H && ldo >= H && ldg >= xoff + H, PSAM_EINVAL, "psam_swiglu_ln: bad shape");
+    hipLaunchKernelGGL(swiglu_ln_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, gx, ldg, xoff, w, b, out, ldo, rows, H, eps);
+    return psam_launch_status("psam_swiglu_ln: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Max-pool over the K members of every group: x [groups*K, C] -> y [groups, C]     (common.py:502,505)
+// ------------------------------------------------------------------------------------------------
+__global__ void group_max_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int64_t groups, int K, int C) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * C) return;
+    const int64_t g = t / C;
+    const int c = (int)(t % C);
+    const float* p = x + g * K * ldx + c;
+    float m = p[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, p[(int64_t)k * ldx]);
+    y[g * ldy + c] = m;
+}
+
+PSAM_API int32_t psam_group_max(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t groups, int32_t K, int32_t C, hipStream_t stream) {
+    PSAM_REQUIRE(x && y, PSAM_EINVAL, "psam_group_max: null pointer");
+    PSAM_REQUIRE(groups > 0 && K > 0 && C > 0, PSAM_EINVAL, "psam_group_max: bad shape");
+    hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)psam_cdiv(groups * C, 256)), dim3(256), 0, stream, x, ldx, y, ldy, groups, K, C);
+    return psam_launch_status("psam_group_max: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// pos_embed first layer: y[r, 0:128] = GELU(W[128,3] @ centers[r] + bias)                (pc_encoder.py:102-104)
+// ------------------------------------------------------------------------------------------------
+__global__ void pos_l1_kernel(const float* __restrict__ c, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ y,
+                              int64_t rows) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * 128) return;
+    const int64_t r = t >> 7;
+    const int j = (int)(t & 127);
+    const float* p = c + r * 3;
+    y[t] = gelu_erf(fmaf(W[j * 3 + 2], p[2], fmaf(W[j * 3 + 1], p[1], fmaf(W[j * 3], p[0], bias[j]))));
+}
+
+PSAM_API int32_t psam_pos_l1(const float* centers, const float* W, const float* bias, float* y, int64_t rows, hipStream_t stream) {
+    PSAM_REQUIRE(centers && W && bias && y && rows > 0, PSAM_EINVAL, "psam_pos_l1: bad argument");
+    hipLaunchKernelGGL(pos_l1_kernel, dim3((unsigned)psam_cdiv(rows * 128, 256)), dim3(256), 0, stream, centers, W, bias, y, rows);
+    return psam_launch_status("psam_pos_l1: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Random-Fourier positional encoding (+ optional label embedding):                  (prompt_encoder.py:27-48,63-77)
+//   e = [sin(2*pi*x@Gm), cos(2*pi*x@Gm)]  (+ emb0 if label==0, + emb1 if label==1)
+// Row r is written to out + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * 2F (token assembly).
+// *flag is OR-ed with 1 if any coordinate is outside [-1-1e-6, 1+1e-6] (the reference raises ValueError).
+// ------------------------------------------------------------------------------------------------
+__global__ void fourier_pe_kernel(const float* __restrict__ x, const float* __restrict__ Gm, int F, const int64_t* __restrict__ labels,
+                                  const float* __restrict__ emb0, const float* __restrict__ emb1, float* __restrict__ out, int64_t rows,
+                                  int rows_per_batch, int64_t batch_stride, int* __restrict__ flag) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * F) return;
+    const int64_t r = t / F;
+    const int j = (int)(t % F);
+    const float px = x[r * 3], py = x[r * 3 + 1], pz = x[r * 3 + 2];
+    if (j == 0 && flag) {
+        const float lo = -1.0f - 1e-6f, hi = 1.0f + 1e-6f;
+        if (px < lo || py < lo || pz < lo || px > hi || py > hi || pz > hi) atomicOr(flag, 1);
+    }
+    // (x @ Gm) accumulated in the order of a 3-term dot product, then * 2*pi in fp32 like the reference
+    float v = px * Gm[j];
+    v = fmaf(py, Gm[F + j], v);
+    v = fmaf(pz, Gm[2 * F + j], v);
+    v = 6.283185307179586f * v;
+    float s = sinf(v), c = cosf(v);
+    if (labels) {
+        const int64_t lab = labels[r];
+        if (lab == 0) { s += emb0[j]; c += emb0[F + j]; }
+        else if (lab == 1) { s += emb1[j]; c += emb1[F + j]; }
+    }
+    float* o = out + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * (2 * F);
+    o[j] = s;
+    o[F + j] = c;
+}
+
+PSAM_API int32_t psam_fourier_pe(const float* coords, const float* gauss, int32_t F, const int64_t* labels, const float* emb0, const float* emb1,
+                                 float* out, int64_t rows, int32_t rows_per_batch, int64_t batch_stride, int32_t* flag, hipStream_t stream) {
+    PSAM_REQUIRE(coords && gauss && out && rows > 0 && F > 0 && rows_per_batch > 0, PSAM_EINVAL, "psam_fourier_pe: bad argument");
+    PSAM_REQUIRE(!labels || (emb0 && emb1), PSAM_EINVAL, "psam_fourier_pe: labels need both embeddings");
+    hipLaunchKernelGGL(fourier_pe_kernel, dim3((unsigned)psam_cdiv(rows * F, 256)), dim3(256), 0, stream, coords, gauss, F, labels, emb0, emb1,
+                       out, rows, rows_per_batch, batch_stride, flag);
+    return psam_launch_status("psam_fourier_pe: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[z, r, :] = a[(z / rep), r, :] + (b ? b[z*sb + r*ldb + :] : 0)      rows R, cols C (C % 4 == 0)
+// Covers: src = repeat_interleave(pc_embeddings) + dense (mask_decoder.py:136-139), q = queries + query_pe,
+// k = keys + key_pe (transformer.py:153-170), and plain broadcast copies (b == null).
+// sb == 0 && ldb == 0 broadcasts one row vector (no_mask_embed, prompt_encoder.py:119-122).
+// ------------------------------------------------------------------------------------------------
+__global__ void add_bcast_kernel(const float* __restrict__ a, int64_t sa, int rep, const float* __restrict__ b, int64_t sb, int64_t ldb,
+                                 float* __restrict__ out, int64_t so, int64_t Z, int64_t R, int C4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Z * R * C4) return;
+    const int c = (int)(t % C4);
+    const int64_t r = (t / C4) % R;
+    const int64_t z = t / ((int64_t)C4 * R);
+    f32x4 v = reinterpret_cast<const f32x4*>(a + (z / rep) * sa + r * C4 * 4)[c];
+    if (b) v += reinterpret_cast<const f32x4*>(b + z * sb + r * ldb)[c];
+    reinterpret_cast<f32x4*>(out + z * so + r * C4 * 4)[c] = v;
+}
+
+PSAM_API int32_t psam_add_bcast(const float* a, int64_t sa, int32_t rep, const float* b, int64_t sb, int64_t ldb, float* out, int64_t so,
+                                int64_t Z, int64_t R, int32_t C, hipStream_t stream) {
+    PSAM_REQUIRE(a && out && Z > 0 && R > 0 && C > 0 && rep > 0, PSAM_EINVAL, "psam_add_bcast: bad argument");
+    PSAM_REQUIRE((C & 3) == 0 && (sa & 3) == 0 && (sb & 3) == 0 && (ldb & 3) == 0 && (so & 3) == 0 && ((uintptr_t)a & 15) == 0 &&
+                     ((uintptr_t)out & 15) == 0 && ((uintptr_t)b & 15) == 0,
+                 PSAM_EALIGN, "psam_add_bcast: needs C, strides multiples of 4 and 16-byte aligned pointers");
+    hipLaunchKernelGGL(add_bcast_kernel, dim3((unsigned)psam_cdiv(Z * R * (C / 4), 256)), dim3(256), 0, stream, a, sa, rep, b, sb, ldb, out, so,
+                       Z, R, C / 4);
+    return psam_launch_status("psam_add_bcast: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// interpolate_features (common.py:258-274): out[z, n, :] = sum_k w3[b,n,k] * src[z, idx3[b,n,k], :], b = z / rep.
+// One wave per point, float4 per lane (C == 256).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx3, const float* __restrict__ w3,
+                                                      float* __restrict__ out, int rep, int64_t Z, int N, int G, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wv >= Z * N) return;
+    const int64_t z = wv / N, n = wv % N, b = z / rep;
+    const int64_t o = (b * N + n) * 3;
+    const int64_t i0 = idx3[o], i1 = idx3[o + 1], i2 = idx3[o + 2];
+    const float w0 = w3[o], w1 = w3[o + 1], w2 = w3[o + 2];
+    const float* s = src + z * (int64_t)G * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s + i0 * C + c);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(s + i1 * C + c);
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(s + i2 * C + c);
+        // same association as (x*w).sum(-2): ((a*w0) + b*w1) + c*w2
+        f32x4 v = a * w0;
+        v = v + bb * w1;
+        v = v + cc * w2;
+        *reinterpret_cast<f32x4*>(out + (z * N + n) * C + c) = v;
+    }
+}
+
+PSAM_API int32_t psam_interp3(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G,
+                              int32_t C, hipStream_t stream) {
+    PSAM_REQUIRE(src && idx3 && w3 && out && rep > 0 && Z > 0 && N > 0 && G > 0 && C > 0, PSAM_EINVAL, "psam_interp3: bad argument");
+    PSAM_REQUIRE((C & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0, PSAM_EALIGN, "psam_interp3: C % 4 and 16B alignment");
+    hipLaunchKernelGGL(interp3_kernel, dim3((unsigned)psam_cdiv(Z * N, 4)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, C);
+    return psam_launch_status("psam_interp3: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small multi-head attention for the decoder's token-sized problems (transformer.py:214-236): softmax(q k^T / sqrt(hd)) v.
+// One wave per (batch, head, query).  q/k/v/out are [Z, L, H*hd] with explicit row strides; keys are scored one per
+// lane, probabilities parked in LDS, then lanes own output channels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_small_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq, const float* __restrict__ k,
+                                                              int64_t ldk, int64_t sk, const float* __restrict__ v, int64_t ldv, int64_t sv,
+                                                              float* __restrict__ out, int64_t ldo, int64_t so, int64_t Z, int H, int Lq, int Lk,
+                                                              int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float s_p[];  // [4 waves][Lk]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + wave;
+    if (wv >= Z * H * Lq) return;
+    const int qi = (int)(wv % Lq);
+    const int hh = (int)((wv / Lq) % H);
+    const int64_t z = wv / ((int64_t)Lq * H);
+    const float* qp = q + z * sq + (int64_t)qi * ldq + hh * hd;
+    const float* kp = k + z * sk + hh * hd;
+    const float* vp = v + z * sv + hh * hd;
+    float* p = s_p + wave * Lk;
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) {
+        const float* kr = kp + (int64_t)j * ldk;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(qp[d], kr[d], s);
+        s *= scale;
+        p[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < Lk; j += 64) { const float e = __expf(p[j] - m); p[j] = e; l += e; }
+    l = wave_sum(l);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const float invl = 1.0f / l;
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < Lk; ++j) acc = fmaf(p[j], vp[(int64_t)j * ldv + d], acc);
+        out[z * so + (int64_t)qi * ldo + hh * hd + d] = acc * invl;
+    }
+}
+
+PSAM_API int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v,
+                                      int64_t ldv, int64_t sv, float* out, int64_t ldo, int64_t so, int64_t Z, int32_t H, int32_t Lq, int32_t Lk,
+                                      int32_t hd, float scale, hipStream_t stream) {
+    PSAM_REQUIRE(q && k && v && out && Z > 0 && H > 0 && Lq > 0 && Lk > 0 && hd > 0, PSAM_EINVAL, "psam_attention_small: bad argument");
+    PSAM_REQUIRE((size_t)Lk * 16 <= 128 * 1024, PSAM_EINVAL, "psam_attention_small: Lk too large");
+    const int64_t waves = Z * H * Lq;
+    hipLaunchKernelGGL(attention_small_kernel, dim3((unsigned)psam_cdiv(waves, 4)), dim3(256), (size_t)Lk * 16, stream, q, ldq, sq, k, ldk, sk, v,
+                       ldv, sv, out, ldo, so, Z, H, Lq, Lk, hd, scale);
+    return psam_launch_status("psam_attention_small: launch failed");
+}

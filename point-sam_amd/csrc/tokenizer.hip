@@ -1,0 +1,474 @@
+// Point tokenizer kernels for gfx950: farthest point sampling, kNN grouping, 3-NN interpolation weights,
+// neighbourhood gather and the first (tiny-K) layer of the per-group mini-PointNet.
+//
+// Reference semantics (file:line under /root/reference):
+//   FPS            pc_sam/model/common.py:91  (torkit3d.sample_farthest_points; third party, absent)
+//   center gather  pc_sam/model/common.py:92  (torkit3d batch_index_select)
+//   kNN            pc_sam/model/common.py:27-56,97 (torch.cdist + topk)
+//   grouping       pc_sam/model/common.py:99-120
+//   3-NN weights   pc_sam/model/common.py:238-255
+// Numerical spec = oracle/tokenizer_oracle.c: fp32 d = (dx*dx + dy*dy) + dz*dz without FMA contraction,
+// ties broken by lowest index.  This file is compiled with -ffp-contract=off and additionally uses the
+// explicitly rounded intrinsics in dist2_exact().
+#include "common.h"
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------------
+// FPS.  One 1024-thread workgroup per cloud (G dependent iterations; per iteration one block-wide
+// arg-max).  Coordinates are re-laid out once as planar x[] y[] z[] (float4-coalesced loads); the running
+// min-distance lives in registers (N <= 32768) or in the workspace (larger N).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int FPS_THREADS = 1024;
+constexpr int FPS_WAVES = FPS_THREADS / WAVE;
+
+static inline int64_t fps_npad(int64_t N) { return psam_cdiv(N, 4 * FPS_THREADS) * (4 * FPS_THREADS); }
+
+__global__ void fps_soa_kernel(const float* __restrict__ xyz, int N, int64_t npad, float* __restrict__ ws) {
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= npad) return;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (n < N) {
+        const float* p = xyz + ((int64_t)b * N + n) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+    }
+    float* base = ws + (int64_t)b * 3 * npad;
+    base[n] = x;
+    base[npad + n] = y;
+    base[2 * npad + n] = z;
+}
+
+// PPT4 = float4 groups per thread held in registers (0 => min-distance array streamed through `mdg`).
+template <int PPT4>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, const float* __restrict__ soa,
+                                                          float* __restrict__ mdg, int N, int64_t npad, int G,
+                                                          int64_t* __restrict__ idx_out, float* __restrict__ centers_out) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* P = xyz + (int64_t)b * N * 3;
+    // Planar coordinates are read through a buffer descriptor: address = SGPR base + SGPR plane/group offset +
+    // one per-lane VGPR offset, so the 24 loads of an iteration need no per-load address registers (a 1024-thread
+    // workgroup leaves only 128 VGPRs per lane, 32 of which hold the running min-distances).
+    const float* soa_b = soa + (int64_t)b * 3 * npad;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)soa_b, 0, (int)(3 * npad * 4), 0x00020000);
+    const int plane_bytes = (int)(npad * 4);
+    const int voff = tid * 16;
+    float4* MD4 = reinterpret_cast<float4*>(mdg + (int64_t)b * npad);
+    const int ngroups = (int)(npad / (4 * FPS_THREADS));
+
+    __shared__ float s_val[2][FPS_WAVES];
+    __shared__ int s_idx[2][FPS_WAVES];
+
+    constexpr int NREG = PPT4 > 0 ? PPT4 : 1;
+    float4 md[NREG];
+    if (PPT4 > 0) {
+#pragma unroll
+        for (int g = 0; g < NREG; ++g) {
+            const int base = (g * FPS_THREADS + tid) * 4;
+            md[g].x = base + 0 < N ? INFINITY : -1.0f;  // padding never wins: real min-distances are >= 0
+            md[g].y = base + 1 < N ? INFINITY : -1.0f;
+            md[g].z = base + 2 < N ? INFINITY : -1.0f;
+            md[g].w = base + 3 < N ? INFINITY : -1.0f;
+        }
+    } else {
+        for (int g = 0; g < ngroups; ++g) {
+            const int base = (g * FPS_THREADS + tid) * 4;
+            float4 m;
+            m.x = base + 0 < N ? INFINITY : -1.0f;
+            m.y = base + 1 < N ? INFINITY : -1.0f;
+            m.z = base + 2 < N ? INFINITY : -1.0f;
+            m.w = base + 3 < N ? INFINITY : -1.0f;
+            MD4[g * FPS_THREADS + tid] = m;
+        }
+    }
+
+    int last = 0;
+    if (tid == 0) idx_out[(int64_t)b * G] = 0;
+    if (tid < 3) centers_out[(int64_t)b * G * 3 + tid] = P[tid];
+
+    for (int j = 1; j < G; ++j) {
+        const float cx = P[(int64_t)last * 3 + 0], cy = P[(int64_t)last * 3 + 1], cz = P[(int64_t)last * 3 + 2];
+        float best = -1.0f;
+        int besti = 0x7fffffff;
+        auto visit = [&](float4& m, int g) {
+            const int goff = g * (FPS_THREADS * 16);
+            const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, goff, 0));
+            const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, goff + plane_bytes, 0));
+            const f32x4 z = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, goff + 2 * plane_bytes, 0));
+            const int base = (g * FPS_THREADS + tid) * 4;
+            float d;
+            d = dist2_exact(x.x, y.x, z.x, cx, cy, cz); m.x = fminf(m.x, d); if (m.x > best) { best = m.x; besti = base; }
+            d = dist2_exact(x.y, y.y, z.y, cx, cy, cz); m.y = fminf(m.y, d); if (m.y > best) { best = m.y; besti = base + 1; }
+            d = dist2_exact(x.z, y.z, z.z, cx, cy, cz); m.z = fminf(m.z, d); if (m.z > best) { best = m.z; besti = base + 2; }
+            d = dist2_exact(x.w, y.w, z.w, cx, cy, cz); m.w = fminf(m.w, d); if (m.w > best) { best = m.w; besti = base + 3; }
+        };
+        if (PPT4 > 0) {
+#pragma unroll
+            for (int g = 0; g < NREG; ++g) {
+                visit(md[g], g);
+                // keep at most two float4 groups of loads in flight: the 1024-thread block caps a wave at 128 VGPRs
+                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int g = 0; g < ngroups; ++g) {
+                float4 m = MD4[g * FPS_THREADS + tid];
+                visit(m, g);
+                MD4[g * FPS_THREADS + tid] = m;
+            }
+        }
+        // wave arg-max, lowest index on ties
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        const int slot = j & 1;
+        if (lane == 0) { s_val[slot][wave] = best; s_idx[slot][wave] = besti; }
+        __syncthreads();
+        float v = lane < FPS_WAVES ? s_val[slot][lane] : -2.0f;
+        int vi = lane < FPS_WAVES ? s_idx[slot][lane] : 0x7fffffff;
+#pragma unroll
+        for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(vi, o, 64);
+            if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+        }
+        last = __builtin_amdgcn_readfirstlane(vi);
+        if (tid == 0) idx_out[(int64_t)b * G + j] = last;
+        if (tid < 3) centers_out[((int64_t)b * G + j) * 3 + tid] = P[(int64_t)last * 3 + tid];
+    }
+}
+
+PSAM_API size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G) {
+    (void)G;
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float);  // planar xyz (3) + streamed min-distance (1)
+}
+
+// xyz [B,N,3] f32 -> fps_idx [B,G] i64 (start index 0), centers [B,G,3] f32 (fused batch_index_select).
+PSAM_API int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws,
+                          size_t ws_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(xyz && fps_idx && centers && ws, PSAM_EINVAL, "psam_fps: null pointer");
+    PSAM_REQUIRE(B > 0 && N > 0 && G > 0 && G <= N, PSAM_EINVAL, "psam_fps: need B>0, 0<G<=N");
+    PSAM_REQUIRE((int64_t)N <= (int64_t)1 << 30, PSAM_EINVAL, "psam_fps: N too large");
+    PSAM_REQUIRE(ws_bytes >= psam_fps_workspace_bytes(B, N, G), PSAM_EWORKSPACE, "psam_fps: workspace too small");
+    PSAM_REQUIRE(((uintptr_t)ws & 15) == 0, PSAM_EALIGN, "psam_fps: workspace must be 16-byte aligned");
+    const int64_t npad = fps_npad(N);
+    float* soa = (float*)ws;
+    float* mdg = soa + (int64_t)B * 3 * npad;
+    hipLaunchKernelGGL(fps_soa_kernel, dim3((unsigned)psam_cdiv(npad, 256), B), dim3(256), 0, stream, xyz, N, npad, soa);
+    const int groups = (int)(npad / (4 * FPS_THREADS));
+#define FPS_LAUNCH(P) \
+    hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, soa, mdg, N, npad, G, fps_idx, centers)
+    switch (groups) {
+        case 1: FPS_LAUNCH(1); break;
+        case 2: FPS_LAUNCH(2); break;
+        case 3: FPS_LAUNCH(3); break;
+        case 4: FPS_LAUNCH(4); break;
+        case 5: FPS_LAUNCH(5); break;
+        case 6: FPS_LAUNCH(6); break;
+        case 7: FPS_LAUNCH(7); break;
+        case 8: FPS_LAUNCH(8); break;
+        default: FPS_LAUNCH(0); break;
+    }
+#undef FPS_LAUNCH
+    return psam_launch_status("psam_fps: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN: for each center the K nearest points, ascending by (d2, index).  One 256-thread workgroup per
+// center: 3-pass radix select on the fp32 bit pattern of d2 (11+11+10 bits) finds the exact K-th smallest
+// value, a 4th pass collects, a bitonic sort orders.  The distance matrix is never materialised.
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_MAXK = 1024;
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int* s_wave, int& total) {
+    // exclusive scan over 256 threads (4 waves); s_wave: 4 ints of LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < KNN_THREADS / 64; ++w) {
+        const int t = s_wave[w];
+        if (w < wave) off += t;
+        total += t;
+    }
+    __syncthreads();
+    return off + inc - v;
+}
+
+__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ centers, const float* __restrict__ xyz,
+                                                          int G, int N, int K, int64_t* __restrict__ out_idx) {
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* P = xyz + (int64_t)b * N * 3;
+    const float* c = centers + ((int64_t)b * G + g) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long keys[KNN_MAXK];
+    __shared__ int s_wave[4];
+    __shared__ int s_bin, s_below, s_cnt_less, s_cnt_eq;
+
+    unsigned prefix_mask = 0, prefix_val = 0;
+    int remaining = K;  // rank (1-based) of the K-th smallest inside the current candidate set
+    int eq_total = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+        const int nb = pass == 2 ? 1024 : 2048;
+        for (int i = tid; i < 2048; i += KNN_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int n = tid; n < N; n += KNN_THREADS) {
+            const float d = dist2_exact(cx, cy, cz, P[n * 3 + 0], P[n * 3 + 1], P[n * 3 + 2]);
+            const unsigned u = __float_as_uint(d);
+            if ((u & prefix_mask) == prefix_val) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        // locate the bin that holds rank `remaining`
+        int loc[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { loc[i] = (int)hist[tid * 8 + i]; sum += loc[i]; }
+        int total;
+        int before = block_excl_scan_256(sum, s_wave, total);
+        if (remaining > before && remaining <= before + sum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (remaining > before && remaining <= before + loc[i]) { s_bin = tid * 8 + i; s_below = before; }
+                before += loc[i];
+            }
+        }
+        __syncthreads();
+        const int bin = s_bin;
+        remaining -= s_below;
+        eq_total = (int)hist[bin];
+        prefix_val |= (unsigned)bin << shift;
+        prefix_mask |= (unsigned)(nb - 1) << shift;
+        __syncthreads();
+    }
+    const unsigned T = prefix_val;     // bit pattern of the K-th smallest d2
+    const int need_eq = remaining;     // how many of the points with d2 == T belong to the answer (lowest indices)
+    const int n_less = K - need_eq;
+    if (tid == 0) { s_cnt_less = 0; s_cnt_eq = 0; }
+    __syncthreads();
+    if (eq_total == need_eq) {
+        // no truncation among ties: unordered collection
+        for (int n = tid; n < N; n += KNN_THREADS) {
+            const float d = dist2_exact(cx, cy, cz, P[n * 3 + 0], P[n * 3 + 1], P[n * 3 + 2]);
+            const unsigned u = __float_as_uint(d);
+            if (u < T) {
+                const int p = atomicAdd(&s_cnt_less, 1);
+                keys[p] = ((unsigned long long)u << 32) | (unsigned)n;
+            } else if (u == T) {
+                const int p = atomicAdd(&s_cnt_eq, 1);
+                keys[n_less + p] = ((unsigned long long)u << 32) | (unsigned)n;
+            }
+        }
+    } else {
+        // ties at the K-th distance must be cut: take the lowest indices -> index-ordered sweep
+        int eq_taken = 0;
+        for (int n0 = 0; n0 < N; n0 += KNN_THREADS) {
+            const int n = n0 + tid;
+            unsigned u = 0xffffffffu;
+            if (n < N) u = __float_as_uint(dist2_exact(cx, cy, cz, P[n * 3 + 0], P[n * 3 + 1], P[n * 3 + 2]));
+            if (u < T) {
+                const int p = atomicAdd(&s_cnt_less, 1);
+                keys[p] = ((unsigned long long)u << 32) | (unsigned)n;
+            }
+            int total;
+            const int is_eq = (u == T) ? 1 : 0;
+            const int rank = block_excl_scan_256(is_eq, s_wave, total);
+            if (is_eq && eq_taken + rank < need_eq) keys[n_less + eq_taken + rank] = ((unsigned long long)u << 32) | (unsigned)n;
+            eq_taken += total;
+        }
+    }
+    // bitonic sort of K keys padded to a power of two
+    int P2 = 1;
+    while (P2 < K) P2 <<= 1;
+    __syncthreads();
+    for (int i = K + tid; i < P2; i += KNN_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < P2; i += KNN_THREADS) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], bb = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > bb) == up) { keys[i] = bb; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int64_t* out = out_idx + ((int64_t)b * G + g) * K;
+    for (int i = tid; i < K; i += KNN_THREADS) out[i] = (int64_t)(keys[i] & 0xffffffffull);
+}
+
+// centers [B,G,3], xyz [B,N,3] -> knn_idx [B,G,K] i64 ascending by (squared distance, index).
+PSAM_API int32_t psam_knn(const float* centers, const float* xyz, int32_t B, int32_t G, int32_t N, int32_t K, int64_t* knn_idx,
+                          hipStream_t stream) {
+    PSAM_REQUIRE(centers && xyz && knn_idx, PSAM_EINVAL, "psam_knn: null pointer");
+    PSAM_REQUIRE(B > 0 && G > 0 && N > 0 && K > 0 && K <= N, PSAM_EINVAL, "psam_knn: need 0<K<=N");
+    PSAM_REQUIRE(K <= KNN_MAXK, PSAM_EINVAL, "psam_knn: K > 1024 unsupported");
+    PSAM_REQUIRE(B <= 65535, PSAM_EINVAL, "psam_knn: B > 65535 unsupported");
+    hipLaunchKernelGGL(knn_kernel, dim3(G, B), dim3(KNN_THREADS), 0, stream, centers, xyz, G, N, K, knn_idx);
+    return psam_launch_status("psam_knn: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-NN of every point among the G centers + inverse-squared-distance weights (common.py:238-255).
+// Centers are staged in LDS (broadcast reads); one thread per point.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__ xyz, const float* __restrict__ centers, int N, int G,
+                                                       float eps, int64_t* __restrict__ idx3, float* __restrict__ w3) {
+    extern __shared__ __attribute__((aligned(16))) float s_c[];
+    const int b = blockIdx.y;
+    const float* C = centers + (int64_t)b * G * 3;
+    for (int i = threadIdx.x; i < G * 3; i += blockDim.x) s_c[i] = C[i];
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* p = xyz + ((int64_t)b * N + n) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = -1, i1 = -1, i2 = -1;
+    for (int g = 0; g < G; ++g) {
+        const float d = dist2_exact(px, py, pz, s_c[g * 3 + 0], s_c[g * 3 + 1], s_c[g * 3 + 2]);
+        if (d < d2) {  // strict: equal distance keeps the earlier (lower) center index
+            if (d < d1) {
+                d2 = d1; i2 = i1;
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = g; }
+                else { d1 = d; i1 = g; }
+            } else { d2 = d; i2 = g; }
+        }
+    }
+    // dist = sqrt(d2); w = 1/max(dist*dist, eps), normalised: correctly rounded sqrt and divide (hipcc default),
+    // no contraction (translation unit is built with -ffp-contract=off) => bit-identical to the C oracle.
+    float s0 = sqrtf(d0), s1 = sqrtf(d1), s2 = sqrtf(d2);
+    s0 = s0 * s0; s1 = s1 * s1; s2 = s2 * s2;
+    const float v0 = 1.0f / fmaxf(s0, eps), v1 = 1.0f / fmaxf(s1, eps), v2 = 1.0f / fmaxf(s2, eps);
+    float s = v0 + v1;
+    s = s + v2;
+    const int64_t o = ((int64_t)b * N + n) * 3;
+    idx3[o + 0] = i0; idx3[o + 1] = i1; idx3[o + 2] = i2;
+    w3[o + 0] = v0 / s; w3[o + 1] = v1 / s; w3[o + 2] = v2 / s;
+}
+
+PSAM_API int32_t psam_three_nn(const float* xyz, const float* centers, int32_t B, int32_t N, int32_t G, float eps, int64_t* idx3,
+                               float* w3, hipStream_t stream) {
+    PSAM_REQUIRE(xyz && centers && idx3 && w3, PSAM_EINVAL, "psam_three_nn: null pointer");
+    PSAM_REQUIRE(B > 0 && N > 0 && G >= 3, PSAM_EINVAL, "psam_three_nn: need G>=3");
+    PSAM_REQUIRE((size_t)G * 12 <= 144 * 1024, PSAM_EINVAL, "psam_three_nn: G too large for LDS staging");
+    PSAM_REQUIRE(B <= 65535, PSAM_EINVAL, "psam_three_nn: B > 65535 unsupported");
+    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)psam_cdiv(N, 256), B), dim3(256), (size_t)G * 12, stream, xyz, centers, N, G,
+                       eps, idx3, w3);
+    return psam_launch_status("psam_three_nn: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Neighbourhood gather: out[b,g,k,:] = [xyz[idx]-center, feats[idx]]   (common.py:99-120, radius=None)
+// `feats` is [BF, N, C] with BF = B*rep (rep>1: several per-cloud feature sets share one knn_idx,
+// as group_with_centers_and_knn does for mask logits, common.py:126-187).
+// ------------------------------------------------------------------------------------------------
+__global__ void group_gather_kernel(const float* __restrict__ xyz, const float* __restrict__ feats, const float* __restrict__ centers,
+                                    const int64_t* __restrict__ knn_idx, int rep, int N, int G, int K, int C, int64_t total,
+                                    float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t row = t;  // (bf, g, k)
+    const int k = (int)(row % K);
+    const int g = (int)((row / K) % G);
+    const int64_t bf = row / ((int64_t)K * G);
+    const int64_t b = bf / rep;
+    const int64_t n = knn_idx[(b * G + g) * K + k];
+    const float* p = xyz + (b * N + n) * 3;
+    const float* c = centers + (b * G + g) * 3;
+    float* o = out + row * (3 + C);
+    o[0] = p[0] - c[0]; o[1] = p[1] - c[1]; o[2] = p[2] - c[2];
+    const float* f = feats + (bf * N + n) * C;
+    for (int i = 0; i < C; ++i) o[3 + i] = f[i];
+}
+
+PSAM_API int32_t psam_group_gather(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
+                                   int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float* out, hipStream_t stream) {
+    PSAM_REQUIRE(xyz && feats && centers && knn_idx && out, PSAM_EINVAL, "psam_group_gather: null pointer");
+    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0 && C > 0, PSAM_EINVAL, "psam_group_gather: bad shape");
+    const int64_t total = (int64_t)B * rep * G * K;
+    hipLaunchKernelGGL(group_gather_kernel, dim3((unsigned)psam_cdiv(total, 256)), dim3(256), 0, stream, xyz, feats, centers, knn_idx,
+                       rep, N, G, K, C, total, out);
+    return psam_launch_status("psam_group_gather: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// First mini-PointNet layer fused with the gather: rows = (bf,g,k);
+//   h = GELU(LayerNorm_128(W[128,3+C] @ [xyz[idx]-center, feats[idx]] + bias))       (common.py:486-489,499)
+// One wave per row, two channels per lane; weights live in registers.
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__ xyz, const float* __restrict__ feats,
+                                                       const float* __restrict__ centers, const int64_t* __restrict__ knn_idx,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, int rep,
+                                                       int N, int G, int K, int64_t rows, float* __restrict__ out) {
+    constexpr int C = CIN - 3;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float w0[CIN], w1[CIN];
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) { w0[i] = W[lane * CIN + i]; w1[i] = W[(lane + 64) * CIN + i]; }
+    const float b0 = bias[lane], b1 = bias[lane + 64];
+    const float g0 = lnw[lane], g1 = lnw[lane + 64], e0 = lnb[lane], e1 = lnb[lane + 64];
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        const int k = (int)(row % K);
+        const int g = (int)((row / K) % G);
+        const int64_t bf = row / ((int64_t)K * G);
+        const int64_t b = bf / rep;
+        const int64_t n = knn_idx[(b * G + g) * K + k];
+        const float* p = xyz + (b * N + n) * 3;
+        const float* c = centers + (b * G + g) * 3;
+        float in[CIN];
+        in[0] = p[0] - c[0]; in[1] = p[1] - c[1]; in[2] = p[2] - c[2];
+        const float* f = feats + (bf * N + n) * C;
+#pragma unroll
+        for (int i = 0; i < C; ++i) in[3 + i] = f[i];
+        float y0 = b0, y1 = b1;
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) { y0 = fmaf(w0[i], in[i], y0); y1 = fmaf(w1[i], in[i], y1); }
+        const float mean = wave_sum(y0 + y1) * (1.0f / 128.0f);
+        const float a0 = y0 - mean, a1 = y1 - mean;
+        const float var = wave_sum(a0 * a0 + a1 * a1) * (1.0f / 128.0f);
+        const float r = 1.0f / sqrtf(var + eps);
+        out[row * 128 + lane] = gelu_erf(a0 * r * g0 + e0);
+        out[row * 128 + lane + 64] = gelu_erf(a1 * r * g1 + e1);
+    }
+}
+
+// W [128, 3+C] (nn.Linear layout), bias/lnw/lnb [128]; out [B*rep*G*K, 128].  C in {1, 3}.
+PSAM_API int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,
+                               const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
+                               int32_t G, int32_t K, int32_t C, float* out, hipStream_t stream) {
+    PSAM_REQUIRE(xyz && feats && centers && knn_idx && W && bias && lnw && lnb && out, PSAM_EINVAL, "psam_patch_l1: null pointer");
+    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0, PSAM_EINVAL, "psam_patch_l1: bad shape");
+    PSAM_REQUIRE(C == 1 || C == 3, PSAM_EINVAL, "psam_patch_l1: C must be 1 (mask logit) or 3 (rgb)");
+    const int64_t rows = (int64_t)B * rep * G * K;
+    const int64_t blocks = rows / 4 < 8192 ? (rows + 3) / 4 : 8192;
+#define L1_LAUNCH(CIN)                                                                                                              \
+    hipLaunchKernelGGL(patch_l1_kernel<CIN>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, feats, centers, knn_idx, W, bias, lnw, \
+                       lnb, eps, rep, N, G, K, rows, out)
+    if (C == 3) L1_LAUNCH(6); else L1_LAUNCH(4);
+#undef L1_LAUNCH
+    return psam_launch_status("psam_patch_l1: launch failed");
+}

@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference model interface for the inference hot path, executing on the HIP library.
+
+Mirrors (same names, argument meaning, return values, error behaviour):
+  pc_sam/model/pc_sam.py:20-88      PointCloudSAM.predict_masks
+  pc_sam/model/pc_sam.py:112-194    the encoder-once / decoder-per-click data flow (``encode`` + ``decode``)
+  evaluation/eval_kitti.py:352-362  run-time mutation of ``model.pc_encoder.patch_embed.grouper.{num_groups,group_size}``
+
+Python here only sequences kernel launches and owns buffers (torch tensors); all arithmetic is in
+csrc/libpointsam_hip.so.  There is no CPU path: tensors must be on the GPU.
+"""
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+
+from . import ops
+from .config import ModelConfig
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU
+from .weights import check_state_dict
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class EncoderState:
+    """What the reference keeps between encoder and decoder: the ``patches`` dict (common.py:121-123) and
+    ``AuxInputs`` (mask_decoder.py:12-18)."""
+    coords: torch.Tensor
+    features: torch.Tensor
+    pc_embeddings: torch.Tensor      # [B, G, E]
+    pc_pe: torch.Tensor              # [B, G, E]
+    centers: torch.Tensor            # [B, G, 3]
+    knn_idx: torch.Tensor            # [B, G, K] int64
+    fps_idx: torch.Tensor            # [B, G] int64
+    patch_embeddings: torch.Tensor   # [B, G, patch_out]
+    interp_index: Optional[torch.Tensor] = None   # [B, N, 3] int64 (cached after the first decode)
+    interp_weight: Optional[torch.Tensor] = None  # [B, N, 3]
+
+
+class PointCloudSAM:
+    """HIP implementation behind the reference's ``PointCloudSAM`` inference interface."""
+
+    def __init__(self, cfg: ModelConfig, state_dict, device="cuda"):
+        check_state_dict(cfg, state_dict)
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("point_sam_amd.PointCloudSAM runs on the GPU only (HIP kernels; no CPU fallback)")
+        ops._lib.load()  # fail loudly now if the HIP library is missing
+        self.prompt_iters = cfg.prompt_iters
+        # attribute tree the reference's callers mutate (evaluation/eval_kitti.py:353-362)
+        grouper = SimpleNamespace(num_groups=cfg.num_groups, group_size=cfg.group_size)
+        self.pc_encoder = SimpleNamespace(patch_embed=SimpleNamespace(grouper=grouper), embed_dim=cfg.embed_dim)
+        self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
+        self._pack()
+        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _pack(self):
+        w, cfg, D = self.w, self.cfg, self.cfg.vit.dim
+        self.blocks = []
+        for i in range(cfg.vit.depth):
+            p = f"pc_encoder.transformer.blocks.{i}"
+            blk = SimpleNamespace()
+            if cfg.vit.swiglu:
+                blk.wqkv = torch.cat([w[p + ".attn.q_proj.weight"], w[p + ".attn.k_proj.weight"], w[p + ".attn.v_proj.weight"]], 0).contiguous()
+                blk.bqkv = torch.cat([w[p + ".attn.q_proj.bias"], torch.zeros(D, device=self.device), w[p + ".attn.v_proj.bias"]]).contiguous()
+                H = cfg.vit.mlp_hidden
+                Hp = _round_up(H, 32)
+                w1 = torch.zeros(2 * Hp, D, device=self.device)
+                b1 = torch.zeros(2 * Hp, device=self.device)
+                w1[:H] = w[p + ".mlp.fc1_g.weight"]; w1[Hp:Hp + H] = w[p + ".mlp.fc1_x.weight"]
+                b1[:H] = w[p + ".mlp.fc1_g.bias"]; b1[Hp:Hp + H] = w[p + ".mlp.fc1_x.bias"]
+                w2 = torch.zeros(D, Hp, device=self.device)
+                w2[:, :H] = w[p + ".mlp.fc2.weight"]
+                blk.w1, blk.b1, blk.w2, blk.hp = w1, b1, w2, Hp
+            else:
+                blk.wqkv = w[p + ".attn.qkv.weight"]
+                blk.bqkv = torch.cat([w[p + ".attn.q_bias"], torch.zeros(D, device=self.device), w[p + ".attn.v_bias"]]).contiguous()
+                blk.w1, blk.b1, blk.w2 = w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], w[p + ".mlp.fc2.weight"]
+            blk.p = p
+            self.blocks.append(blk)
+        self.out_tokens = torch.cat([w["mask_decoder.iou_token.weight"], w["mask_decoder.mask_tokens.weight"]], 0).contiguous()
+
+    # ------------------------------------------------------------------------------------------ building blocks
+    def _lin(self, name, x, **kw):
+        return ops.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"), **kw)
+
+    def _ln(self, name, x, eps, **kw):
+        return ops.layernorm(x, self.w[name + ".weight"], self.w[name + ".bias"], eps, **kw)
+
+    def _patch_encoder(self, prefix, coords, feats, centers, knn_idx):
+        """PatchEncoder.forward on gathered groups (common.py:499-506) -> [B*rep*G, Cout]."""
+        w, eps = self.w, self.cfg.ln_eps
+        K = knn_idx.shape[2]
+        h0 = self.cfg.patch_hidden[0]
+        h1 = ops.patch_l1(coords, feats, centers, knn_idx, w[prefix + ".conv1.0.weight"], w[prefix + ".conv1.0.bias"],
+                          w[prefix + ".conv1.1.weight"], w[prefix + ".conv1.1.bias"], eps)
+        h2 = self._lin(prefix + ".conv1.3", h1)
+        del h1
+        y1 = ops.group_max(h2, K)
+        w2a = w[prefix + ".conv2.0.weight"]
+        # cat([max, x]) @ W^T = max @ W[:, :h0]^T (one row per group) + x @ W[:, h0:]^T
+        g1 = ops.linear(y1, w2a[:, :h0], w[prefix + ".conv2.0.bias"])
+        h3 = ops.linear(h2, w2a[:, h0:], None, rowbias=g1, rowgroup=K)
+        del h2
+        self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3)
+        h4 = self._lin(prefix + ".conv2.3", h3)
+        del h3
+        return ops.group_max(h4, K)
+
+    def _block(self, blk, x, B, L):
+        vit = self.cfg.vit
+        D, H, hd = vit.dim, vit.heads, vit.head_dim
+        p = blk.p
+        h = self._ln(p + ".norm1", x, vit.ln_eps)
+        qkv = ops.linear(h, blk.wqkv, blk.bqkv)
+        o = torch.empty_like(x)
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5)
+        self._lin(p + ".attn.proj", o, residual=x, out=x)
+        self._ln(p + ".norm2", x, vit.ln_eps, out=h)
+        if vit.swiglu:
+            gx = ops.linear(h, blk.w1, blk.b1)
+            g = torch.empty(x.shape[0], blk.hp, device=x.device)
+            ops.swiglu_ln(gx, blk.hp, vit.mlp_hidden, self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, g)
+            ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
+        else:
+            g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU)
+            ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
+        return x
+
+    # ------------------------------------------------------------------------------------------ encoder
+    @torch.no_grad()
+    def encode(self, coords: torch.Tensor, features: torch.Tensor) -> EncoderState:
+        """PointCloudEncoder.forward (pc_encoder.py:118-145) + pe_layer(centers) (pc_sam.py:59)."""
+        cfg, w = self.cfg, self.w
+        coords = coords.to(self.device, torch.float32).contiguous()
+        features = features.to(self.device, torch.float32).contiguous()
+        B, N, _ = coords.shape
+        g = self.pc_encoder.patch_embed.grouper
+        G, K = int(g.num_groups), int(g.group_size)
+        E = cfg.embed_dim
+        fps_idx, centers = ops.fps(coords, G)
+        knn_idx = ops.knn(centers, coords, K)
+        emb = self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, centers, knn_idx)
+        x = self._lin("pc_encoder.patch_proj", emb)
+        p1 = ops.pos_l1(centers, w["pc_encoder.pos_embed.0.weight"], w["pc_encoder.pos_embed.0.bias"])
+        self._lin("pc_encoder.pos_embed.2", p1, residual=x, out=x)
+        for blk in self.blocks:
+            x = self._block(blk, x, B, G)
+        h = self._ln("pc_encoder.transformer.fc_norm", x, cfg.vit.ln_eps)
+        pc_emb = self._lin("pc_encoder.out_proj", h).view(B, G, E)
+        pc_pe = torch.empty(B, G, E, device=self.device)
+        ops.fourier_pe(centers, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], pc_pe, G, G * E, flag=self._flag)
+        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1))
+
+    # ------------------------------------------------------------------------------------------ decoder
+    def _attn(self, prefix, q_in, k_in, v_in, Z, Lq, Lk):
+        """Attention.forward up to (not including) out_proj (transformer.py:214-234)."""
+        H = self.cfg.dec_heads
+        q = self._lin(prefix + ".q_proj", q_in)
+        k = self._lin(prefix + ".k_proj", k_in)
+        v = self._lin(prefix + ".v_proj", v_in)
+        inner = q.shape[1]
+        hd = inner // H
+        o = torch.empty(Z * Lq, inner, device=q.device)
+        return ops.attention_small(q, k, v, o, Z, H, Lq, Lk, hd, 1.0 / math.sqrt(hd))
+
+    def _two_way(self, src, pos, tokens, Z, G, T, rep):
+        """TwoWayTransformer.forward (transformer.py:61-100).  src [Z*G,E] (overwritten), pos [B,G,E], tokens [Z*T,E]."""
+        cfg, E, eps = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps
+        P = "mask_decoder.transformer"
+        queries, keys = tokens, src
+        q = torch.empty_like(tokens)
+        k = torch.empty_like(keys)
+        for i in range(cfg.dec_depth):
+            L = f"{P}.layers.{i}"
+            if i == 0:
+                a = self._attn(L + ".self_attn", queries, queries, queries, Z, T, T)
+                queries = self._ln(L + ".norm1", self._lin(L + ".self_attn.out_proj", a), eps)
+            else:
+                ops.add_bcast(queries, 1, tokens, q, Z, T, E)
+                a = self._attn(L + ".self_attn", q, q, queries, Z, T, T)
+                queries = self._ln(L + ".norm1", self._lin(L + ".self_attn.out_proj", a), eps, residual=queries)
+            ops.add_bcast(queries, 1, tokens, q, Z, T, E)
+            ops.add_bcast(pos, rep, keys, k, Z, G, E)
+            a = self._attn(L + ".cross_attn_token_to_image", q, k, keys, Z, T, G)
+            queries = self._ln(L + ".norm2", self._lin(L + ".cross_attn_token_to_image.out_proj", a), eps, residual=queries)
+            m = self._lin(L + ".mlp.lin2", self._lin(L + ".mlp.lin1", queries, act=ACT_RELU))
+            queries = self._ln(L + ".norm3", m, eps, residual=queries)
+            ops.add_bcast(queries, 1, tokens, q, Z, T, E)
+            a = self._attn(L + ".cross_attn_image_to_token", k, q, queries, Z, G, T)
+            keys = self._ln(L + ".norm4", self._lin(L + ".cross_attn_image_to_token.out_proj", a), eps, residual=keys)
+        ops.add_bcast(queries, 1, tokens, q, Z, T, E)
+        ops.add_bcast(pos, rep, keys, k, Z, G, E)
+        a = self._attn(P + ".final_attn_token_to_image", q, k, keys, Z, T, G)
+        queries = self._ln(P + ".norm_final_attn", self._lin(P + ".final_attn_token_to_image.out_proj", a), eps, residual=queries)
+        return queries, keys
+
+    def _mlp3(self, prefix, x, out=None):
+        h = self._lin(prefix + ".layers.0", x, act=ACT_RELU)
+        h = self._lin(prefix + ".layers.1", h, act=ACT_RELU)
+        return self._lin(prefix + ".layers.2", h, out=out)
+
+    @torch.no_grad()
+    def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True):
+        """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState."""
+        cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
+        B, N, _ = st.coords.shape
+        G = st.centers.shape[1]
+        prompt_coords = prompt_coords.to(self.device, torch.float32).contiguous()
+        if prompt_coords.shape[:-1] != prompt_labels.shape:  # prompt_encoder.py:73
+            raise AssertionError((tuple(prompt_coords.shape), tuple(prompt_labels.shape)))
+        prompt_labels = prompt_labels.to(self.device, torch.int64).contiguous()
+        Z, Pn, _ = prompt_coords.shape
+        if Z % B != 0:
+            raise ValueError(f"prompt batch {Z} is not a multiple of the cloud batch {B}")
+        rep = Z // B
+        nmt = cfg.num_mask_tokens
+        T = 1 + nmt + Pn
+        # tokens = [iou_token, mask_tokens, sparse prompt embeddings]   (mask_decoder.py:126-133)
+        tokens = torch.empty(Z, T, E, device=self.device)
+        ops.add_bcast(self.out_tokens, Z, None, tokens, Z, 1 + nmt, E, sa=0, so=T * E)
+        ops.fourier_pe(prompt_coords, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], tokens.view(-1)[(1 + nmt) * E:], Pn,
+                       T * E, labels=prompt_labels, emb0=w["point_encoder.point_embeddings.0.weight"],
+                       emb1=w["point_encoder.point_embeddings.1.weight"], flag=self._flag)
+        # src = repeat(pc_embeddings) + dense prompt embedding        (prompt_encoder.py:118-133, mask_decoder.py:136-139)
+        src = torch.empty(Z, G, E, device=self.device)
+        if prompt_masks is None:
+            ops.add_bcast(st.pc_embeddings, rep, w["mask_encoder.no_mask_embed.weight"], src, Z, G, E, sb=0, ldb=0)
+        else:
+            pm = prompt_masks.to(self.device, torch.float32).contiguous()
+            if pm.shape != (Z, N):
+                raise AssertionError((tuple(pm.shape), (Z, N)))
+            dense = self._patch_encoder("mask_encoder.patch_encoder", st.coords, pm.view(Z, N, 1), st.centers, st.knn_idx)
+            ops.add_bcast(st.pc_embeddings, rep, dense, src, Z, G, E)
+        hs, keys = self._two_way(src.view(Z * G, E), st.pc_pe, tokens.view(Z * T, E), Z, G, T, rep)
+        hs = hs.view(Z, T, E)
+        # upscale: 3-NN interpolation G -> N, MLP, hyper-network dot product    (mask_decoder.py:146-176)
+        if st.interp_index is None:
+            st.interp_index, st.interp_weight = ops.three_nn(st.coords, st.centers)
+        up = torch.empty(Z * N, E, device=self.device)
+        ops.interp3(keys.view(Z, G, E), st.interp_index, st.interp_weight, up, rep)
+        u1 = self._lin("mask_decoder.output_upscaling.0", up)
+        self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1)
+        self._lin("mask_decoder.output_upscaling.3", u1, act=ACT_GELU, out=up)
+        sel = list(range(1, nmt)) if multimask_output else [0]
+        C = len(sel)
+        hyper = torch.empty(Z, C, E, device=self.device)
+        for j, i in enumerate(sel):
+            self._mlp3(f"mask_decoder.output_hypernetworks_mlps.{i}", hs[:, 1 + i, :], out=hyper[:, j, :])
+        masks = torch.empty(Z, C, N, device=self.device)
+        ops.gemm_batched(hyper, up, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
+        iou = self._mlp3("mask_decoder.iou_prediction_head", hs[:, 0, :])
+        return masks, iou[:, sel[0]:sel[-1] + 1]
+
+    # ------------------------------------------------------------------------------------------ reference API
+    def check_coordinate_range(self):
+        """Raises the reference's ValueError (prompt_encoder.py:44-46) if any encoded coordinate left [-1, 1].
+        The kernels record the violation in a device flag; reading it is the one host sync of a call."""
+        if int(self._flag.item()) != 0:
+            self._flag.zero_()
+            raise ValueError("Input coordinates must be normalized to [-1, 1].")
+
+    @torch.no_grad()
+    def predict_masks(self, coords, features, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, validate=True):
+        """PointCloudSAM.predict_masks (pc_sam.py:37-88): (masks [B*M,C,N] logits, iou_preds [B*M,C])."""
+        st = self.encode(coords, features)
+        masks, iou = self.decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output)
+        if validate:
+            self.check_coordinate_range()
+        return masks, iou
+
+    __call__ = predict_masks
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self

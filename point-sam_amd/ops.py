@@ -1,0 +1,231 @@
+"""Thin torch-tensor wrappers over the C ABI (include/pointsam_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every computation is a kernel of
+libpointsam_hip.so launched on ``torch.cuda.current_stream()``.  Inputs must be CUDA(HIP) fp32 / int64
+tensors; there is no CPU path.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+# Measurement hook (bench.py): when set to a list, every GEMM launch is bracketed by two HIP events on the launch
+# stream and (start, end, flops, M, N, K) is appended.  None = no instrumentation.
+GEMM_PROFILE = None
+
+
+def _gemm_call(fn_args, flops, M, N, K, what):
+    L = _lib.load()
+    if GEMM_PROFILE is None:
+        check(L.psam_gemm_f32(*fn_args), what)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(L.psam_gemm_f32(*fn_args), what)
+    e.record()
+    GEMM_PROFILE.append((s, e, flops, M, N, K))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.PointSamHipError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+# ------------------------------------------------------------------------------------------ tokenizer
+def fps(xyz: torch.Tensor, num_samples: int):
+    """[B,N,3] -> (fps_idx [B,G] int64, centers [B,G,3]).  common.py:91-92."""
+    _chk(xyz, name="xyz")
+    B, N, _ = xyz.shape
+    L = _lib.load()
+    nbytes = L.psam_fps_workspace_bytes(B, N, num_samples)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=xyz.device)
+    idx = torch.empty(B, num_samples, dtype=torch.int64, device=xyz.device)
+    centers = torch.empty(B, num_samples, 3, dtype=torch.float32, device=xyz.device)
+    check(L.psam_fps(xyz.data_ptr(), B, N, num_samples, idx.data_ptr(), centers.data_ptr(), ws.data_ptr(), nbytes, _stream()), "psam_fps")
+    return idx, centers
+
+
+def knn(centers: torch.Tensor, xyz: torch.Tensor, k: int) -> torch.Tensor:
+    """[B,G,3], [B,N,3] -> knn_idx [B,G,K] int64 ascending by (d2, index).  common.py:27-56,97."""
+    _chk(centers, name="centers"); _chk(xyz, name="xyz")
+    B, G, _ = centers.shape
+    N = xyz.shape[1]
+    out = torch.empty(B, G, k, dtype=torch.int64, device=xyz.device)
+    check(_lib.load().psam_knn(centers.data_ptr(), xyz.data_ptr(), B, G, N, k, out.data_ptr(), _stream()), "psam_knn")
+    return out
+
+
+def three_nn(xyz: torch.Tensor, centers: torch.Tensor, eps: float = 1e-8):
+    """-> (idx3 [B,N,3] int64, w3 [B,N,3]).  common.py:238-255."""
+    _chk(xyz, name="xyz"); _chk(centers, name="centers")
+    B, N, _ = xyz.shape
+    G = centers.shape[1]
+    idx = torch.empty(B, N, 3, dtype=torch.int64, device=xyz.device)
+    w = torch.empty(B, N, 3, dtype=torch.float32, device=xyz.device)
+    check(_lib.load().psam_three_nn(xyz.data_ptr(), centers.data_ptr(), B, N, G, eps, idx.data_ptr(), w.data_ptr(), _stream()), "psam_three_nn")
+    return idx, w
+
+
+def group_gather(xyz, feats, centers, knn_idx):
+    """feats [B*rep,N,C] -> [B*rep,G,K,3+C].  common.py:99-120 / 126-187."""
+    _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64)
+    B, N, _ = xyz.shape
+    rep = feats.shape[0] // B
+    G, K = knn_idx.shape[1:]
+    C = feats.shape[-1]
+    out = torch.empty(B * rep, G, K, 3 + C, dtype=torch.float32, device=xyz.device)
+    check(_lib.load().psam_group_gather(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), B, rep, N, G, K, C,
+                                        out.data_ptr(), _stream()), "psam_group_gather")
+    return out
+
+
+def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None):
+    """Fused gather + Linear(3+C,128) + LayerNorm + GELU -> [B*rep*G*K, 128].  common.py:486-489."""
+    _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64); _chk(W)
+    B, N, _ = xyz.shape
+    rep = feats.shape[0] // B
+    G, K = knn_idx.shape[1:]
+    C = feats.shape[-1]
+    assert W.shape == (128, 3 + C), W.shape
+    rows = B * rep * G * K
+    if out is None:
+        out = torch.empty(rows, 128, dtype=torch.float32, device=xyz.device)
+    check(_lib.load().psam_patch_l1(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                    lnw.data_ptr(), lnb.data_ptr(), eps, B, rep, N, G, K, C, out.data_ptr(), _stream()), "psam_patch_l1")
+    return out
+
+
+def group_max(x: torch.Tensor, K: int, out=None):
+    """[groups*K, C] -> [groups, C]."""
+    _chk(x)
+    rows, C = x.shape
+    groups = rows // K
+    if out is None:
+        out = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    check(_lib.load().psam_group_max(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), groups, K, C, _stream()), "psam_group_max")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ dense
+def _row_view(t, name):
+    """2-D fp32 view with unit inner stride -> (ptr, ld)."""
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D CUDA fp32 tensor with unit inner stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+    return t.data_ptr(), t.stride(0)
+
+
+def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None):
+    """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views."""
+    xp, ldx = _row_view(x, "x")
+    wp, ldw = _row_view(W, "W")
+    M = x.shape[0]
+    N = W.shape[0]
+    if K is None:
+        K = W.shape[1]
+        assert x.shape[1] == K, (x.shape, W.shape)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    op, ldo = _row_view(out, "out")
+    rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
+    rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
+    _gemm_call((xp, ldx, 0, 0, wp, ldw, 0, 0, op, ldo, 0, 0, _p(bias), rp, ldr, 0, 0, rbp, ldrb, rowgroup, M, N, K, 1, 1, 1.0, act, _stream()),
+               2.0 * M * N * K, M, N, K, "psam_gemm_f32")
+    return out
+
+
+def gemm_batched(A, W, out, M, N, K, lda, ldw, ldc, sA, sW, sC, batch, alpha=1.0):
+    """out[z] = alpha * A[z] @ W[z]^T (raw strided-batched form; tensors give base pointers only)."""
+    _gemm_call((A.data_ptr(), lda, sA, 0, W.data_ptr(), ldw, sW, 0, out.data_ptr(), ldc, sC, 0, 0, 0, 0, 0, 0, 0, 0, 0, M, N, K, batch, 1, alpha,
+                ACT_NONE, _stream()), 2.0 * M * N * K * batch, M, N, K, "psam_gemm_f32(batched)")
+    return out
+
+
+def layernorm(x, w, b, eps, act=ACT_NONE, residual=None, out=None):
+    """y = act(LN(x + residual)) over the last dim of a 2-D row view."""
+    xp, ldx = _row_view(x, "x")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, dtype=torch.float32, device=x.device)
+    op, ldo = _row_view(out, "out")
+    rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
+    check(_lib.load().psam_layernorm(xp, ldx, rp, ldr, w.data_ptr(), b.data_ptr(), op, ldo, rows, cols, eps, act, _stream()), "psam_layernorm")
+    return out
+
+
+def swiglu_ln(gx, xoff, H, w, b, eps, out):
+    gp, ldg = _row_view(gx, "gx")
+    op, ldo = _row_view(out, "out")
+    check(_lib.load().psam_swiglu_ln(gp, ldg, xoff, w.data_ptr(), b.data_ptr(), op, ldo, gx.shape[0], H, eps, _stream()), "psam_swiglu_ln")
+    return out
+
+
+def attention(q, k, v, out, B, H, Lq, Lk, hd, scale):
+    """q/k/v/out: 2-D row views [B*L, >=H*hd] (may be column slices of a fused qkv buffer)."""
+    qp, ldq = _row_view(q, "q"); kp, ldk = _row_view(k, "k"); vp, ldv = _row_view(v, "v"); op, ldo = _row_view(out, "out")
+    check(_lib.load().psam_attention_f32(qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale,
+                                         _stream()), "psam_attention_f32")
+    return out
+
+
+def attention_small(q, k, v, out, Z, H, Lq, Lk, hd, scale):
+    qp, ldq = _row_view(q, "q"); kp, ldk = _row_view(k, "k"); vp, ldv = _row_view(v, "v"); op, ldo = _row_view(out, "out")
+    check(_lib.load().psam_attention_small(qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, Z, H, Lq, Lk, hd, scale,
+                                           _stream()), "psam_attention_small")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ encodings etc.
+def pos_l1(centers, W, bias, out=None):
+    _chk(centers)
+    rows = centers.numel() // 3
+    if out is None:
+        out = torch.empty(rows, 128, dtype=torch.float32, device=centers.device)
+    check(_lib.load().psam_pos_l1(centers.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, _stream()), "psam_pos_l1")
+    return out
+
+
+def fourier_pe(coords, gauss, out, rows_per_batch, batch_stride, labels=None, emb0=None, emb1=None, flag=None):
+    """coords [..., 3] -> writes [sin,cos] (+label embedding) rows into ``out`` (see header for the row mapping)."""
+    _chk(coords)
+    rows = coords.numel() // 3
+    F = gauss.shape[1]
+    if labels is not None:
+        _chk(labels, torch.int64, "labels")
+    check(_lib.load().psam_fourier_pe(coords.data_ptr(), gauss.data_ptr(), F, _p(labels), _p(emb0), _p(emb1), out.data_ptr(), rows, rows_per_batch,
+                                      batch_stride, _p(flag), _stream()), "psam_fourier_pe")
+    return out
+
+
+def add_bcast(a, rep, b, out, Z, R, C, sa=None, sb=None, ldb=None, so=None):
+    sa = R * C if sa is None else sa
+    so = R * C if so is None else so
+    if b is None:
+        sb, ldb = 0, 0
+    else:
+        sb = R * C if sb is None else sb
+        ldb = C if ldb is None else ldb
+    check(_lib.load().psam_add_bcast(a.data_ptr(), sa, rep, _p(b), sb, ldb, out.data_ptr(), so, Z, R, C, _stream()), "psam_add_bcast")
+    return out
+
+
+def interp3(src, idx3, w3, out, rep):
+    """src [Z,G,C], idx3/w3 [B,N,3] -> out [Z,N,C]."""
+    Z, G, C = src.shape
+    N = idx3.shape[1]
+    check(_lib.load().psam_interp3(src.data_ptr(), idx3.data_ptr(), w3.data_ptr(), out.data_ptr(), rep, Z, N, G, C, _stream()), "psam_interp3")
+    return out

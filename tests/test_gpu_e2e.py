@@ -1,0 +1,150 @@
+"""End-to-end parity of the HIP path (through the reference-shaped host interface) against
+  (a) the golden vectors produced by the reference's own modules (tests/golden), and
+  (b) the CPU oracle on the same seeded inputs, up to BASELINE.json's full single-cloud size (ViT-L, N=32768, 512x64),
+plus size-independent properties (determinism, batch independence, click-loop cache consistency).
+Tolerance: north_star's 1e-3 on mask logits (fp32); FPS / kNN / 3-NN indices bit-exact."""
+from dataclasses import replace
+
+import pytest
+import torch
+
+from oracle import pointsam_oracle as O
+from point_sam_amd.config import VIT_GIANT, ModelConfig, get_config
+from point_sam_amd.weights import random_state_dict, state_dict_checksum
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from point_sam_amd.model import PointCloudSAM
+    return PointCloudSAM
+
+
+def _maxerr(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu"])
+def test_against_reference_golden(gpu, which, request):
+    meta, a = request.getfixturevalue(which)
+    cfg = get_config(meta["cfg"])
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    assert state_dict_checksum(sd) == pytest.approx(meta["weights_checksum"], rel=1e-12)
+    model = gpu(cfg, sd)
+    st = model.encode(a["xyz"].cuda(), a["rgb"].cuda())
+    assert torch.equal(st.fps_idx.cpu(), a["fps_idx"]), "FPS indices differ from the reference run"
+    assert torch.equal(st.centers.cpu(), a["centers"])
+    assert torch.equal(st.knn_idx.cpu().sort(-1).values, a["knn_idx"].sort(-1).values), "kNN sets differ from torch.cdist+topk"
+    assert _maxerr(st.patch_embeddings, a["patch_embeddings"]) < 1e-4
+    assert _maxerr(st.pc_embeddings, a["pc_embeddings"]) < 5e-4
+    assert _maxerr(st.pc_pe, a["pc_pe"]) < 5e-5
+    masks, iou = model.decode(st, a["prompt_coords"].cuda(), a["prompt_labels"].cuda(), None, True)
+    assert masks.shape == a["masks_click1"].shape and iou.shape == a["iou_click1"].shape
+    assert _maxerr(masks, a["masks_click1"]) < TOL, _maxerr(masks, a["masks_click1"])
+    assert _maxerr(iou, a["iou_click1"]) < TOL
+    masks2, iou2 = model.decode(st, a["prompt_coords"].cuda(), a["prompt_labels"].cuda(), a["prompt_masks_click2"].cuda(), False)
+    assert _maxerr(masks2, a["masks_click2"]) < TOL, _maxerr(masks2, a["masks_click2"])
+    assert _maxerr(iou2, a["iou_click2"]) < TOL
+    model.check_coordinate_range()
+
+
+def _giant_slim():
+    return ModelConfig(replace(VIT_GIANT, depth=2), 128, 32)
+
+
+CASES = {
+    # name: (config, B, N, M)
+    "cfg1_base_4096_128x32": (lambda: get_config("base", 128, 32), 1, 4096, 1),
+    "tiny_ragged": (lambda: get_config("tiny", 37, 11), 3, 1000, 2),
+    "giant_width_depth2": (_giant_slim, 1, 3000, 1),
+    "cfg2_large_32768_512x64": (lambda: get_config("large", 512, 64), 1, 32768, 1),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_against_oracle(gpu, name):
+    mk, B, N, M = CASES[name]
+    cfg = mk()
+    sd = random_state_dict(cfg, seed=42)
+    xyz, rgb, prompt, labels = O.synthetic_batch(B, N, seed=42, num_prompts=1)
+    prompt = prompt.repeat_interleave(M, 0)
+    labels = labels.repeat_interleave(M, 0)
+    if M > 1:
+        prompt = prompt + 0.0  # same click per mask set is fine: exercises the repeat path
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    want_masks, want_iou, mid = O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="exact", return_intermediates=True)
+    model = gpu(cfg, sd)
+    st = model.encode(xyz.cuda(), rgb.cuda())
+    assert torch.equal(st.fps_idx.cpu(), mid["patches"]["fps_idx"]), "FPS indices not bit-exact"
+    assert torch.equal(st.knn_idx.cpu(), mid["patches"]["knn_idx"]), "kNN indices not bit-exact"
+    e_emb = _maxerr(st.pc_embeddings, mid["pc_embeddings"])
+    masks, iou = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+    assert torch.equal(st.interp_index.cpu(), mid["aux"].interp_index), "3-NN indices not bit-exact"
+    e_m, e_i = _maxerr(masks, want_masks), _maxerr(iou, want_iou)
+    print(f"\n[{name}] max|err| embeddings {e_emb:.2e} masks {e_m:.2e} iou {e_i:.2e} (|logit| max {want_masks.abs().max():.2f})")
+    assert e_m < TOL and e_i < TOL, (e_emb, e_m, e_i)
+    # second click: previous best mask as dense prompt, single-mask output
+    best = torch.gather(want_masks, 1, want_iou.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0]
+    want2, want_iou2 = O.mask_decoder(sd, cfg, mid["pc_embeddings"], mid["pc_pe"], mid["sparse"],
+                                      O.mask_encoder(sd, cfg, best, xyz, mid["patches"]["centers"], mid["patches"]["knn_idx"]), mid["aux"], False)
+    masks2, iou2 = model.decode(st, prompt.cuda(), labels.cuda(), best.cuda(), False)
+    assert _maxerr(masks2, want2) < TOL and _maxerr(iou2, want_iou2) < TOL, (_maxerr(masks2, want2), _maxerr(iou2, want_iou2))
+
+
+def test_properties_full_size(gpu):
+    """BASELINE sizes without an oracle run: determinism and batch independence (clouds never interact)."""
+    cfg = get_config("tiny", 512, 64)
+    model = gpu(cfg, random_state_dict(cfg, 1))
+    xyz, rgb, prompt, labels = O.synthetic_batch(3, 32768, seed=5)
+    xyz, rgb, prompt, labels = xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda()
+    m1, i1 = model.predict_masks(xyz, rgb, prompt, labels)
+    m2, i2 = model.predict_masks(xyz, rgb, prompt, labels)
+    assert torch.equal(m1, m2) and torch.equal(i1, i2), "same input twice must be bit-identical"
+    ms, _ = model.predict_masks(xyz[1:2].contiguous(), rgb[1:2].contiguous(), prompt[1:2].contiguous(), labels[1:2].contiguous())
+    assert torch.equal(ms[0], m1[1]), "a cloud's logits must not depend on its batch neighbours"
+    st = model.encode(xyz, rgb)
+    idx = st.fps_idx.cpu()
+    assert (idx[:, 0] == 0).all() and all(len(set(r.tolist())) == 512 for r in idx)
+    assert (st.knn_idx[:, :, 0].cpu() == idx).all(), "each center is its own nearest neighbour"
+    model.decode(st, prompt, labels)
+    assert torch.allclose(st.interp_weight.sum(-1), torch.ones(3, 32768, device="cuda"), atol=1e-6)
+
+
+def test_predictor_click_loop(gpu):
+    from point_sam_amd.predictor import PointSAMPredictor
+    cfg = get_config("tiny")
+    sd = random_state_dict(cfg, 3)
+    pred = PointSAMPredictor(gpu(cfg, sd))
+    xyz, rgb, _, _ = O.synthetic_batch(1, 1500, seed=8)
+    g = torch.Generator().manual_seed(0)
+    clicks = xyz[:, torch.randint(0, 1500, (4,), generator=g)]
+    labels = torch.tensor([[1, 0, 1, 1]])
+    want = O.click_loop(sd, cfg, xyz, rgb, clicks, labels)
+    xyz_d, rgb_d = xyz.cuda(), rgb.cuda()
+    prompt_mask = None
+    for t in range(4):  # demo/app.py:177-206 protocol
+        pred.set_pointcloud(xyz_d, rgb_d)
+        state_before = pred._state
+        mask, scores, logits = pred.predict_masks(clicks[:, : t + 1].cuda(), labels[:, : t + 1].cuda(), prompt_mask, prompt_mask is None)
+        assert pred._state is state_before, "encoder must be cached across clicks"
+        assert _maxerr(logits, want[t][0]) < TOL and _maxerr(scores, want[t][1]) < TOL, (t, _maxerr(logits, want[t][0]))
+        prompt_mask = logits[0][torch.argmax(scores[0])][None, ...]
+    pred.set_prompts(clicks[:, :1].cuda(), labels[:, :1].cuda())
+    m, s, _ = pred.predict_masks()
+    assert _maxerr(m, want[0][0]) < TOL
+
+
+def test_out_of_range_coordinates_raise(gpu):
+    cfg = get_config("tiny")
+    model = gpu(cfg, random_state_dict(cfg, 3))
+    xyz, rgb, prompt, labels = O.synthetic_batch(1, 600, seed=2)
+    with pytest.raises(ValueError):
+        model.predict_masks(xyz.cuda(), rgb.cuda(), (prompt * 0 + 1.5).cuda(), labels.cuda())
+    with pytest.raises(AssertionError):
+        model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels[:, :0].cuda())
+    m, _ = model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda())  # flag was reset
+    assert torch.isfinite(m).all()

@@ -1,0 +1,269 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the CPU oracle (bit-exact for index work,
+fp32 tolerance for floating point) on the same seeded inputs.  Run with ``pytest -m gpu``."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pointsam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from point_sam_amd import ops as _ops
+    _ops._lib.load()
+    return _ops
+
+
+def cu(t):
+    return t.cuda().contiguous()
+
+
+def _close(got, want, atol, rtol=0.0, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max abs err {err.max():.3e} (max |want| {want.abs().max():.3e})"
+
+
+def _cloud(B, N, seed, dup=0):
+    xyz, rgb, _, _ = O.synthetic_batch(B, N, seed=seed)
+    if dup:  # exact duplicate points, like demo/static/models/*.ply
+        g = torch.Generator().manual_seed(seed + 99)
+        src = torch.randint(0, N, (dup,), generator=g)
+        dst = torch.randint(0, N, (dup,), generator=g)
+        xyz[:, dst] = xyz[:, src]
+    return xyz, rgb
+
+
+# ------------------------------------------------------------------------------------------------ tokenizer
+@pytest.mark.parametrize("B,N,G,dup", [(2, 1024, 32, 0), (1, 777, 32, 0), (2, 4096, 128, 0), (1, 5000, 64, 300), (2, 32768, 512, 0),
+                                       (1, 20000, 256, 5000), (1, 40000, 48, 0), (1, 64, 64, 0)])
+def test_fps_bit_exact(ops, B, N, G, dup):
+    xyz, _ = _cloud(B, N, seed=N + G, dup=dup)
+    want = O.fps(xyz, G)
+    idx, centers = ops.fps(cu(xyz), G)
+    got = idx.cpu()
+    if not torch.equal(got, want):
+        first = (got != want).nonzero()[0].tolist()
+        raise AssertionError(f"FPS differs: {(got != want).sum().item()} of {got.numel()} indices, first at {first}: got {got[tuple(first)]} want {want[tuple(first)]}")
+    assert torch.equal(centers.cpu(), O.batch_index_select(xyz, want))
+
+
+@pytest.mark.parametrize("B,N,G,K,dup", [(2, 1024, 32, 16, 0), (1, 777, 32, 16, 0), (2, 4096, 128, 32, 0), (1, 32768, 96, 64, 0),
+                                         (1, 5000, 64, 64, 2500), (1, 3000, 16, 256, 0), (1, 100, 8, 100, 40), (1, 20000, 32, 1000, 0)])
+def test_knn_bit_exact(ops, B, N, G, K, dup):
+    xyz, _ = _cloud(B, N, seed=3 * N + K, dup=dup)
+    centers = O.batch_index_select(xyz, O.fps(xyz, G))
+    _, want = O.knn(centers, xyz, K, "exact")
+    got = ops.knn(cu(centers), cu(xyz), K).cpu()
+    if not torch.equal(got, want):
+        rows = (got != want).any(-1).nonzero()
+        raise AssertionError(f"kNN differs in {len(rows)} of {B * G} groups; first {rows[0].tolist()}: got {got[tuple(rows[0])][:8]} want {want[tuple(rows[0])][:8]}")
+
+
+def test_knn_all_points_identical(ops):
+    """Degenerate tie: every distance equal -> the K lowest indices."""
+    xyz = torch.full((1, 500, 3), 0.25)
+    got = ops.knn(cu(xyz[:, :4]), cu(xyz), 37).cpu()
+    assert torch.equal(got, torch.arange(37).expand(1, 4, 37))
+
+
+@pytest.mark.parametrize("B,N,G", [(2, 1024, 32), (1, 777, 17), (2, 32768, 512), (1, 5000, 2048)])
+def test_three_nn(ops, B, N, G):
+    xyz, _ = _cloud(B, N, seed=N + 7 * G)
+    centers = O.batch_index_select(xyz, O.fps(xyz, G))
+    want_i, want_w = O.interp_weights(xyz, centers, "exact")
+    got_i, got_w = ops.three_nn(cu(xyz), cu(centers))
+    assert torch.equal(got_i.cpu(), want_i), f"{(got_i.cpu() != want_i).sum().item()} index mismatches"
+    _close(got_w, want_w, 1e-6, what="3-NN weights")
+
+
+def test_group_gather_and_patch_l1(ops):
+    B, N, G, K = 2, 2048, 48, 16
+    xyz, rgb = _cloud(B, N, seed=5)
+    centers = O.batch_index_select(xyz, O.fps(xyz, G))
+    _, kidx = O.knn(centers, xyz, K, "exact")
+    want = O.group_points(xyz, rgb, centers, kidx)
+    got = ops.group_gather(cu(xyz), cu(rgb), cu(centers), cu(kidx))
+    assert torch.equal(got.cpu(), want)
+    g = torch.Generator().manual_seed(1)
+    for C, rep in ((3, 1), (1, 3)):
+        feats = rgb if C == 3 else torch.randn(B * rep, N, 1, generator=g)
+        W = torch.randn(128, 3 + C, generator=g) * 0.5
+        b, lw, lb = torch.randn(128, generator=g) * 0.1, 1 + 0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)
+        if C == 3:
+            grouped = want
+        else:
+            rel = want[..., :3].repeat_interleave(rep, 0)
+            ki = kidx.repeat_interleave(rep, 0)
+            grouped = torch.cat([rel, torch.gather(feats[..., 0], 1, ki.reshape(B * rep, -1)).reshape(B * rep, G, K, 1)], -1)
+        ref = F.gelu(F.layer_norm(F.linear(grouped, W, b), (128,), lw, lb, 1e-5)).reshape(-1, 128)
+        out = ops.patch_l1(cu(xyz), cu(feats), cu(centers), cu(kidx), cu(W), cu(b), cu(lw), cu(lb), 1e-5)
+        _close(out, ref, 2e-5, what=f"patch_l1 C={C}")
+
+
+# ------------------------------------------------------------------------------------------------ dense
+@pytest.mark.parametrize("cfg", [0, 1, 2, -1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 130, 36), (64, 200, 4), (1000, 96, 516), (33, 7, 128), (512, 2752, 64)])
+def test_gemm_shapes(ops, cfg, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ops._lib.load().psam_gemm_force_config(cfg)
+    try:
+        y = ops.linear(cu(x), cu(W), cu(b))
+    finally:
+        ops._lib.load().psam_gemm_force_config(-1)
+    want = (x.double() @ W.double().T + b.double())
+    _close(y, want, 1e-5 * math.sqrt(K) * 4, what=f"gemm {M}x{N}x{K} cfg{cfg}")
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric W catches transposed / permuted output layouts."""
+    n = 128
+    W = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    y = ops.linear(cu(torch.eye(n)), cu(W))
+    assert torch.equal(y.cpu(), W.T.contiguous())
+
+
+def test_gemm_epilogues_and_views(ops):
+    g = torch.Generator().manual_seed(0)
+    M, N, K, grp = 192, 160, 96, 16
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, 2 * K, generator=g), torch.randn(N, generator=g)
+    res, rb = torch.randn(M, N, generator=g), torch.randn(M // grp, N, generator=g)
+    Wd = cu(W)
+    base = x.double() @ W[:, K:].double().T
+    y = ops.linear(cu(x), Wd[:, K:], cu(b), act=ops.ACT_GELU)                       # column-sliced weight view
+    _close(y, F.gelu(base + b.double()), 1e-4, what="gelu epilogue")
+    y = ops.linear(cu(x), Wd[:, K:], None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
+    _close(y, F.relu(base + rb.double().repeat_interleave(grp, 0)), 1e-4, what="rowbias+relu")
+    xr = cu(res.clone())
+    ops.linear(cu(x), Wd[:, K:], cu(b), residual=xr, out=xr)                        # in-place residual
+    _close(xr, base + b.double() + res.double(), 1e-4, what="residual in place")
+    # batched, strided: masks[z] = hyper[z] @ up[z]^T
+    Z, C, Np, E = 3, 3, 500, 64
+    hyper, up = torch.randn(Z, C, E, generator=g), torch.randn(Z, Np, E, generator=g)
+    out = torch.empty(Z, C, Np, device="cuda")
+    ops.gemm_batched(cu(hyper), cu(up), out, C, Np, E, E, E, Np, C * E, Np * E, C * Np, Z)
+    _close(out, hyper.double() @ up.double().transpose(1, 2), 1e-4, what="batched gemm")
+
+
+@pytest.mark.parametrize("cols", [64, 128, 256, 512, 1000, 1024, 1408, 2730])
+def test_layernorm(ops, cols):
+    g = torch.Generator().manual_seed(cols)
+    x, r = torch.randn(37, cols, generator=g) * 3 + 1, torch.randn(37, cols, generator=g)
+    w, b = 1 + 0.1 * torch.randn(cols, generator=g), 0.1 * torch.randn(cols, generator=g)
+    _close(ops.layernorm(cu(x), cu(w), cu(b), 1e-6), F.layer_norm(x.double(), (cols,), w.double(), b.double(), 1e-6), 2e-5, what="LN")
+    got = ops.layernorm(cu(x), cu(w), cu(b), 1e-5, act=ops.ACT_GELU, residual=cu(r))
+    _close(got, F.gelu(F.layer_norm((x + r).double(), (cols,), w.double(), b.double(), 1e-5)), 2e-5, what="LN+res+gelu")
+
+
+def test_swiglu_ln(ops):
+    g = torch.Generator().manual_seed(2)
+    H, Hp, M = 170, 192, 50
+    gx = torch.randn(M, 2 * Hp, generator=g)
+    w, b = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    out = torch.full((M, Hp), 7.0, device="cuda")
+    ops.swiglu_ln(cu(gx), Hp, H, cu(w), cu(b), 1e-6, out)
+    want = F.layer_norm((F.silu(gx[:, :H]) * gx[:, Hp:Hp + H]).double(), (H,), w.double(), b.double(), 1e-6)
+    _close(out[:, :H], want, 2e-5, what="swiglu_ln")
+    assert (out[:, H:] == 0).all()
+
+
+def test_group_max_pos_fourier_addbcast_interp(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(40 * 16, 96, generator=g)
+    assert torch.equal(ops.group_max(cu(x), 16).cpu(), x.view(40, 16, 96).max(1).values)
+    c = torch.rand(77, 3, generator=g) * 2 - 1
+    W, b = torch.randn(128, 3, generator=g), torch.randn(128, generator=g)
+    _close(ops.pos_l1(cu(c), cu(W), cu(b)), F.gelu(F.linear(c.double(), W.double(), b.double())), 1e-5, what="pos_l1")
+    # fourier PE + label embeddings written into a token buffer at an offset
+    Gm = torch.randn(3, 128, generator=g)
+    e0, e1 = torch.randn(1, 256, generator=g), torch.randn(1, 256, generator=g)
+    Z, P, T = 5, 3, 8
+    pts = torch.rand(Z, P, 3, generator=g) * 2 - 1
+    lab = torch.randint(0, 2, (Z, P), generator=g)
+    sd = {"point_encoder.pe_layer.positional_encoding_gaussian_matrix": Gm, "point_encoder.point_embeddings.0.weight": e0,
+          "point_encoder.point_embeddings.1.weight": e1}
+    tokens = torch.zeros(Z, T, 256, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.fourier_pe(cu(pts), cu(Gm), tokens.view(-1)[5 * 256:], P, T * 256, labels=cu(lab), emb0=cu(e0), emb1=cu(e1), flag=flag)
+    _close(tokens[:, 5:], O.point_encoder(sd, pts, lab), 3e-5, what="point encoder")
+    assert (tokens[:, :5] == 0).all() and flag.item() == 0
+    pe = torch.empty(Z * P, 256, device="cuda")
+    bad = pts.clone(); bad[2, 1, 0] = 1.5
+    ops.fourier_pe(cu(bad), cu(Gm), pe, Z * P, 0, flag=flag)
+    assert flag.item() == 1
+    # add_bcast: repeat + add, and row-vector broadcast
+    a, bb = torch.randn(2, 6, 256, generator=g), torch.randn(6, 6, 256, generator=g)
+    out = torch.empty(6, 6, 256, device="cuda")
+    ops.add_bcast(cu(a), 3, cu(bb), out, 6, 6, 256)
+    assert torch.equal(out.cpu(), a.repeat_interleave(3, 0) + bb)
+    ops.add_bcast(cu(a), 3, cu(e0), out, 6, 6, 256, sb=0, ldb=0)
+    assert torch.equal(out.cpu(), a.repeat_interleave(3, 0) + e0)
+    # interpolation
+    src = torch.randn(4, 20, 256, generator=g)
+    idx = torch.randint(0, 20, (2, 300, 3), generator=g)
+    w3 = torch.rand(2, 300, 3, generator=g)
+    out = torch.empty(4, 300, 256, device="cuda")
+    ops.interp3(cu(src), cu(idx), cu(w3), out, 2)
+    _close(out, O.interpolate(src, idx.repeat_interleave(2, 0), w3.repeat_interleave(2, 0)), 1e-5, what="interp3")
+
+
+def _sdpa(q, k, v, H, scale):
+    B, Lq, D = q.shape
+    sp = lambda t: t.reshape(B, t.shape[1], H, D // H).transpose(1, 2).double()
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * scale, -1) @ sp(v)
+    return a.transpose(1, 2).reshape(B, Lq, D)
+
+
+@pytest.mark.parametrize("hd,H,Lq,Lk", [(64, 2, 128, 128), (64, 3, 512, 512), (32, 2, 32, 32), (24, 4, 100, 100), (88, 2, 200, 200),
+                                        (16, 2, 70, 333), (64, 1, 5, 64), (48, 1, 129, 65), (128, 1, 64, 96), (96, 1, 33, 31)])
+def test_flash_attention(ops, hd, H, Lq, Lk):
+    g = torch.Generator().manual_seed(hd + Lq)
+    B, D = 2, H * hd
+    qkv_q = torch.randn(B, Lq, 3 * D, generator=g)          # fused-buffer layout: q | k | v in one row
+    qkv_k = torch.randn(B, Lk, 3 * D, generator=g)
+    bq, bk = cu(qkv_q).view(B * Lq, 3 * D), cu(qkv_k).view(B * Lk, 3 * D)
+    out = torch.empty(B * Lq, D, device="cuda")
+    scale = hd ** -0.5 * 2.0  # larger logits exercise the running-max path
+    ops.attention(bq[:, :D], bk[:, D:2 * D], bk[:, 2 * D:], out, B, H, Lq, Lk, hd, scale)
+    want = _sdpa(qkv_q[..., :D], qkv_k[..., D:2 * D], qkv_k[..., 2 * D:], H, scale)
+    _close(out.view(B, Lq, D), want, 2e-5, what=f"flash hd={hd}")
+
+
+def test_flash_attention_running_max_spike(ops):
+    """Forces the rescale branch: one key dominates late in the sequence."""
+    g = torch.Generator().manual_seed(9)
+    B, H, hd, L = 1, 1, 64, 256
+    q, k, v = (torch.randn(B, L, hd, generator=g) for _ in range(3))
+    k[0, 200] = q[0, 7] * 4.0
+    out = torch.empty(B * L, hd, device="cuda")
+    ops.attention(cu(q).view(L, hd), cu(k).view(L, hd), cu(v).view(L, hd), out, B, H, L, L, hd, 1.0)
+    _close(out.view(B, L, hd), _sdpa(q, k, v, H, 1.0), 2e-5, what="flash spike")
+
+
+@pytest.mark.parametrize("hd,H,Lq,Lk", [(32, 8, 7, 7), (16, 8, 7, 512), (16, 8, 512, 7), (16, 8, 6, 2048), (24, 2, 3, 70)])
+def test_attention_small(ops, hd, H, Lq, Lk):
+    g = torch.Generator().manual_seed(hd * Lk)
+    Z, D = 3, H * hd
+    q, k, v = torch.randn(Z, Lq, D, generator=g), torch.randn(Z, Lk, D, generator=g), torch.randn(Z, Lk, D, generator=g)
+    out = torch.empty(Z * Lq, D, device="cuda")
+    ops.attention_small(cu(q).view(-1, D), cu(k).view(-1, D), cu(v).view(-1, D), out, Z, H, Lq, Lk, hd, hd ** -0.5)
+    _close(out.view(Z, Lq, D), _sdpa(q, k, v, H, hd ** -0.5), 2e-5, what="attention_small")
+
+
+def test_invalid_arguments_raise(ops):
+    with pytest.raises(ops._lib.PointSamHipError):
+        ops.knn(torch.zeros(1, 4, 3, device="cuda"), torch.zeros(1, 8, 3, device="cuda"), 9)      # K > N
+    with pytest.raises(ops._lib.PointSamHipError):
+        ops.linear(torch.zeros(8, 6, device="cuda"), torch.zeros(8, 6, device="cuda"))             # K % 4 != 0
+    with pytest.raises(ops._lib.PointSamHipError):
+        ops.fps(torch.zeros(1, 8, 3, device="cuda"), 9)                                             # G > N

@@ -1,0 +1,62 @@
+"""CPU-side checks: C-ABI library exports, header/binding sync, weight ABI, loud failure without a GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+from point_sam_amd import _lib, get_config
+from point_sam_amd.weights import check_state_dict, expected_shapes, random_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from point_sam_amd.build import build_library
+    build_library()
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "pointsam_hip.h")).read()
+    declared = set(re.findall(r"\b(psam_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.psam_version() == 100
+
+
+def test_invalid_arguments_return_status_not_crash():
+    lib = _lib.load()
+    # null pointers / bad shapes are rejected on the host before any launch
+    assert lib.psam_fps(None, 1, 16, 4, None, None, None, 0, None) == -1
+    assert b"null" in lib.psam_last_error_string()
+    assert lib.psam_knn(None, None, 1, 1, 1, 1, None, None) == -1
+    assert lib.psam_fps_workspace_bytes(2, 1000, 10) == 2 * 4 * 4096 * 4
+
+
+def test_product_path_refuses_cpu():
+    from point_sam_amd.model import PointCloudSAM
+    cfg = get_config("tiny")
+    with pytest.raises(RuntimeError):
+        PointCloudSAM(cfg, random_state_dict(cfg), device="cpu")
+    from point_sam_amd import ops
+    with pytest.raises(_lib.PointSamHipError):
+        ops.fps(torch.zeros(1, 8, 3), 2)
+
+
+def test_weight_abi_names():
+    for name in ("base", "large", "giant"):
+        cfg = get_config(name)
+        shapes = expected_shapes(cfg)
+        assert "pc_encoder.patch_embed.patch_encoder.conv2.3.weight" in shapes
+        assert "mask_decoder.transformer.final_attn_token_to_image.out_proj.weight" in shapes
+        assert shapes["pc_encoder.out_proj.weight"] == (256, cfg.vit.dim)
+    cfg = get_config("large")
+    assert expected_shapes(cfg)["pc_encoder.transformer.blocks.23.mlp.fc1_g.weight"] == (2730, 1024)
+    n = sum(int(torch.tensor(s).prod()) for s in expected_shapes(cfg).values())
+    assert 300e6 < n < 330e6  # ViT-L + decoder
+    cfg = get_config("tiny")
+    sd = random_state_dict(cfg)
+    sd["pc_encoder.transformer.cls_token"] = torch.zeros(1, 1, 64)  # timm leftovers are tolerated
+    check_state_dict(cfg, sd)
+    sd["bogus.weight"] = torch.zeros(1)
+    with pytest.raises(KeyError):
+        check_state_dict(cfg, sd)
