@@ -10,14 +10,15 @@
 // the 157.3 TFLOP/s f32 matrix rate, not the bf16 one.
 //
 // Tiling: 256 threads = 2x2 waves, each wave TM x TN MFMA tiles of 32x32; K is consumed in 32-wide slabs staged
-// through LDS (row stride 36 floats: conflict-free ds_read_b128 for the 16-lane groups), double-buffered with the
-// next slab prefetched into registers while the current one feeds the matrix pipe.  One ds_read_b128 per operand
+// through LDS (unpadded 128-byte rows with an XOR chunk swizzle: conflict-free ds_read_b128), double-buffered with
+// the next slab prefetched into registers while the current one feeds the matrix pipe.  One ds_read_b128 per operand
 // row feeds 4 MFMAs: lanes 0-31 take k = 8s..8s+3, lanes 32-63 take k = 8s+4..8s+7 (A and W use the same
 // permutation of k, so the sum over k is unchanged).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float* A; const float* W; float* C;
@@ -31,16 +32,21 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-constexpr int GEMM_BK = 32;
-constexpr int GEMM_LD = GEMM_BK + 4;
+constexpr int GEMM_BK = 32;   // K slab: one 128-byte row segment per operand row
+
+// LDS image of a slab: rows of 32 floats (8 x 16-byte chunks), NO padding; chunk c of row r lives at chunk slot
+// c ^ ((r >> 1) & 7).  Conflict-free for ds_read_b128 (each 16-lane service group sees 16 distinct rows mod 16 ->
+// 16 distinct 4-bank slots) and for ds_write_b128 (8 lanes cover one whole row).  Unpadded rows keep a 128x64
+// double-buffered tile at 48 KiB, i.e. 3 workgroups (12 waves) per CU.
+__device__ __forceinline__ int lds_chunk_off(int row, int chunk) { return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int A_F4 = BM * (GEMM_BK / 4) / 256;  // float4 loads per thread per slab
     constexpr int W_F4 = BN * (GEMM_BK / 4) / 256;
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * GEMM_LD];
-    __shared__ __attribute__((aligned(16))) float sW[2][BN * GEMM_LD];
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * GEMM_BK];
+    __shared__ __attribute__((aligned(16))) float sW[2][BN * GEMM_BK];
 
     // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous
     // range of tiles (they share A row panels / W column panels in that XCD's private L2).
@@ -65,78 +71,125 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[A_F4], rw[W_F4];
-    const int lr = tid >> 3, lc = (tid & 7) * 4;  // this thread's (row, k) inside a 32-row stripe of a slab
+    // Two register sets for global->LDS staging: the loads of slab t+2 are issued while slab t is computed, so a
+    // load has ~1.5 slab times (2-4 us) to return -- operands mostly come from the Infinity Cache / HBM (A and W exceed
+    // the 4 MiB XCD L2) and one slab time is not enough under load (measured: +40 % MFMA idle with distance 1).
+    f32x4 ra0[A_F4], rw0[W_F4], ra1[A_F4], rw1[W_F4];
+    const int lr = tid >> 3, lc4 = tid & 7;             // this thread's (row, 16-byte chunk) inside a 32-row stripe
+    const int st_off = lds_chunk_off(lr, lc4);           // (row >> 1) & 7 is the same for row and row + 32*i
 
-    auto load_slab = [&](int k0) {
+    // Operands are read through buffer descriptors: rows >= M / >= N and the K tail fall outside num_records and
+    // return 0 from the hardware bounds check -- no exec-mask branches around the loads, so the compiler can keep the
+    // two register sets in flight with COUNTED vmcnt waits instead of draining to vmcnt(0).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((((int64_t)p.M - 1) * p.lda + p.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((((int64_t)p.N - 1) * p.ldw + p.K) * 4), 0x00020000);
+    const int voA = (int)(((int64_t)(m0 + lr) * p.lda + lc4 * 4) * 4), voW = (int)(((int64_t)(n0 + lr) * p.ldw + lc4 * 4) * 4);
+    const int stepA = (int)(32 * p.lda * 4), stepW = (int)(32 * p.ldw * 4);
+    constexpr int OOB = 0x7ffffff0;  // >= num_records (operands are < 2 GiB, checked on the host)
+    auto load_slab = [&](int k0, f32x4 (&ra)[A_F4], f32x4 (&rw)[W_F4]) {
+        const bool kok = k0 + lc4 * 4 < p.K;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int row = m0 + i * 32 + lr, k = k0 + lc;
-            ra[i] = (row < p.M && k < p.K) ? *reinterpret_cast<const f32x4*>(A + (int64_t)row * p.lda + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = kok && (m0 + i * 32 + lr < p.M);
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? voA + i * stepA : OOB, k0 * 4, 0));
         }
 #pragma unroll
         for (int i = 0; i < W_F4; ++i) {
-            const int row = n0 + i * 32 + lr, k = k0 + lc;
-            rw[i] = (row < p.N && k < p.K) ? *reinterpret_cast<const f32x4*>(W + (int64_t)row * p.ldw + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = kok && (n0 + i * 32 + lr < p.N);
+            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, ok ? voW + i * stepW : OOB, k0 * 4, 0));
         }
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, const f32x4 (&ra)[A_F4], const f32x4 (&rw)[W_F4]) {
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<f32x4*>(&sA[buf][(i * 32 + lr) * GEMM_LD + lc]) = ra[i];
+        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<f32x4*>(&sA[buf][i * 32 * GEMM_BK + st_off]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < W_F4; ++i) *reinterpret_cast<f32x4*>(&sW[buf][(i * 32 + lr) * GEMM_LD + lc]) = rw[i];
+        for (int i = 0; i < W_F4; ++i) *reinterpret_cast<f32x4*>(&sW[buf][i * 32 * GEMM_BK + st_off]) = rw[i];
+    };
+    // fragment of k-chunk s (k = 8s .. 8s+7): lanes 0-31 take 8s..8s+3, lanes 32-63 take 8s+4..8s+7
+    int frag_off[GEMM_BK / 8];
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 8; ++s) frag_off[s] = lds_chunk_off(r32, 2 * s + h);
+    const int a_row0 = wm * TM * 32 * GEMM_BK, w_row0 = wn * TN * 32 * GEMM_BK;
+    auto load_frags = [&](int buf, int s, f32x4 (&af)[TM], f32x4 (&wf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][a_row0 + i * 32 * GEMM_BK + frag_off[s]]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const f32x4*>(&sW[buf][w_row0 + j * 32 * GEMM_BK + frag_off[s]]);
     };
 
+    // Software pipeline (one barrier per slab, no LDS latency exposed to the matrix pipe):
+    //   slab t+2: global -> register set (t&1) at the top of slab t;
+    //   slab t+1: register set ((t+1)&1) -> LDS[buf^1] before the 3rd MFMA chunk of slab t;
+    //   fragments of chunk s+1 are read from LDS while chunk s feeds the MFMAs, also across the slab barrier.
+    f32x4 af[2][TM], wf[2][TN];
     const int nslabs = (p.K + GEMM_BK - 1) / GEMM_BK;
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int t = 0; t < nslabs; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nslabs) load_slab((t + 1) * GEMM_BK);
-        const float* a_base = &sA[buf][(wm * TM * 32 + r32) * GEMM_LD + h * 4];
-        const float* w_base = &sW[buf][(wn * TN * 32 + r32) * GEMM_LD + h * 4];
+    auto slab_body = [&](int t, int buf, f32x4 (&ra_far)[A_F4], f32x4 (&rw_far)[W_F4], f32x4 (&ra_near)[A_F4], f32x4 (&rw_near)[W_F4]) {
 #pragma unroll
         for (int s = 0; s < GEMM_BK / 8; ++s) {
-            f32x4 af[TM], wf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * GEMM_LD + s * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const f32x4*>(w_base + j * 32 * GEMM_LD + s * 8);
+            if (s < GEMM_BK / 8 - 1) {
+                load_frags(buf, s + 1, af[(s + 1) & 1], wf[(s + 1) & 1]);
+            } else {
+                __syncthreads();  // all waves: reads of LDS[buf] done, writes of LDS[buf^1] visible
+                load_frags(buf ^ 1, 0, af[0], wf[0]);  // (after the last slab this reads the all-zero slab; unused)
+            }
+            if (s == GEMM_BK / 8 - 2) {  // unconditional, also for the last slab: keeps every vmcnt wait counted
+                store_slab(buf ^ 1, ra_near, rw_near);                              // slab t+1 (loaded during slab t-1)
+                // registers free again: slab t+3.  Issued unconditionally (past the end of K it is an all-out-of-bounds
+                // load returning zeros) so that the number of younger loads in flight is a compile-time constant.
+                load_slab((t + 3) * GEMM_BK, ra_near, rw_near);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], wf[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][q], wf[s & 1][j][q], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nslabs) store_slab(buf ^ 1);
-        __syncthreads();
+        (void)t; (void)ra_far; (void)rw_far;
+    };
+    load_slab(0, ra0, rw0);
+    load_slab(GEMM_BK, ra1, rw1);
+    store_slab(0, ra0, rw0);
+    load_slab(2 * GEMM_BK, ra0, rw0);
+    __syncthreads();
+    load_frags(0, 0, af[0], wf[0]);
+    // invariant at the top of slab t: LDS[t&1] holds slab t; set ((t+1)&1) holds (or is receiving) slab t+1;
+    // set (t&1) holds (or is receiving) slab t+2.
+    int t = 0;
+    for (; t + 1 < nslabs; t += 2) {  // both bodies unconditional inside the loop (counted vmcnt needs straight-line code)
+        slab_body(t, 0, ra0, rw0, ra1, rw1);
+        slab_body(t + 1, 1, ra1, rw1, ra0, rw0);
     }
+    if (t < nslabs) slab_body(t, 0, ra0, rw0, ra1, rw1);
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* C = p.C + z1 * p.sC1 + z2 * p.sC2;
     const float* R = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    const bool group_uniform = p.rowbias && (p.rowgroup & 31) == 0;  // a 32-row MFMA tile never straddles two groups
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int row0 = m0 + (wm * TM + i) * 32;
+        const float* rb_tile = group_uniform ? p.rowbias + (int64_t)(row0 / p.rowgroup) * p.ldrb : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + r32;
             if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+            float bv = p.bias ? p.bias[col] : 0.f;
+            if (rb_tile) bv += rb_tile[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] * p.alpha + bv;
-                if (p.rowbias) v += p.rowbias[(int64_t)(row / p.rowgroup) * p.ldrb + col];
+                if (p.rowbias && !group_uniform) v += p.rowbias[(int64_t)(row / p.rowgroup) * p.ldrb + col];
                 if (p.act == 1) v = gelu_erf(v);
                 else if (p.act == 2) v = fmaxf(v, 0.f);
                 if (R) v += R[(int64_t)row * p.ldr + col];
                 C[(int64_t)row * p.ldc + col] = v;
             }
         }
+    }
 }
 
 static int g_force_cfg = -1;  // test/bench hook: 0=128x128, 1=128x64, 2=64x64, -1=auto
@@ -156,6 +209,8 @@ PSAM_API int32_t psam_gemm_f32(const float* A, int64_t lda, int64_t sA1, int64_t
     PSAM_REQUIRE((K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && (sA1 & 3) == 0 && (sA2 & 3) == 0 && (sW1 & 3) == 0 &&
                      (sW2 & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
                  PSAM_EALIGN, "psam_gemm_f32: K, lda, ldw, batch strides must be multiples of 4 and A, W 16-byte aligned");
+    PSAM_REQUIRE(((int64_t)M - 1) * lda + K < ((int64_t)1 << 29) - 8 && ((int64_t)N - 1) * ldw + K < ((int64_t)1 << 29) - 8, PSAM_EINVAL,
+                 "psam_gemm_f32: one operand matrix must span < 2 GiB (32-bit buffer offsets); split the batch");
     GemmArgs p;
     p.A = A; p.W = W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
@@ -164,11 +219,11 @@ PSAM_API int32_t psam_gemm_f32(const float* A, int64_t lda, int64_t sA1, int64_t
     const int64_t batch = (int64_t)batch1 * batch2;
     int cfg = g_force_cfg;
     if (cfg < 0) {
-        const int64_t tl = psam_cdiv(M, 128) * psam_cdiv(N, 128) * batch;
+        // Measured on MI355X (scripts/gemm_bench.py): with f32 MFMA the matrix pipe is slow enough that the extra
+        // operand traffic of small tiles is free, while more resident waves (3 WG/CU at 128x64, 5 at 64x64) and finer
+        // tile quantisation over 256 CUs are not: 128x64 for the ViT GEMMs, 64x64 for short-K / small problems.
         const int64_t tmid = psam_cdiv(M, 128) * psam_cdiv(N, 64) * batch;
-        if (tl >= 384) cfg = 0;
-        else if (tmid >= 256 && M > 64) cfg = 1;
-        else cfg = 2;
+        cfg = (K <= 256 || M <= 64 || tmid < 512) ? 2 : 1;
     }
     const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 128 : 64;
     p.tiles_m = (int)psam_cdiv(M, bm);

@@ -87,6 +87,7 @@ PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, i
 // timm SwiGLU with inner norm (eva02 blocks): out = LayerNorm_H(SiLU(g) * x); g = gx[:, 0:H], x = gx[:, xoff:xoff+H].
 // out has leading dimension ldo >= H; columns [H, ldo) are written as zeros (K padding of the following fc2 GEMM).
 // ------------------------------------------------------------------------------------------------
+template <int NREG>  // NREG*64 >= H: the gated row lives in registers (one read of gx, one write of out)
 __global__ __launch_bounds__(256) void swiglu_ln_kernel(const float* __restrict__ gx, int64_t ldg, int xoff, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ out, int64_t ldo, int64_t rows, int H,
                                                         float eps) {
@@ -96,26 +97,58 @@ __global__ __launch_bounds__(256) void swiglu_ln_kernel(const float* __restrict_
     const float* g = gx + row * ldg;
     const float* x = g + xoff;
     float* o = out + row * ldo;
-    float s = 0.f;
-    for (int c = lane; c < H; c += 64) {
-        const float u = silu(g[c]) * x[c];
-        o[c] = u;  // same lane re-reads its own columns below
-        s += u;
-    }
     const float inv = 1.0f / (float)H;
-    const float mean = wave_sum(s) * inv;
-    float q = 0.f;
-    for (int c = lane; c < H; c += 64) { const float d = o[c] - mean; q += d * d; }
-    const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
-    for (int c = lane; c < H; c += 64) o[c] = (o[c] - mean) * r * w[c] + b[c];
-    for (int c = H + lane; c < ldo; c += 64) o[c] = 0.f;
+    if (NREG > 0) {
+        float u[NREG > 0 ? NREG : 1];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = i * 64 + lane;
+            u[i] = c < H ? silu(g[c]) * x[c] : 0.f;
+            s += u[i];
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const float d = (i * 64 + lane) < H ? u[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = i * 64 + lane;
+            if (c < H) o[c] = (u[i] - mean) * r * w[c] + b[c];
+            else if (c < ldo) o[c] = 0.f;
+        }
+        for (int c = NREG * 64 + lane; c < ldo; c += 64) o[c] = 0.f;
+    } else {
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) {
+            const float u = silu(g[c]) * x[c];
+            o[c] = u;  // same lane re-reads its own columns below
+            s += u;
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+        for (int c = lane; c < H; c += 64) { const float d = o[c] - mean; q += d * d; }
+        const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+        for (int c = lane; c < H; c += 64) o[c] = (o[c] - mean) * r * w[c] + b[c];
+        for (int c = H + lane; c < ldo; c += 64) o[c] = 0.f;
+    }
 }
 
 PSAM_API int32_t psam_swiglu_ln(const float* gx, int64_t ldg, int32_t xoff, const float* w, const float* b, float* out, int64_t ldo,
                                 int64_t rows, int32_t H, float eps, hipStream_t stream) {
     PSAM_REQUIRE(gx && w && b && out, PSAM_EINVAL, "psam_swiglu_ln: null pointer");
     PSAM_REQUIRE(rows > 0 && H > 0 && xoff >= H && ldo >= H && ldg >= xoff + H, PSAM_EINVAL, "psam_swiglu_ln: bad shape");
-    hipLaunchKernelGGL(swiglu_ln_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, gx, ldg, xoff, w, b, out, ldo, rows, H, eps);
+    const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
+#define SG_LAUNCH(R) hipLaunchKernelGGL(swiglu_ln_kernel<R>, grid, block, 0, stream, gx, ldg, xoff, w, b, out, ldo, rows, H, eps)
+    if (H <= 8 * 64) SG_LAUNCH(8);
+    else if (H <= 32 * 64) SG_LAUNCH(32);
+    else if (H <= 44 * 64) SG_LAUNCH(44);
+    else SG_LAUNCH(0);
+#undef SG_LAUNCH
     return psam_launch_status("psam_swiglu_ln: launch failed");
 }
 
