@@ -34,6 +34,7 @@ typedef struct ihipStream_t* psam_stream_t; /* == hipStream_t */
 #define PSAM_ACT_NONE 0
 #define PSAM_ACT_GELU 1 /* exact erf GELU (torch.nn.GELU default) */
 #define PSAM_ACT_RELU 2
+#define PSAM_ACT_SWIGLU 3 /* GEMM only: W packs alternating 32-row blocks of fc1_g / fc1_x; C gets N/2 columns silu(g)*x */
 
 int32_t psam_version(void);
 const char* psam_last_error_string(void);

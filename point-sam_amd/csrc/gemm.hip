@@ -27,7 +27,7 @@ struct GemmArgs {
     const float* rowbias;   // [ceil(M/rowgroup), ldrb] or null (per-group broadcast row, e.g. the max-pooled half of conv2.0)
     int64_t lda, ldw, ldc, ldr, ldrb;
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sR1, sR2;  // batch strides (elements): z1 = z / batch2, z2 = z % batch2
-    int M, N, K, batch2, rowgroup, act;               // act: 0 none, 1 GELU(erf), 2 ReLU
+    int M, N, K, batch2, rowgroup, act;               // act: 0 none, 1 GELU(erf), 2 ReLU, 3 SwiGLU gate (paired tiles)
     float alpha;
     int tiles_m, tiles_n;
 };
@@ -40,9 +40,10 @@ constexpr int GEMM_BK = 32;   // K slab: one 128-byte row segment per operand ro
 // double-buffered tile at 48 KiB, i.e. 3 workgroups (12 waves) per CU.
 __device__ __forceinline__ int lds_chunk_off(int row, int chunk) { return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-template <int TM, int TN>
+template <int WM, int WN, int TM, int TN>  // WM x WN waves (WM*WN == 4), each TM x TN MFMA tiles of 32x32
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
-    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    static_assert(WM * WN == 4, "256-thread workgroup");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM * (GEMM_BK / 4) / 256;  // float4 loads per thread per slab
     constexpr int W_F4 = BN * (GEMM_BK / 4) / 256;
     __shared__ __attribute__((aligned(16))) float sA[2][BM * GEMM_BK];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     const float* W = p.W + z1 * p.sW1 + z2 * p.sW2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r32 = lane & 31, h = lane >> 5;
 
     f32x16 acc[TM][TN];
@@ -166,6 +167,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* C = p.C + z1 * p.sC1 + z2 * p.sC2;
     const float* R = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    if (p.act == 3) {
+        // SwiGLU gate fused into fc1 (timm SwiGLU: act(fc1_g x) * fc1_x x): the packed weight alternates 32-row blocks of
+        // fc1_g and fc1_x, so accumulator tile j=2q holds g and tile j=2q+1 holds x for the SAME 32 hidden units in
+        // the same lane/register.  Output has N/2 columns.
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row0 = m0 + (wm * TM + i) * 32;
+#pragma unroll
+                for (int q = 0; q < TN / 2; ++q) {
+                    const int colg = n0 + (wn * TN + 2 * q) * 32 + r32;   // packed column of g; x is 32 further
+                    if (colg >= p.N) continue;
+                    const float bg = p.bias ? p.bias[colg] : 0.f, bx = p.bias ? p.bias[colg + 32] : 0.f;
+                    const int ocol = (n0 + (wn * TN + 2 * q) * 32) / 2 + r32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row >= p.M) continue;
+                        C[(int64_t)row * p.ldc + ocol] = silu(acc[i][2 * q][r] + bg) * (acc[i][2 * q + 1][r] + bx);
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool group_uniform = p.rowbias && (p.rowgroup & 31) == 0;  // a 32-row MFMA tile never straddles two groups
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -202,7 +228,7 @@ PSAM_API int32_t psam_gemm_f32(const float* A, int64_t lda, int64_t sA1, int64_t
                                int32_t N, int32_t K, int32_t batch1, int32_t batch2, float alpha, int32_t act, hipStream_t stream) {
     PSAM_REQUIRE(A && W && C, PSAM_EINVAL, "psam_gemm_f32: null pointer");
     PSAM_REQUIRE(M > 0 && N > 0 && K > 0 && batch1 > 0 && batch2 > 0, PSAM_EINVAL, "psam_gemm_f32: bad shape");
-    PSAM_REQUIRE(act >= 0 && act <= 2, PSAM_EINVAL, "psam_gemm_f32: bad activation code");
+    PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_f32: bad activation code");
     PSAM_REQUIRE((int64_t)batch1 * batch2 <= 65535, PSAM_EINVAL, "psam_gemm_f32: batch > 65535");
     PSAM_REQUIRE(!rowbias || rowgroup > 0, PSAM_EINVAL, "psam_gemm_f32: rowbias needs rowgroup > 0");
     // float4 staging: K-contiguous operands whose rows start on 16-byte boundaries
@@ -225,13 +251,17 @@ PSAM_API int32_t psam_gemm_f32(const float* A, int64_t lda, int64_t sA1, int64_t
         const int64_t tmid = psam_cdiv(M, 128) * psam_cdiv(N, 64) * batch;
         cfg = (K <= 256 || M <= 64 || tmid < 512) ? 2 : 1;
     }
+    if (act == 3) {
+        PSAM_REQUIRE((N & 63) == 0 && !residual && !rowbias, PSAM_EINVAL, "psam_gemm_f32: SwiGLU epilogue needs N % 64 == 0, no residual/rowbias");
+        if (cfg == 2) cfg = 1;  // needs paired accumulator tiles (TN even)
+    }
     const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 128 : 64;
     p.tiles_m = (int)psam_cdiv(M, bm);
     p.tiles_n = (int)psam_cdiv(N, bn);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch);
-    if (cfg == 0) hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), grid, dim3(256), 0, stream, p);
-    else if (cfg == 1) hipLaunchKernelGGL((gemm_nt_kernel<2, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<1, 1>), grid, dim3(256), 0, stream, p);
+    if (cfg == 0) hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, p);       // 128x128
+    else if (cfg == 1) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2>), grid, dim3(256), 0, stream, p);  // 128x64, wave = 32x64
+    else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 1>), grid, dim3(256), 0, stream, p);                // 64x64
     return psam_launch_status("psam_gemm_f32: launch failed");
 }
 

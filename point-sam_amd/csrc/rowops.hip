@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // y = act(LayerNorm(x (+ res)))          nn.LayerNorm / apex FusedLayerNorm (pc_sam/utils/torch_utils.py:28-38)
-// One wave per row; rows of <= 1024 columns are held in registers, longer rows are re-read (L2-resident).
+// One wave per row; rows of <= 2816 columns are held in registers, longer rows are re-read (L2-resident).
 // ------------------------------------------------------------------------------------------------
 template <int NREG>  // NREG*64 >= cols for the register path; NREG == 0 -> streaming path
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
@@ -78,6 +78,7 @@ PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, i
     else if (cols <= 256) LN_LAUNCH(4);
     else if (cols <= 512) LN_LAUNCH(8);
     else if (cols <= 1024) LN_LAUNCH(16);
+    else if (cols <= 2816) LN_LAUNCH(44);
     else LN_LAUNCH(0);
 #undef LN_LAUNCH
     return psam_launch_status("psam_layernorm: launch failed");

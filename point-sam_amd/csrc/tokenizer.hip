@@ -16,7 +16,8 @@
 // ------------------------------------------------------------------------------------------------
 // FPS.  One 1024-thread workgroup per cloud (G dependent iterations; per iteration one block-wide
 // arg-max).  Coordinates are re-laid out once as planar x[] y[] z[] (float4-coalesced loads); the running
-// min-distance lives in registers (N <= 32768) or in the workspace (larger N).
+// min-distance lives in registers (N <= 32768) or in the workspace (larger N); for N <= 32768 the coordinates
+// are held on chip as well (registers + LDS), see fps_kernel.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -40,18 +41,26 @@ __global__ void fps_soa_kernel(const float* __restrict__ xyz, int N, int64_t npa
     base[2 * npad + n] = z;
 }
 
-// PPT4 = float4 groups per thread held in registers (0 => min-distance array streamed through `mdg`).
+// PPT4 = float4 groups (4 points each) per thread.  PPT4 > 0: the whole cloud lives on chip -- the running
+// min-distances in VGPRs, the coordinates of the first RG <= 5 groups in VGPRs and of the next LG <= 3 groups in LDS
+// (each thread only ever reads back its own 16-byte slots: LDS as spill space with ds_read_b128, no barrier involved).
+// A 1024-thread workgroup owns the CU: 128 VGPRs/lane (32 min-dist + 60 xyz + temporaries) and 144 of the 160 KiB LDS
+// hold a 32768-point cloud (512 KiB of state), so an iteration touches no memory besides the 12-byte winner broadcast.
+// (SG = groups that would not fit and are re-read from L2 each iteration; 0 for every instantiated size.)
+// PPT4 == 0: any N, min-distances and coordinates streamed from the workspace (L2-resident).
 template <int PPT4>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, const float* __restrict__ soa,
                                                           float* __restrict__ mdg, int N, int64_t npad, int G,
                                                           int64_t* __restrict__ idx_out, float* __restrict__ centers_out) {
+    constexpr int RG = PPT4 > 5 ? 5 : (PPT4 > 0 ? PPT4 : 1);                    // groups with coordinates in registers
+    constexpr int LG = PPT4 > 5 ? (PPT4 - 5 > 3 ? 3 : PPT4 - 5) : 0;          // groups with coordinates parked in LDS
+    constexpr int SG = PPT4 > 0 ? PPT4 - RG - LG : 0;                          // highest group(s): re-read from L2 (48 KiB/iter)
+    static_assert(SG <= 1, "register + LDS capacity of one CU");
+    constexpr int NREG = PPT4 > 0 ? PPT4 : 1;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const float* P = xyz + (int64_t)b * N * 3;
-    // Planar coordinates are read through a buffer descriptor: address = SGPR base + SGPR plane/group offset +
-    // one per-lane VGPR offset, so the 24 loads of an iteration need no per-load address registers (a 1024-thread
-    // workgroup leaves only 128 VGPRs per lane, 32 of which hold the running min-distances).
     const float* soa_b = soa + (int64_t)b * 3 * npad;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)soa_b, 0, (int)(3 * npad * 4), 0x00020000);
     const int plane_bytes = (int)(npad * 4);
@@ -61,9 +70,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
 
     __shared__ float s_val[2][FPS_WAVES];
     __shared__ int s_idx[2][FPS_WAVES];
+    __shared__ __attribute__((aligned(16))) f32x4 s_xyz[LG > 0 ? LG * 3 * FPS_THREADS : 1];
 
-    constexpr int NREG = PPT4 > 0 ? PPT4 : 1;
-    float4 md[NREG];
+    auto gload = [&](int g, int plane) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, g * (FPS_THREADS * 16) + plane * plane_bytes, 0));
+    };
+
+    f32x4 md[NREG];
+    f32x4 rx[RG], ry[RG], rz[RG];
     if (PPT4 > 0) {
 #pragma unroll
         for (int g = 0; g < NREG; ++g) {
@@ -72,6 +86,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
             md[g].y = base + 1 < N ? INFINITY : -1.0f;
             md[g].z = base + 2 < N ? INFINITY : -1.0f;
             md[g].w = base + 3 < N ? INFINITY : -1.0f;
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) { rx[g] = gload(g, 0); ry[g] = gload(g, 1); rz[g] = gload(g, 2); }
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {
+            s_xyz[(g * 3 + 0) * FPS_THREADS + tid] = gload(RG + g, 0);
+            s_xyz[(g * 3 + 1) * FPS_THREADS + tid] = gload(RG + g, 1);
+            s_xyz[(g * 3 + 2) * FPS_THREADS + tid] = gload(RG + g, 2);
         }
     } else {
         for (int g = 0; g < ngroups; ++g) {
@@ -92,33 +114,41 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     for (int j = 1; j < G; ++j) {
         const float cx = P[(int64_t)last * 3 + 0], cy = P[(int64_t)last * 3 + 1], cz = P[(int64_t)last * 3 + 2];
         float best = -1.0f;
-        int besti = 0x7fffffff;
-        auto visit = [&](float4& m, int g) {
-            const int goff = g * (FPS_THREADS * 16);
-            const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, goff, 0));
-            const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, goff + plane_bytes, 0));
-            const f32x4 z = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, goff + 2 * plane_bytes, 0));
-            const int base = (g * FPS_THREADS + tid) * 4;
+        // The winner is tracked as a slot number 4*g+k (an inline constant per compare -- per-point global indices would
+        // cost one loop-invariant VGPR each, 32 of the 128 available); the global index is rebuilt once after the scan.
+        int bslot = -1;
+        auto visit = [&](f32x4& m, const f32x4 x, const f32x4 y, const f32x4 z, int g) {
             float d;
-            d = dist2_exact(x.x, y.x, z.x, cx, cy, cz); m.x = fminf(m.x, d); if (m.x > best) { best = m.x; besti = base; }
-            d = dist2_exact(x.y, y.y, z.y, cx, cy, cz); m.y = fminf(m.y, d); if (m.y > best) { best = m.y; besti = base + 1; }
-            d = dist2_exact(x.z, y.z, z.z, cx, cy, cz); m.z = fminf(m.z, d); if (m.z > best) { best = m.z; besti = base + 2; }
-            d = dist2_exact(x.w, y.w, z.w, cx, cy, cz); m.w = fminf(m.w, d); if (m.w > best) { best = m.w; besti = base + 3; }
+            d = dist2_exact(x.x, y.x, z.x, cx, cy, cz); m.x = fminf(m.x, d); if (m.x > best) { best = m.x; bslot = 4 * g; }
+            d = dist2_exact(x.y, y.y, z.y, cx, cy, cz); m.y = fminf(m.y, d); if (m.y > best) { best = m.y; bslot = 4 * g + 1; }
+            d = dist2_exact(x.z, y.z, z.z, cx, cy, cz); m.z = fminf(m.z, d); if (m.z > best) { best = m.z; bslot = 4 * g + 2; }
+            d = dist2_exact(x.w, y.w, z.w, cx, cy, cz); m.w = fminf(m.w, d); if (m.w > best) { best = m.w; bslot = 4 * g + 3; }
         };
         if (PPT4 > 0) {
+            // ascending point index within the thread (register groups, LDS groups, streamed group) keeps "first maximum"
+            f32x4 sx, sy, sz;
+            if (SG > 0) { sx = gload(RG + LG, 0); sy = gload(RG + LG, 1); sz = gload(RG + LG, 2); }
 #pragma unroll
-            for (int g = 0; g < NREG; ++g) {
-                visit(md[g], g);
-                // keep at most two float4 groups of loads in flight: the 1024-thread block caps a wave at 128 VGPRs
-                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < RG; ++g) {
+                visit(md[g], rx[g], ry[g], rz[g], g);
+                if (PPT4 > 5) __builtin_amdgcn_sched_barrier(0);  // bound the scheduler's live temporaries (4 waves/SIMD hide latency)
             }
+#pragma unroll
+            for (int g = 0; g < LG; ++g) {
+                __builtin_amdgcn_sched_barrier(0);  // one LDS group (12 VGPRs) in flight at a time: the register file is full
+                visit(md[RG + g], s_xyz[(g * 3 + 0) * FPS_THREADS + tid], s_xyz[(g * 3 + 1) * FPS_THREADS + tid],
+                      s_xyz[(g * 3 + 2) * FPS_THREADS + tid], RG + g);
+            }
+            if (SG > 0) visit(md[RG + LG], sx, sy, sz, RG + LG);
         } else {
             for (int g = 0; g < ngroups; ++g) {
-                float4 m = MD4[g * FPS_THREADS + tid];
-                visit(m, g);
-                MD4[g * FPS_THREADS + tid] = m;
+                float4 m4 = MD4[g * FPS_THREADS + tid];
+                f32x4 m = {m4.x, m4.y, m4.z, m4.w};
+                visit(m, gload(g, 0), gload(g, 1), gload(g, 2), g);
+                MD4[g * FPS_THREADS + tid] = make_float4(m.x, m.y, m.z, m.w);
             }
         }
+        int besti = bslot < 0 ? 0x7fffffff : ((bslot >> 2) * FPS_THREADS + tid) * 4 + (bslot & 3);
         // wave arg-max, lowest index on ties
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {

@@ -71,10 +71,16 @@ class PointCloudSAM:
                 blk.bqkv = torch.cat([w[p + ".attn.q_proj.bias"], torch.zeros(D, device=self.device), w[p + ".attn.v_proj.bias"]]).contiguous()
                 H = cfg.vit.mlp_hidden
                 Hp = _round_up(H, 32)
-                w1 = torch.zeros(2 * Hp, D, device=self.device)
-                b1 = torch.zeros(2 * Hp, device=self.device)
-                w1[:H] = w[p + ".mlp.fc1_g.weight"]; w1[Hp:Hp + H] = w[p + ".mlp.fc1_x.weight"]
-                b1[:H] = w[p + ".mlp.fc1_g.bias"]; b1[Hp:Hp + H] = w[p + ".mlp.fc1_x.bias"]
+                # fc1_g / fc1_x packed as alternating 32-row blocks (PSAM_ACT_SWIGLU epilogue: g and x of the same hidden
+                # unit land in the same lane/register of adjacent accumulator tiles); hidden padded to Hp with zero rows.
+                def pad_rows(t):
+                    out = torch.zeros((Hp,) + tuple(t.shape[1:]), device=self.device)
+                    out[:H] = t
+                    return out
+                gw, xw = pad_rows(w[p + ".mlp.fc1_g.weight"]), pad_rows(w[p + ".mlp.fc1_x.weight"])
+                gb, xb = pad_rows(w[p + ".mlp.fc1_g.bias"]), pad_rows(w[p + ".mlp.fc1_x.bias"])
+                w1 = torch.stack([gw.view(Hp // 32, 32, D), xw.view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D).contiguous()
+                b1 = torch.stack([gb.view(Hp // 32, 32), xb.view(Hp // 32, 32)], 1).reshape(2 * Hp).contiguous()
                 w2 = torch.zeros(D, Hp, device=self.device)
                 w2[:, :H] = w[p + ".mlp.fc2.weight"]
                 blk.w1, blk.b1, blk.w2, blk.hp = w1, b1, w2, Hp
@@ -124,10 +130,12 @@ class PointCloudSAM:
         self._lin(p + ".attn.proj", o, residual=x, out=x)
         self._ln(p + ".norm2", x, vit.ln_eps, out=h)
         if vit.swiglu:
-            gx = ops.linear(h, blk.w1, blk.b1)
-            g = torch.empty(x.shape[0], blk.hp, device=x.device)
-            ops.swiglu_ln(gx, blk.hp, vit.mlp_hidden, self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, g)
-            ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
+            # fc1 with the SiLU gate fused in the GEMM epilogue -> u [M, Hp] (pad columns exactly 0), inner LayerNorm over
+            # the first H columns in place, then fc2 over K = Hp (zero-padded weight columns)
+            u = ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU)
+            Hh = vit.mlp_hidden
+            ops.layernorm(u[:, :Hh], self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, out=u[:, :Hh])
+            ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
         else:
             g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU)
             ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)

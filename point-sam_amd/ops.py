@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU = 0, 1, 2, 3
 
 # Measurement hook (bench.py): when set to a list, every GEMM launch is bracketed by two HIP events on the launch
 # stream and (start, end, flops, M, N, K) is appended.  None = no instrumentation.
@@ -139,7 +139,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         K = W.shape[1]
         assert x.shape[1] == K, (x.shape, W.shape)
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        out = torch.empty(M, N // 2 if act == ACT_SWIGLU else N, dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")

@@ -155,6 +155,29 @@ def test_gemm_epilogues_and_views(ops):
     _close(out, hyper.double() @ up.double().transpose(1, 2), 1e-4, what="batched gemm")
 
 
+def test_gemm_swiglu_epilogue(ops):
+    """fc1 with the SiLU gate in the epilogue: packed weight = alternating 32-row blocks of fc1_g / fc1_x."""
+    g = torch.Generator().manual_seed(11)
+    M, D, H = 200, 96, 170
+    Hp = 192
+    x = torch.randn(M, D, generator=g)
+    Wg, Wx = torch.randn(H, D, generator=g) / D ** 0.5, torch.randn(H, D, generator=g) / D ** 0.5
+    bg, bx = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    pad = lambda t: torch.cat([t, torch.zeros((Hp - H,) + tuple(t.shape[1:]))], 0)
+    W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
+    b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
+    for cfg in (0, 1, -1):
+        ops._lib.load().psam_gemm_force_config(cfg)
+        try:
+            u = ops.linear(cu(x), cu(W1), cu(b1), act=ops.ACT_SWIGLU)
+        finally:
+            ops._lib.load().psam_gemm_force_config(-1)
+        assert u.shape == (M, Hp)
+        want = F.silu(F.linear(x.double(), Wg.double(), bg.double())) * F.linear(x.double(), Wx.double(), bx.double())
+        _close(u[:, :H], want, 1e-4, what=f"swiglu epilogue cfg{cfg}")
+        assert (u[:, H:] == 0).all()
+
+
 @pytest.mark.parametrize("cols", [64, 128, 256, 512, 1000, 1024, 1408, 2730])
 def test_layernorm(ops, cols):
     g = torch.Generator().manual_seed(cols)
