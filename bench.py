@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--group-size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=8, help="clouds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run FPS/kNN of each batch inline instead of one batch ahead on a side stream")
     ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")
     args = ap.parse_args()
 
@@ -72,26 +73,42 @@ def main():
     xyz, rgb, prompt, labels = xyz.to(dev), rgb.to(dev), prompt.to(dev), labels.to(dev)
     total = B * world
 
-    def step():
-        masks, iou = model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False)
+    from point_sam_amd.model import BatchPipeline
+    pipe = BatchPipeline(model) if not args.no_pipeline else None
+
+    def finish(masks, iou):
         if world > 1:
             masks = psdist.gather_results(masks, total)
             iou = psdist.gather_results(iou, total)
         return masks, iou
+
+    def run_steps(n):
+        """n full passes (every batch is tokenized, encoded and decoded inside this call).  With the pipeline the
+        tokenizer stage of step k+1 is enqueued on its own stream before the dense stage of step k."""
+        out = None
+        if pipe is None:
+            for _ in range(n):
+                out = finish(*model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False))
+            return out
+        pipe.submit(xyz, rgb, prompt, labels, None, True)
+        for k in range(n):
+            if k + 1 < n:
+                pipe.submit(xyz, rgb, prompt, labels, None, True)
+            out = finish(*pipe.next())
+        return out
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     prof = None if args.no_gemm_profile else []
     ops.GEMM_PROFILE = prof
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
@@ -121,7 +138,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ViT-{args.config} N={N} g={args.groups}x{args.group_size} batch={B}/GPU 1 point prompt multimask",
-                       "global_batch": total, "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoint offline)"},
+                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None, "weights": "seeded random init (no checkpoint offline)"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

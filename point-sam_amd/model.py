@@ -26,6 +26,20 @@ def _round_up(x, m):
 
 
 @dataclass
+class TokenizerState:
+    """Index work that depends on the coordinates only (FPS, kNN grouping, 3-NN interpolation weights): the part of the
+    path that is latency-bound on a handful of CUs and can run ahead on its own stream (see BatchPipeline)."""
+    fps_idx: torch.Tensor        # [B, G] int64
+    centers: torch.Tensor        # [B, G, 3]
+    knn_idx: torch.Tensor        # [B, G, K] int64
+    interp_index: torch.Tensor   # [B, N, 3] int64
+    interp_weight: torch.Tensor  # [B, N, 3]
+
+    def tensors(self):
+        return (self.fps_idx, self.centers, self.knn_idx, self.interp_index, self.interp_weight)
+
+
+@dataclass
 class EncoderState:
     """What the reference keeps between encoder and decoder: the ``patches`` dict (common.py:121-123) and
     ``AuxInputs`` (mask_decoder.py:12-18)."""
@@ -142,18 +156,32 @@ class PointCloudSAM:
         return x
 
     # ------------------------------------------------------------------------------------------ encoder
+    def _prep_inputs(self, coords, features):
+        return (coords.to(self.device, torch.float32).contiguous(), features.to(self.device, torch.float32).contiguous())
+
     @torch.no_grad()
-    def encode(self, coords: torch.Tensor, features: torch.Tensor) -> EncoderState:
-        """PointCloudEncoder.forward (pc_encoder.py:118-145) + pe_layer(centers) (pc_sam.py:59)."""
-        cfg, w = self.cfg, self.w
+    def tokenize(self, coords: torch.Tensor, with_interp: bool = True) -> TokenizerState:
+        """FPS -> centers -> kNN groups (common.py:91-97) and, optionally ahead of time, the 3-NN interpolation
+        indices/weights the decoder needs (common.py:238-255)."""
         coords = coords.to(self.device, torch.float32).contiguous()
-        features = features.to(self.device, torch.float32).contiguous()
-        B, N, _ = coords.shape
         g = self.pc_encoder.patch_embed.grouper
         G, K = int(g.num_groups), int(g.group_size)
-        E = cfg.embed_dim
         fps_idx, centers = ops.fps(coords, G)
         knn_idx = ops.knn(centers, coords, K)
+        ii, iw = ops.three_nn(coords, centers) if with_interp else (None, None)
+        return TokenizerState(fps_idx, centers, knn_idx, ii, iw)
+
+    @torch.no_grad()
+    def encode(self, coords: torch.Tensor, features: torch.Tensor, tok: Optional[TokenizerState] = None) -> EncoderState:
+        """PointCloudEncoder.forward (pc_encoder.py:118-145) + pe_layer(centers) (pc_sam.py:59)."""
+        cfg, w = self.cfg, self.w
+        coords, features = self._prep_inputs(coords, features)
+        B, N, _ = coords.shape
+        E = cfg.embed_dim
+        if tok is None:
+            tok = self.tokenize(coords, with_interp=False)
+        fps_idx, centers, knn_idx = tok.fps_idx, tok.centers, tok.knn_idx
+        G = centers.shape[1]
         emb = self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, centers, knn_idx)
         x = self._lin("pc_encoder.patch_proj", emb)
         p1 = ops.pos_l1(centers, w["pc_encoder.pos_embed.0.weight"], w["pc_encoder.pos_embed.0.bias"])
@@ -164,7 +192,7 @@ class PointCloudSAM:
         pc_emb = self._lin("pc_encoder.out_proj", h).view(B, G, E)
         pc_pe = torch.empty(B, G, E, device=self.device)
         ops.fourier_pe(centers, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], pc_pe, G, G * E, flag=self._flag)
-        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1))
+        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1), tok.interp_index, tok.interp_weight)
 
     # ------------------------------------------------------------------------------------------ decoder
     def _attn(self, prefix, q_in, k_in, v_in, Z, Lq, Lk):
@@ -290,3 +318,41 @@ class PointCloudSAM:
 
     def cuda(self):
         return self
+
+
+class BatchPipeline:
+    """Two-stage software pipeline over a stream of independent batches: the coordinate-only tokenizer stage (FPS, kNN,
+    3-NN; a few latency-bound workgroups) of batch i+1 runs on its own high-priority HIP stream while the dense stage
+    (mini-PointNet, ViT, decoder; every CU) of batch i runs on the caller's stream.  ``submit`` enqueues stage 1,
+    ``next`` enqueues stage 2 of the oldest submitted batch and returns its (masks, iou).  Results are identical to
+    ``predict_masks`` (same kernels, same order per batch); only the interleaving on the device changes."""
+
+    def __init__(self, model: PointCloudSAM):
+        from collections import deque
+        self.model = model
+        self.tok_stream = torch.cuda.Stream(device=model.device, priority=-1)
+        self.queue = deque()
+
+    @torch.no_grad()
+    def submit(self, coords, features, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True):
+        m = self.model
+        coords, features = m._prep_inputs(coords, features)
+        main = torch.cuda.current_stream(m.device)
+        self.tok_stream.wait_stream(main)  # inputs may have been produced on the caller's stream
+        with torch.cuda.stream(self.tok_stream):
+            tok = m.tokenize(coords, with_interp=True)
+            ready = torch.cuda.Event()
+            ready.record(self.tok_stream)
+        for t in tok.tensors():
+            t.record_stream(main)  # allocated on tok_stream, consumed on the caller's stream
+        self.queue.append((tok, ready, coords, features, prompt_coords, prompt_labels, prompt_masks, multimask_output))
+
+    @torch.no_grad()
+    def next(self):
+        tok, ready, coords, features, pc, pl, pm, mm = self.queue.popleft()
+        torch.cuda.current_stream(self.model.device).wait_event(ready)
+        st = self.model.encode(coords, features, tok)
+        return self.model.decode(st, pc, pl, pm, mm)
+
+    def __len__(self):
+        return len(self.queue)

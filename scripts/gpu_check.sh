@@ -14,12 +14,13 @@ for t in $FUNCS_K; do
   echo "== kernels::$t" >> $LOG
   timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "$t" 2>&1 | tail -40 >> $LOG
 done
-FUNCS_E="test_against_reference_golden test_against_oracle test_properties_full_size test_predictor_click_loop test_out_of_range_coordinates_raise"
+FUNCS_E="test_batch_pipeline_matches_predict_masks test_against_reference_golden test_against_oracle test_properties_full_size test_predictor_click_loop test_out_of_range_coordinates_raise"
 for t in $FUNCS_E; do
   echo "== e2e::$t" >> $LOG
   timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -s --tb=short -p no:cacheprovider -k "$t" 2>&1 | tail -40 >> $LOG
 done
 echo "== bench" >> $LOG
-timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> $LOG
+timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> $LOG
 cat gpurun_out/bench.json >> $LOG; tail -5 gpurun_out/bench.err >> $LOG
+timeout 900 python bench.py --steps 10 --warmup 2 --no-pipeline --no-cpu-baseline > gpurun_out/bench_nopipe.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_nopipe.json >> $LOG
 grep -E "passed|failed|error|exit" $LOG | tail -40

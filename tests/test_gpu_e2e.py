@@ -148,3 +148,26 @@ def test_out_of_range_coordinates_raise(gpu):
         model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels[:, :0].cuda())
     m, _ = model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda())  # flag was reset
     assert torch.isfinite(m).all()
+
+
+def test_batch_pipeline_matches_predict_masks(gpu):
+    """The 2-stream pipeline (tokenizer one batch ahead) returns bit-identical results to the inline path."""
+    from point_sam_amd.model import BatchPipeline
+    cfg = get_config("tiny", 64, 16)
+    model = gpu(cfg, random_state_dict(cfg, 4))
+    batches = []
+    for i in range(4):
+        xyz, rgb, prompt, labels = O.synthetic_batch(2, 3000 + 500 * i, seed=20 + i)
+        batches.append(tuple(t.cuda() for t in (xyz, rgb, prompt, labels)))
+    want = [model.predict_masks(*b) for b in batches]
+    pipe = BatchPipeline(model)
+    got = []
+    pipe.submit(*batches[0])
+    for k in range(len(batches)):
+        if k + 1 < len(batches):
+            pipe.submit(*batches[k + 1])
+        got.append(pipe.next())
+    torch.cuda.synchronize()
+    for (m1, i1), (m2, i2) in zip(want, got):
+        assert torch.equal(m1, m2) and torch.equal(i1, i2)
+    model.check_coordinate_range()
