@@ -89,6 +89,13 @@ int32_t psam_gemm_f32(const float* A, int64_t lda, int64_t sA1, int64_t sA2, con
                       int64_t ldc, int64_t sC1, int64_t sC2, const float* bias, const float* residual, int64_t ldr, int64_t sR1, int64_t sR2,
                       const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, int32_t batch1, int32_t batch2,
                       float alpha, int32_t act, psam_stream_t stream);
+/* Same contract, fp32-accurate on the bf16 matrix pipe: each fp32 operand is split exactly into 3 bf16 terms while its
+ * K slab is staged, 6 of the 9 partial products are accumulated in fp32 (dropped terms <= 2^-24 relative).  128x128
+ * tiles: use for M, N >= 128. */
+int32_t psam_gemm_bf16x6(const float* A, int64_t lda, int64_t sA1, int64_t sA2, const float* W, int64_t ldw, int64_t sW1, int64_t sW2, float* C,
+                         int64_t ldc, int64_t sC1, int64_t sC2, const float* bias, const float* residual, int64_t ldr, int64_t sR1, int64_t sR2,
+                         const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, int32_t batch1, int32_t batch2,
+                         float alpha, int32_t act, psam_stream_t stream);
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 void psam_gemm_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64, 2=64x64 tiles, -1=auto */

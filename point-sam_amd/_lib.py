@@ -25,6 +25,8 @@ SIGNATURES = {
     "psam_group_max": (i32, [ptr, i64, ptr, i64, i64, i32, i32, ptr]),
     "psam_gemm_f32": (i32, [ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, ptr, i64, i64, i64, ptr, i64, i32,
                             i32, i32, i32, i32, i32, f32, i32, ptr]),
+    "psam_gemm_bf16x6": (i32, [ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, ptr, i64, i64, i64, ptr, i64, i32,
+                               i32, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_linear": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
     "psam_gemm_force_config": (None, [i32]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),

@@ -19,6 +19,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=
 SOURCES = [
     ("tokenizer.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
+    ("gemm_split.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("error.cpp", ["-x", "hip"]),

@@ -58,8 +58,14 @@ class EncoderState:
 class PointCloudSAM:
     """HIP implementation behind the reference's ``PointCloudSAM`` inference interface."""
 
-    def __init__(self, cfg: ModelConfig, state_dict, device="cuda"):
+    def __init__(self, cfg: ModelConfig, state_dict, device="cuda", precision: str = "f32"):
+        """precision: arithmetic of the large GEMMs -- "f32" (v_mfma_f32_32x32x2_f32, exact fp32 products) or "bf16x6"
+        (exact 3-way bf16 split of both operands, 6 partial products on the bf16 matrix pipe, fp32 accumulation:
+        fp32-GEMM accuracy at 6/16 of the matrix-pipe time; see csrc/gemm_split.hip)."""
         check_state_dict(cfg, state_dict)
+        if precision not in ops.GEMM_MODES:
+            raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -180,6 +186,11 @@ class PointCloudSAM:
         E = cfg.embed_dim
         if tok is None:
             tok = self.tokenize(coords, with_interp=False)
+        with ops.gemm_mode(self.precision):
+            return self._encode(coords, features, tok, B, N, E)
+
+    def _encode(self, coords, features, tok, B, N, E):
+        cfg, w = self.cfg, self.w
         fps_idx, centers, knn_idx = tok.fps_idx, tok.centers, tok.knn_idx
         G = centers.shape[1]
         emb = self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, centers, knn_idx)
@@ -245,6 +256,10 @@ class PointCloudSAM:
     @torch.no_grad()
     def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True):
         """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState."""
+        with ops.gemm_mode(self.precision):
+            return self._decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output)
+
+    def _decode(self, st, prompt_coords, prompt_labels, prompt_masks, multimask_output):
         cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
         B, N, _ = st.coords.shape
         G = st.centers.shape[1]

@@ -11,21 +11,52 @@ from ._lib import check
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU = 0, 1, 2, 3
 
-# Measurement hook (bench.py): when set to a list, every GEMM launch is bracketed by two HIP events on the launch
-# stream and (start, end, flops, M, N, K) is appended.  None = no instrumentation.
+# Measurement hook (bench.py): when GEMM_PROFILE is a list, every GEMM_PROFILE_EVERY-th GEMM launch is bracketed by two
+# HIP events on the launch stream and (start, end, flops, M, N, K) is appended.  Sampling keeps the perturbation of the
+# timed region small (an event pair costs ~20 us of host+queue time; 260 pairs per step were a 17 % slowdown).
 GEMM_PROFILE = None
+GEMM_PROFILE_EVERY = 7
+_gemm_counter = 0
+
+
+# GEMM arithmetic: "f32" = v_mfma_f32_32x32x2_f32 everywhere (exact fp32 products); "bf16x6" = large GEMMs on the bf16
+# matrix pipe with the exact 3-way operand split (fp32-accurate, see csrc/gemm_split.hip), small ones stay on "f32".
+GEMM_MODE = "f32"
+SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 64
+GEMM_MODES = ("f32", "bf16x6")
+
+
+class gemm_mode:
+    """Context manager selecting the GEMM arithmetic for the enclosed launches."""
+
+    def __init__(self, mode):
+        if mode not in GEMM_MODES:
+            raise ValueError(f"unknown GEMM mode {mode!r}; expected one of {GEMM_MODES}")
+        self.mode = mode
+
+    def __enter__(self):
+        global GEMM_MODE
+        self.prev, GEMM_MODE = GEMM_MODE, self.mode
+
+    def __exit__(self, *exc):
+        global GEMM_MODE
+        GEMM_MODE = self.prev
 
 
 def _gemm_call(fn_args, flops, M, N, K, what):
+    global _gemm_counter
     L = _lib.load()
-    if GEMM_PROFILE is None:
-        check(L.psam_gemm_f32(*fn_args), what)
+    split = GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K
+    fn = L.psam_gemm_bf16x6 if split else L.psam_gemm_f32
+    _gemm_counter += 1
+    if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
+        check(fn(*fn_args), what)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    check(L.psam_gemm_f32(*fn_args), what)
+    check(fn(*fn_args), what)
     e.record()
-    GEMM_PROFILE.append((s, e, flops, M, N, K))
+    GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6" if split else "f32"))
 
 
 def _stream():

@@ -65,8 +65,9 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_against_oracle(gpu, name):
+def test_against_oracle(gpu, name, precision):
     mk, B, N, M = CASES[name]
     cfg = mk()
     sd = random_state_dict(cfg, seed=42)
@@ -77,7 +78,7 @@ def test_against_oracle(gpu, name):
         prompt = prompt + 0.0  # same click per mask set is fine: exercises the repeat path
     torch.set_num_threads(max(1, torch.get_num_threads()))
     want_masks, want_iou, mid = O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="exact", return_intermediates=True)
-    model = gpu(cfg, sd)
+    model = gpu(cfg, sd, precision=precision)
     st = model.encode(xyz.cuda(), rgb.cuda())
     assert torch.equal(st.fps_idx.cpu(), mid["patches"]["fps_idx"]), "FPS indices not bit-exact"
     assert torch.equal(st.knn_idx.cpu(), mid["patches"]["knn_idx"]), "kNN indices not bit-exact"
@@ -85,7 +86,7 @@ def test_against_oracle(gpu, name):
     masks, iou = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
     assert torch.equal(st.interp_index.cpu(), mid["aux"].interp_index), "3-NN indices not bit-exact"
     e_m, e_i = _maxerr(masks, want_masks), _maxerr(iou, want_iou)
-    print(f"\n[{name}] max|err| embeddings {e_emb:.2e} masks {e_m:.2e} iou {e_i:.2e} (|logit| max {want_masks.abs().max():.2f})")
+    print(f"\n[{name} {precision}] max|err| embeddings {e_emb:.2e} masks {e_m:.2e} iou {e_i:.2e} (|logit| max {want_masks.abs().max():.2f})")
     assert e_m < TOL and e_i < TOL, (e_emb, e_m, e_i)
     # second click: previous best mask as dense prompt, single-mask output
     best = torch.gather(want_masks, 1, want_iou.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0]

@@ -155,6 +155,50 @@ def test_gemm_epilogues_and_views(ops):
     _close(out, hyper.double() @ up.double().transpose(1, 2), 1e-4, what="batched gemm")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 36), (128, 128, 32), (520, 640, 2752)])
+def test_gemm_bf16x6_matches_fp64_like_f32(ops, M, N, K):
+    """The split-bf16 GEMM must be as accurate as the f32-MFMA GEMM (both compared with an fp64 reference), also on
+    operands with a wide dynamic range, ragged M/N and a K tail."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))   # rows spanning ~4 decades
+    W = torch.randn(N, K, generator=g) * torch.exp(torch.randn(1, K, generator=g)) / K ** 0.5
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    want = F.gelu(x.double() @ W.double().T + b.double()) + res.double()
+    scale = (x.double().abs() @ W.double().abs().T + 1.0)
+    L = ops._lib.load()
+    args = lambda y: (cu(x).data_ptr(), K, 0, 0, cu(W).data_ptr(), K, 0, 0, y.data_ptr(), N, 0, 0, cu(b).data_ptr(), cu(res).data_ptr(), N, 0, 0, 0, 0, 0,
+                      M, N, K, 1, 1, 1.0, 1, torch.cuda.current_stream().cuda_stream)
+    xd, Wd, bd, rd = cu(x), cu(W), cu(b), cu(res)
+    errs = {}
+    for name, fn in (("f32", L.psam_gemm_f32), ("bf16x6", L.psam_gemm_bf16x6)):
+        y = torch.empty(M, N, device="cuda")
+        rc = fn(xd.data_ptr(), K, 0, 0, Wd.data_ptr(), K, 0, 0, y.data_ptr(), N, 0, 0, bd.data_ptr(), rd.data_ptr(), N, 0, 0, 0, 0, 0, M, N, K, 1, 1, 1.0, 1,
+                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, L.psam_last_error_string()
+        errs[name] = ((y.cpu().double() - want).abs() / scale).max().item()
+    assert errs["bf16x6"] < 3e-7 * math.sqrt(K) + 1e-7, errs
+    assert errs["bf16x6"] < 4 * errs["f32"] + 1e-7, errs
+
+
+def test_gemm_bf16x6_epilogues(ops):
+    g = torch.Generator().manual_seed(3)
+    M, D, H, Hp, grp = 384, 128, 170, 192, 64
+    x = torch.randn(M, D, generator=g)
+    Wg, Wx = torch.randn(H, D, generator=g) / D ** 0.5, torch.randn(H, D, generator=g) / D ** 0.5
+    bg, bx = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    pad = lambda t: torch.cat([t, torch.zeros((Hp - H,) + tuple(t.shape[1:]))], 0)
+    W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
+    b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
+    rb = torch.randn(M // grp, 2 * Hp, generator=g)
+    with ops.gemm_mode("bf16x6"):
+        u = ops.linear(cu(x), cu(W1), cu(b1), act=ops.ACT_SWIGLU)
+        y = ops.linear(cu(x), cu(W1), None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
+    want = F.silu(F.linear(x.double(), Wg.double(), bg.double())) * F.linear(x.double(), Wx.double(), bx.double())
+    _close(u[:, :H], want, 1e-4, what="bf16x6 swiglu epilogue")
+    assert (u[:, H:] == 0).all()
+    _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what="bf16x6 rowbias+relu")
+
+
 def test_gemm_swiglu_epilogue(ops):
     """fc1 with the SiLU gate in the epilogue: packed weight = alternating 32-row blocks of fc1_g / fc1_x."""
     g = torch.Generator().manual_seed(11)
