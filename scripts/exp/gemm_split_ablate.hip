@@ -40,7 +40,8 @@ constexpr int SG_PLANE_A = SG_BM * SG_ROWB;              // bytes per plane
 constexpr int SG_PLANE_W = SG_BN * SG_ROWB;
 
 // x (2 floats) -> packed bf16 pairs hi, mid, lo with x == hi + mid + lo exactly
-__device__ __forceinline__ void split3(const f32x2 x, unsigned& hi, unsigned& mid, unsigned& lo) {
+template <int ABL> __device__ __forceinline__ void split3(const f32x2 x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    if (ABL == 1) { hi = (__builtin_bit_cast(unsigned, x[0]) >> 16) | (__builtin_bit_cast(unsigned, x[1]) & 0xffff0000u); mid = 0; lo = 0; return; }
     const bf16x2 h = __builtin_convertvector(x, bf16x2);
     const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
     const bf16x2 m = __builtin_convertvector(r1, bf16x2);
@@ -51,6 +52,7 @@ __device__ __forceinline__ void split3(const f32x2 x, unsigned& hi, unsigned& mi
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+template <int ABL>
 __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p) {
     // LDS: [A planes hi,mid,lo][W planes hi,mid,lo]
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SG_PLANE_A + 3 * SG_PLANE_W];
@@ -101,11 +103,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned h0, m0_, l0, h1, m1, l1;
-            split3(f32x2{ra[i][0], ra[i][1]}, h0, m0_, l0);
-            split3(f32x2{ra[i][2], ra[i][3]}, h1, m1, l1);
+            split3<ABL>(f32x2{ra[i][0], ra[i][1]}, h0, m0_, l0);
+            split3<ABL>(f32x2{ra[i][2], ra[i][3]}, h1, m1, l1);
             sp[0][i][0] = u32x2{h0, h1}; sp[0][i][1] = u32x2{m0_, m1}; sp[0][i][2] = u32x2{l0, l1};
-            split3(f32x2{rw[i][0], rw[i][1]}, h0, m0_, l0);
-            split3(f32x2{rw[i][2], rw[i][3]}, h1, m1, l1);
+            split3<ABL>(f32x2{rw[i][0], rw[i][1]}, h0, m0_, l0);
+            split3<ABL>(f32x2{rw[i][2], rw[i][3]}, h1, m1, l1);
             sp[1][i][0] = u32x2{h0, h1}; sp[1][i][1] = u32x2{m0_, m1}; sp[1][i][2] = u32x2{l0, l1};
         }
     };
@@ -125,65 +127,56 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p)
     const unsigned char* a_base = sA + wm * 64 * SG_ROWB;
     const unsigned char* w_base = sW + wn * 64 * SG_ROWB;
 
-    auto load_frags = [&](int s, bf16x8 (&af)[2][3], bf16x8 (&wf)[2][3]) {
+    auto compute_slab = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[2][3], wf[2][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                af[i][q] = *reinterpret_cast<const bf16x8*>(a_base + q * SG_PLANE_A + i * 32 * SG_ROWB + frag_off[s]);
-                wf[i][q] = *reinterpret_cast<const bf16x8*>(w_base + q * SG_PLANE_W + i * 32 * SG_ROWB + frag_off[s]);
-            }
-    };
-    // smallest partial products first (hl, lh, mm), then hm, mh, then hh; term-major so that the four accumulator tiles
-    // rotate (an accumulator is reused only after three other MFMAs)
-#define SG_TERM(AF, WF, PA, PW)                                                                                 \
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    af[i][q] = *reinterpret_cast<const bf16x8*>(a_base + q * SG_PLANE_A + i * 32 * SG_ROWB + frag_off[s]);
+                    wf[i][q] = *reinterpret_cast<const bf16x8*>(w_base + q * SG_PLANE_W + i * 32 * SG_ROWB + frag_off[s]);
+                }
+            // smallest partial products first (hl, lh, mm), then hm, mh, then hh; term-major so that the four accumulator
+            // tiles rotate (an accumulator is reused only after three other MFMAs)
+#define SG_TERM(PA, PW)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i][PA], WF[j][PW], acc[i][j], 0, 0, 0);
-#define SG_STEP(AF, WF) SG_TERM(AF, WF, 0, 2) SG_TERM(AF, WF, 2, 0) SG_TERM(AF, WF, 1, 1) SG_TERM(AF, WF, 0, 1) SG_TERM(AF, WF, 1, 0) SG_TERM(AF, WF, 0, 0)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], wf[j][PW], acc[i][j], 0, 0, 0);
+            if (ABL != 2) { SG_TERM(0, 2) SG_TERM(2, 0) SG_TERM(1, 1) SG_TERM(0, 1) SG_TERM(1, 0) } SG_TERM(0, 0)
+#undef SG_TERM
+        }
+    };
 
     const int nslabs = (p.K + SG_BK - 1) / SG_BK;
     // Pipeline.  At the top of slab t: sp = split slab t (registers); (ra0, rw0) = fp32 slab t+1 (landed or landing).
-    // Slab t: [barrier: LDS free] sp -> LDS [barrier: LDS ready]; fragments of k16-step 0; then 2 x 24 MFMAs, in whose
-    // shadow issue: the fragment reads of step 1, the split of slab t+1 into sp (~250 VALU: up to 7 fit behind one
-    // 32-cycle MFMA) and the refill of the fp32 registers with slab t+2.  Measured with SQ counters on the unpipelined
-    // version: 30 % of a wave's time went to issuing that VALU/LDS work serially and 18 % to waits, matrix pipe 47 % busy.
-    // Two workgroups share a CU (one wave of each per SIMD).  They start together and do identical work, so without help
-    // they run in lock-step: both in their MFMA phase (each at half rate), then both staging (matrix pipe idle) -- measured
-    // 47 % pipe utilisation.  A static priority for every other hardware wave slot breaks the symmetry: the favoured wave
-    // runs its MFMA phase at full rate while the other stages, and the two settle half a period apart.
-    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(1);  // HW_REG_HW_ID[3:0] = wave slot in the SIMD
-    bf16x8 af0[2][3], wf0[2][3], af1[2][3], wf1[2][3];
+    // Slab t: [barrier: LDS free] sp -> LDS [barrier: LDS ready] then the MFMAs of slab t with, in their shadow (VALU and
+    // loads issue while the matrix pipe works), the split of slab t+1 into sp and the refill of the fp32 registers with
+    // slab t+2 (a full slab period, ~2 us with two workgroups per CU, to land).  One fp32 set only: with two the kernel
+    // needs > 256 registers and drops to one wave per SIMD.  Loads past K return zeros (bounds-checked descriptor).
     load_slab(0, ra0, rw0);
     split_regs(ra0, rw0);
     load_slab(SG_BK, ra0, rw0);
     for (int t = 0; t < nslabs; ++t) {
-        __syncthreads();
-        store_split();
-        __syncthreads();
-        load_frags(0, af0, wf0);
-        load_frags(1, af1, wf1);
-        SG_STEP(af0, wf0)
+        if (ABL != 4) { __syncthreads(); store_split(); __syncthreads(); }
+        compute_slab();
         split_regs(ra0, rw0);                 // slab t+1
-        SG_STEP(af1, wf1)
-        load_slab((t + 2) * SG_BK, ra0, rw0);
-        // requested issue order (one scheduling region: the loop body after the second barrier)
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // fragments of step 0
+        if (ABL != 3) load_slab((t + 2) * SG_BK, ra0, rw0);
+        // Ask the scheduler for: fragment reads + MFMAs of the first k16 step, then the second step's MFMAs with the
+        // split arithmetic of the next slab in their shadow (as late as possible: its operands were loaded one slab
+        // ago), then the global loads of slab t+2.
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {                            // step-0 MFMAs, fragment reads of step 1 behind them
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
-        }
+        for (int i = 0; i < 24; ++i) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) {                            // remaining MFMAs with the split arithmetic behind them
+        for (int i = 0; i < 24; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 7, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
         __builtin_amdgcn_sched_group_barrier(0x20, 8, 0);
     }
-#undef SG_STEP
-#undef SG_TERM
 
     // ---- epilogue (C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     float* C = p.C + z1 * p.sC1 + z2 * p.sC2;
@@ -231,31 +224,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p)
     }
 }
 
-// Same argument list as psam_gemm_f32 (include/pointsam_hip.h).
-PSAM_API int32_t psam_gemm_bf16x6(const float* A, int64_t lda, int64_t sA1, int64_t sA2, const float* W, int64_t ldw, int64_t sW1,
-                                  int64_t sW2, float* C, int64_t ldc, int64_t sC1, int64_t sC2, const float* bias, const float* residual,
-                                  int64_t ldr, int64_t sR1, int64_t sR2, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,
-                                  int32_t N, int32_t K, int32_t batch1, int32_t batch2, float alpha, int32_t act, hipStream_t stream) {
-    PSAM_REQUIRE(A && W && C, PSAM_EINVAL, "psam_gemm_bf16x6: null pointer");
-    PSAM_REQUIRE(M > 0 && N > 0 && K > 0 && batch1 > 0 && batch2 > 0, PSAM_EINVAL, "psam_gemm_bf16x6: bad shape");
-    PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_bf16x6: bad activation code");
-    PSAM_REQUIRE((int64_t)batch1 * batch2 <= 65535, PSAM_EINVAL, "psam_gemm_bf16x6: batch > 65535");
-    PSAM_REQUIRE(!rowbias || rowgroup > 0, PSAM_EINVAL, "psam_gemm_bf16x6: rowbias needs rowgroup > 0");
-    PSAM_REQUIRE((K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && (sA1 & 3) == 0 && (sA2 & 3) == 0 && (sW1 & 3) == 0 &&
-                     (sW2 & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
-                 PSAM_EALIGN, "psam_gemm_bf16x6: K, lda, ldw, batch strides must be multiples of 4 and A, W 16-byte aligned");
-    PSAM_REQUIRE(((int64_t)M - 1) * lda + K < ((int64_t)1 << 29) - 8 && ((int64_t)N - 1) * ldw + K < ((int64_t)1 << 29) - 8, PSAM_EINVAL,
-                 "psam_gemm_bf16x6: one operand matrix must span < 2 GiB (32-bit buffer offsets); split the batch");
-    PSAM_REQUIRE(act != 3 || ((N & 63) == 0 && !residual && !rowbias), PSAM_EINVAL,
-                 "psam_gemm_bf16x6: SwiGLU epilogue needs N % 64 == 0, no residual/rowbias");
-    SplitGemmArgs p;
-    p.A = A; p.W = W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias;
-    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
-    p.sA1 = sA1; p.sA2 = sA2; p.sW1 = sW1; p.sW2 = sW2; p.sC1 = sC1; p.sC2 = sC2; p.sR1 = sR1; p.sR2 = sR2;
-    p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
-    p.tiles_m = (int)psam_cdiv(M, SG_BM);
-    p.tiles_n = (int)psam_cdiv(N, SG_BN);
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)((int64_t)batch1 * batch2));
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(256), 0, stream, p);
-    return psam_launch_status("psam_gemm_bf16x6: launch failed");
+
+extern "C" __attribute__((visibility("default"))) int gemm_split_ablate(const float* A, const float* W, float* C, const float* bias, int M, int N, int K, int abl, hipStream_t stream) {
+    SplitGemmArgs p; p.A=A; p.W=W; p.C=C; p.bias=bias; p.residual=nullptr; p.rowbias=nullptr; p.lda=K; p.ldw=K; p.ldc=N; p.ldr=0; p.ldrb=0;
+    p.sA1=p.sA2=p.sW1=p.sW2=p.sC1=p.sC2=p.sR1=p.sR2=0; p.M=M; p.N=N; p.K=K; p.batch2=1; p.rowgroup=1; p.act=0; p.alpha=1.f;
+    p.tiles_m=(M+127)/128; p.tiles_n=(N+127)/128;
+    dim3 grid(p.tiles_m*p.tiles_n,1,1);
+    switch(abl){
+      case 0: hipLaunchKernelGGL((gemm_bf16x6_kernel<0>), grid, dim3(256), 0, stream, p); break;
+      case 1: hipLaunchKernelGGL((gemm_bf16x6_kernel<1>), grid, dim3(256), 0, stream, p); break;
+      case 2: hipLaunchKernelGGL((gemm_bf16x6_kernel<2>), grid, dim3(256), 0, stream, p); break;
+      case 3: hipLaunchKernelGGL((gemm_bf16x6_kernel<3>), grid, dim3(256), 0, stream, p); break;
+      case 4: hipLaunchKernelGGL((gemm_bf16x6_kernel<4>), grid, dim3(256), 0, stream, p); break;
+    }
+    return (int)hipGetLastError();
 }
+void psam_set_error(const char*) {}

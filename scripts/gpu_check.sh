@@ -22,5 +22,5 @@ done
 echo "== bench" >> $LOG
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> $LOG
 cat gpurun_out/bench.json >> $LOG; tail -5 gpurun_out/bench.err >> $LOG
-timeout 900 python bench.py --steps 10 --warmup 2 --no-pipeline --no-cpu-baseline > gpurun_out/bench_nopipe.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_nopipe.json >> $LOG
+timeout 900 python bench.py --steps 10 --warmup 2 --precision f32 --no-cpu-baseline > gpurun_out/bench_f32.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_f32.json >> $LOG
 grep -E "passed|failed|error|exit" $LOG | tail -40
