@@ -98,6 +98,7 @@ int32_t psam_gemm_bf16x6(const float* A, int64_t lda, int64_t sA1, int64_t sA2, 
                          float alpha, int32_t act, psam_stream_t stream);
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
+void psam_gemm_bf16x6_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
 void psam_gemm_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64, 2=64x64 tiles, -1=auto */
 
 /* y = act(LayerNorm(x (+ res))).  Replaces nn.LayerNorm / apex FusedLayerNorm (pc_sam/utils/torch_utils.py:28-38)

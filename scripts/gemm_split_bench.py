@@ -12,8 +12,10 @@ for name, M, N, K in SHAPES:
     rows = torch.randint(0, M, (256,), generator=g).cuda()
     ref = (x[rows].double() @ W.double().T + b.double())
     line = f"{name:11s} {M:7d}x{N:5d}x{K:5d} |"
-    for mode in ("f32", "bf16x6"):
-        ops.GEMM_MODE = mode
+    for mode in ("f32", "bf16x6:0", "bf16x6:1"):
+        if ":" in mode:
+            ops._lib.load().psam_gemm_bf16x6_force_config(int(mode[-1]))
+        ops.GEMM_MODE = mode.split(":")[0]
         y = ops.linear(x, W, b)
         err = ((y[rows].double() - ref).abs().max() / ref.abs().max()).item()
         for _ in range(2): ops.linear(x, W, b, out=y)
