@@ -285,7 +285,9 @@ PSAM_API int32_t psam_gemm_bf16x6(const float* A, int64_t lda, int64_t sA1, int6
     p.sA1 = sA1; p.sA2 = sA2; p.sW1 = sW1; p.sW2 = sW2; p.sC1 = sC1; p.sC2 = sC2; p.sR1 = sR1; p.sR2 = sR2;
     p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     int cfg = g_split_cfg;
-    if (cfg < 0) cfg = 0;
+    // measured (scripts/gemm_split_bench.py): both shapes saturate near 158 TFLOP/s fp32-equivalent once >= 2 workgroups
+    // share a CU; with fewer than 512 128x128 tiles (N = 1024 GEMMs at M = 4096) the 128x64 shape keeps 2+ per CU.
+    if (cfg < 0) cfg = (psam_cdiv(M, 128) * psam_cdiv(N, 128) * (int64_t)batch1 * batch2 >= 512 && K > 256) ? 0 : 1;
     const int bn = cfg == 0 ? 128 : 64;
     p.tiles_m = (int)psam_cdiv(M, 128);
     p.tiles_n = (int)psam_cdiv(N, bn);

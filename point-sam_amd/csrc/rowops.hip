@@ -67,12 +67,87 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// float4 variant: NV4*256 >= cols; rows must be 16-byte aligned with ld >= round_up(cols, 4) (the last, partial float4 of
+// a row is read whole -- still inside the row's stride -- masked in the statistics and written back element-wise).
+template <int NV4>
+__global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
+                                                           const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                                           int64_t ldy, int64_t rows, int cols, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ldx);
+    const f32x4* rr = res ? reinterpret_cast<const f32x4*>(res + row * ldr) : nullptr;
+    float* yrow = y + row * ldy;
+    const int c4n = (cols + 3) >> 2;
+    const float inv = 1.0f / (float)cols;
+    f32x4 v[NV4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 64 + lane;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c < c4n) {
+            t = xr[c];
+            if (rr) t += rr[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c * 4 + e >= cols) t[e] = 0.f;
+        }
+        v[i] = t;
+        s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    const float mean = wave_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = (c * 4 + e < cols) ? v[i][e] - mean : 0.f;
+            q += d * d;
+        }
+    }
+    const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 64 + lane;
+        if (c * 4 + 3 < cols) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + c * 4), b4 = *reinterpret_cast<const f32x4*>(b + c * 4);
+            f32x4 o = (v[i] - mean) * r * w4 + b4;
+            if (act == 1) { o[0] = gelu_erf(o[0]); o[1] = gelu_erf(o[1]); o[2] = gelu_erf(o[2]); o[3] = gelu_erf(o[3]); }
+            *reinterpret_cast<f32x4*>(yrow + c * 4) = o;
+        } else if (c * 4 < cols) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c * 4 + e < cols) {
+                    float o = (v[i][e] - mean) * r * w[c * 4 + e] + b[c * 4 + e];
+                    if (act == 1) o = gelu_erf(o);
+                    yrow[c * 4 + e] = o;
+                }
+            }
+        }
+    }
+}
+
 PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
                                 int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, hipStream_t stream) {
     PSAM_REQUIRE(x && w && b && y, PSAM_EINVAL, "psam_layernorm: null pointer");
     PSAM_REQUIRE(rows > 0 && cols > 0, PSAM_EINVAL, "psam_layernorm: bad shape");
     PSAM_REQUIRE(act == 0 || act == 1, PSAM_EINVAL, "psam_layernorm: act must be 0 or 1 (GELU)");
     const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
+    const int64_t c4 = ((int64_t)cols + 3) & ~(int64_t)3;
+    const bool vec = cols >= 256 && cols <= 4096 && ((ldx | ldy | (res ? ldr : 0)) & 3) == 0 && ldx >= c4 && ldy >= c4 && (!res || ldr >= c4) &&
+                     (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)w | (uintptr_t)b) & 15) == 0;
+    if (vec) {
+#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act)
+        if (cols <= 256) LNV_LAUNCH(1);
+        else if (cols <= 512) LNV_LAUNCH(2);
+        else if (cols <= 1024) LNV_LAUNCH(4);
+        else if (cols <= 2048) LNV_LAUNCH(8);
+        else LNV_LAUNCH(16);
+#undef LNV_LAUNCH
+        return psam_launch_status("psam_layernorm: launch failed");
+    }
 #define LN_LAUNCH(R) hipLaunchKernelGGL(layernorm_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act)
     if (cols <= 128) LN_LAUNCH(2);
     else if (cols <= 256) LN_LAUNCH(4);
