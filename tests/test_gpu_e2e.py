@@ -172,3 +172,52 @@ def test_batch_pipeline_matches_predict_masks(gpu):
     for (m1, i1), (m2, i2) in zip(want, got):
         assert torch.equal(m1, m2) and torch.equal(i1, i2)
     model.check_coordinate_range()
+
+
+def test_cfg3_large_scene_tokenizer_and_run(gpu):
+    """BASELINE config #3 (ViT-L, N=131072, 2048x256, batch 1): the streaming-FPS path, K=256 selection and 3-NN among
+    2048 centers are bit-exact against the oracle at full size; the whole path runs and is deterministic."""
+    from point_sam_amd import ops
+    N, G, K = 131072, 2048, 256
+    xyz, rgb, prompt, labels = O.synthetic_batch(1, N, seed=3)
+    want_fps = O.fps(xyz, G)
+    xyz_d = xyz.cuda()
+    idx, centers = ops.fps(xyz_d, G)
+    assert torch.equal(idx.cpu(), want_fps)
+    sub = torch.arange(0, G, 16)  # every 16th center keeps the C oracle's kNN in seconds
+    _, want_knn = O.knn(centers.cpu()[:, sub], xyz, K, "exact")
+    got_knn = ops.knn(centers[:, sub].contiguous(), xyz_d, K)
+    assert torch.equal(got_knn.cpu(), want_knn)
+    wi, ww = O.interp_weights(xyz[:, :8192], centers.cpu(), "exact")
+    gi, gw = ops.three_nn(xyz_d[:, :8192].contiguous(), centers)
+    assert torch.equal(gi.cpu(), wi) and (gw.cpu() - ww).abs().max() < 1e-6
+    cfg = get_config("tiny", G, K)  # full-size tokenizer / grouping / upsampling with a small ViT
+    model = gpu(cfg, random_state_dict(cfg, 2), precision="bf16x6")
+    m1, i1 = model.predict_masks(xyz_d, rgb.cuda(), prompt.cuda(), labels.cuda())
+    m2, i2 = model.predict_masks(xyz_d, rgb.cuda(), prompt.cuda(), labels.cuda())
+    assert m1.shape == (1, 3, N) and torch.isfinite(m1).all() and torch.equal(m1, m2)
+
+
+def test_cfg5_giant_five_click_loop(gpu):
+    """BASELINE config #5 (ViT-giant, N=32768, 512x64, 5 clicks, encoder cached) against the oracle's click loop."""
+    from point_sam_amd.predictor import PointSAMPredictor
+    cfg = get_config("giant", 512, 64)
+    sd = random_state_dict(cfg, seed=42)
+    N = 32768
+    xyz, rgb, _, _ = O.synthetic_batch(1, N, seed=42)
+    g = torch.Generator().manual_seed(1)
+    clicks = xyz[:, torch.randint(0, N, (5,), generator=g)]
+    labels = torch.tensor([[1, 1, 0, 1, 0]])
+    want = O.click_loop(sd, cfg, xyz, rgb, clicks, labels)
+    pred = PointSAMPredictor(gpu(cfg, sd, precision="bf16x6"))
+    xyz_d, rgb_d = xyz.cuda(), rgb.cuda()
+    prompt_mask = None
+    for t in range(5):
+        pred.set_pointcloud(xyz_d, rgb_d)
+        mask, scores, logits = pred.predict_masks(clicks[:, : t + 1].cuda(), labels[:, : t + 1].cuda(), prompt_mask, prompt_mask is None)
+        e = _maxerr(logits, want[t][0])
+        print(f"\n[giant click {t + 1}] max|err| {e:.2e}")
+        assert e < TOL and _maxerr(scores, want[t][1]) < TOL
+        # the oracle feeds ITS best mask forward; do the same so both loops see identical prompts
+        wm, wi = want[t]
+        prompt_mask = (torch.gather(wm, 1, wi.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0] if t == 0 else wm[:, 0]).cuda()
