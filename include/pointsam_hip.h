@@ -75,6 +75,16 @@ int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers
                       const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
                       float* out, psam_stream_t stream);
 
+/* Click simulation of the evaluation protocol.  psam_error_regions: fn = gt & !(logit > 0), fp = !gt & (logit > 0)
+ * (logits == NULL: fn = gt, fp = 0) -- sample_fixed_points, pc_sam/model/common.py:388-405.  psam_border_farthest: per
+ * region the member point farthest from the region's complement (squared distance; -1/-1 when either is empty) --
+ * sample_furthest_points_from_border + torkit3d chamfer_distance, pc_sam/model/common.py:443-474.
+ *   gt/fn/fp/region [Z,N] uint8, xyz [B,N,3], Z = B*rep. */
+int32_t psam_error_regions(const uint8_t* gt, const float* logits, uint8_t* fn, uint8_t* fp, int64_t total, psam_stream_t stream);
+size_t psam_border_farthest_workspace_bytes(int32_t Z, int32_t N);
+int32_t psam_border_farthest(const float* xyz, const uint8_t* region, int32_t B, int32_t rep, int32_t N, int64_t* out_idx, float* out_dist,
+                             void* ws, size_t ws_bytes, psam_stream_t stream);
+
 /* Max over the K members of each group: x [groups*K, C] -> y [groups, C].
  * Replaces torch.max(x, dim=-2): pc_sam/model/common.py:502,505. */
 int32_t psam_group_max(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t groups, int32_t K, int32_t C, psam_stream_t stream);

@@ -50,7 +50,8 @@ def _lib():
         _LIB.fps_f32.argtypes = [p, i64, i64, p, p]
         _LIB.knn_f32.argtypes = [p, p, i64, i64, i64, p, p]
         _LIB.three_nn_f32.argtypes = [p, p, i64, i64, ctypes.c_float, p, p]
-        for f in (_LIB.fps_f32, _LIB.knn_f32, _LIB.three_nn_f32):
+        _LIB.border_farthest_f32.argtypes = [p, p, i64, p, p]
+        for f in (_LIB.fps_f32, _LIB.knn_f32, _LIB.three_nn_f32, _LIB.border_farthest_f32):
             f.restype = ctypes.c_int
     return _LIB
 
@@ -397,6 +398,78 @@ def click_loop(sd, cfg, coords, features, clicks, labels, mode="exact"):
             prompt_masks = masks[:, 0]
         outs.append((masks, iou))
     return outs
+
+
+# --------------------------------------------------------------------------------------------------
+# Prompt simulation for the evaluation protocol          (pc_sam/model/common.py:287-316,368-474; pc_sam.py:139-194)
+# --------------------------------------------------------------------------------------------------
+def border_farthest(coords: torch.Tensor, region: torch.Tensor):
+    """sample_furthest_points_from_border (common.py:443-474) for one cloud: (index, squared distance) of the region point
+    farthest from the region's complement, or (-1, -1.0) when either is empty."""
+    xyz = _f32c(coords)
+    reg = region.to(torch.uint8).contiguous()
+    idx = ctypes.c_int64(-1)
+    dist = ctypes.c_float(-1.0)
+    _lib().border_farthest_f32(xyz.data_ptr(), reg.data_ptr(), xyz.shape[0], ctypes.byref(idx), ctypes.byref(dist))
+    return int(idx.value), float(dist.value)
+
+
+def sample_eval_prompts(points, gt_masks, pred_logits):
+    """sample_prompts_adapter(..., is_eval=True) (common.py:287-316) -> sample_fixed_points (common.py:368-441).
+    points [B,N,3], gt_masks [B,M,N] bool, pred_logits None or [B*M,N] -> (coords [B*M,1,3], labels [B*M,1] bool)."""
+    B, M, N = gt_masks.shape
+    coords, labels = [], []
+    for i in range(B):
+        for j in range(M):
+            gt = gt_masks[i, j]
+            if pred_logits is None:  # from_error_region=True with fn = gt, fp = 0
+                n, _ = border_farthest(points[i], gt)
+            else:
+                pred = pred_logits.reshape(B, M, N)[i, j] > 0
+                pn, pd = border_farthest(points[i], gt & ~pred)   # false negatives
+                nn_, nd = border_farthest(points[i], ~gt & pred)   # false positives
+                if pd > nd:
+                    n = pn
+                elif nd == -1:
+                    n, _ = border_farthest(points[i], gt)
+                else:
+                    n = nn_
+            if n < 0:
+                raise ValueError("empty region: the reference would fail in torch.stack on None (common.py:439)")
+            coords.append(points[i][n][None])
+            labels.append(gt[n][None])
+    return torch.stack(coords), torch.stack(labels)
+
+
+@torch.no_grad()
+def forward_eval(sd, cfg, coords, features, gt_masks, prompt_iters=None, mode="exact"):
+    """PointCloudSAM.forward(coords, features, gt_masks, is_eval=True) in eval mode (pc_sam.py:90-196)."""
+    B, M, N = gt_masks.shape
+    iters = cfg.prompt_iters if prompt_iters is None else prompt_iters
+    pc_emb, patches = pc_encoder(sd, cfg, coords, features, mode)
+    centers, knn_idx = patches["centers"], patches["knn_idx"]
+    aux = Aux(coords=coords, centers=centers)
+    pc_pe = pe_encoding(sd, centers)
+    prompt_coords = coords.new_empty((B * M, 0, 3))
+    prompt_labels = gt_masks.new_empty((B * M, 0))
+    prompt_masks, outputs = None, []
+    for i in range(iters):
+        nc, nl = sample_eval_prompts(coords, gt_masks, prompt_masks)
+        prompt_coords = torch.cat([prompt_coords, nc], dim=1)
+        prompt_labels = torch.cat([prompt_labels, nl], dim=1)
+        sparse = point_encoder(sd, prompt_coords, prompt_labels)
+        dense = mask_encoder(sd, cfg, prompt_masks, coords, centers, knn_idx)
+        dense = dense.repeat_interleave(sparse.shape[0] // dense.shape[0], 0)
+        masks, iou = mask_decoder(sd, cfg, pc_emb, pc_pe, sparse, dense, aux, i == 0, mode)
+        if i == 0:
+            best = iou.argmax(1)
+            prompt_masks = torch.gather(masks, 1, best.view(-1, 1, 1).expand(-1, 1, N))[:, 0]
+        else:
+            best = 0
+            prompt_masks = masks[:, 0]
+        outputs.append(dict(prompt_coords=prompt_coords, prompt_labels=prompt_labels, masks=masks, iou_preds=iou,
+                            max_iou_pred_ind=best, prompt_masks=prompt_masks))
+    return outputs
 
 
 # --------------------------------------------------------------------------------------------------

@@ -113,3 +113,28 @@ int three_nn_f32(const float *xyz, const float *centers, int64_t N, int64_t G, f
     }
     return 0;
 }
+
+/* Farthest-from-border point of a region: among points with region[n]==1, the one whose nearest point with
+ * region==0 is farthest (squared distance, fp32, same dist2 as above); first maximum = lowest index on ties.
+ * Reference: sample_furthest_points_from_border (pc_sam/model/common.py:443-474), which calls the third-party
+ * torkit3d chamfer_distance (absent) for the nearest-background distance and torch.argmax/max on it.
+ * Returns 0 and (*idx, *dist) or 1 with idx=-1, dist=-1 when the region or its complement is empty (common.py:458-460). */
+int border_farthest_f32(const float *xyz, const unsigned char *region, int64_t N, int64_t *idx, float *dist) {
+    int64_t nfg = 0, nbg = 0;
+    for (int64_t n = 0; n < N; ++n) { if (region[n]) ++nfg; else ++nbg; }
+    *idx = -1; *dist = -1.0f;
+    if (nfg == 0 || nbg == 0) return 1;
+    float best = -1.0f;
+    for (int64_t n = 0; n < N; ++n) {
+        if (!region[n]) continue;
+        float m = INFINITY;
+        for (int64_t k = 0; k < N; ++k) {
+            if (region[k]) continue;
+            float d = dist2(xyz + 3 * n, xyz + 3 * k);
+            if (d < m) m = d;
+        }
+        if (m > best) { best = m; *idx = n; }
+    }
+    *dist = best;
+    return 0;
+}

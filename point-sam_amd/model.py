@@ -326,7 +326,80 @@ class PointCloudSAM:
             self.check_coordinate_range()
         return masks, iou
 
-    __call__ = predict_masks
+    # ------------------------------------------------------------------------------------------ evaluation protocol
+    @torch.no_grad()
+    def sample_prompts(self, coords, gt_masks, pred_logits=None, is_eval=True):
+        """sample_prompts_adapter (common.py:287-316): one simulated click per (cloud, mask).  Fixed sampler
+        (sample_fixed_points, common.py:368-441) = the point of the error region farthest from its border; the random
+        sampler (common.py:319-365) only when not evaluating and the batch IoU is exactly 1.
+        coords [B,N,3], gt_masks [B,M,N] bool, pred_logits None | [B*M,N] -> (coords [B*M,1,3], labels [B*M,1] bool)."""
+        B, M, N = gt_masks.shape
+        Z = B * M
+        gt = gt_masks.reshape(Z, N).to(self.device).to(torch.uint8).contiguous()
+        if pred_logits is not None:
+            pred_logits = pred_logits.to(self.device, torch.float32).contiguous()
+            if not is_eval:
+                pred = pred_logits > 0
+                g = gt.bool()
+                if float((g & pred).sum()) / max(float((g | pred).sum()), 1.0) >= 1.0:  # common.py:310-315
+                    idx = torch.stack([(m.nonzero()[:, 0])[torch.randint(0, int(m.sum()), (1,), device=m.device)] for m in g]).view(Z)
+                    return self._gather_clicks(coords, gt, idx, M)
+        fn, fp = ops.error_regions(gt, pred_logits)
+        pi, pd = ops.border_farthest(coords, fn)
+        if pred_logits is None:  # from_error_region=True: mask = fn | fp = gt
+            idx = pi
+        else:
+            ni, nd = ops.border_farthest(coords, fp)
+            pd_h, nd_h = pd.cpu(), nd.cpu()  # the reference branches on these per mask too (common.py:424-437)
+            take_p = pd_h > nd_h
+            none = (~take_p) & (nd_h == -1)
+            idx = torch.where(take_p.to(self.device), pi, ni)
+            if bool(none.any()):
+                gi, _ = ops.border_farthest(coords, gt)
+                idx = torch.where(none.to(self.device), gi, idx)
+        if bool((idx < 0).any()):
+            raise ValueError("empty ground-truth / error region: no click can be sampled (the reference fails in torch.stack, common.py:439)")
+        return self._gather_clicks(coords, gt, idx, M)
+
+    @staticmethod
+    def _gather_clicks(coords, gt, idx, M):
+        Z = gt.shape[0]
+        pts = coords.repeat_interleave(M, 0) if M > 1 else coords
+        ar = torch.arange(Z, device=gt.device)
+        return pts[ar, idx][:, None, :].contiguous(), gt[ar, idx].bool()[:, None]
+
+    @torch.no_grad()
+    def forward(self, coords, features, gt_masks, is_eval=False):
+        """PointCloudSAM.forward in inference mode (pc_sam.py:90-196): encoder once, then ``prompt_iters`` iterations of
+        {simulate a click from the current error region, decode with all clicks so far and the previous best mask}.
+        Returns the reference's list of dicts.  (The two training-only mask-refinement iterations, pc_sam.py:128-134,
+        apply only when ``self.training``; this object is inference-only.)"""
+        coords, features = self._prep_inputs(coords, features)
+        B, M, N = gt_masks.shape
+        gt_masks = gt_masks.to(self.device)
+        st = self.encode(coords, features)
+        prompt_coords = coords.new_empty((B * M, 0, 3))
+        prompt_labels = torch.empty((B * M, 0), dtype=torch.bool, device=self.device)
+        prompt_masks, outputs = None, []
+        for i in range(self.prompt_iters):
+            nc, nl = self.sample_prompts(coords, gt_masks, prompt_masks, is_eval)
+            prompt_coords = torch.cat([prompt_coords, nc], dim=1)
+            prompt_labels = torch.cat([prompt_labels, nl], dim=1)
+            masks, iou_preds = self.decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output=(i == 0))
+            if i == 0:  # pc_sam.py:176-180
+                max_iou_pred_ind = torch.argmax(iou_preds, dim=1)
+                prompt_masks = torch.gather(masks, 1, max_iou_pred_ind.view(-1, 1, 1).expand(-1, 1, N))[:, 0].contiguous()
+            else:       # pc_sam.py:181-183
+                max_iou_pred_ind = 0
+                prompt_masks = masks[:, 0].contiguous()
+            outputs.append(dict(prompt_coords=prompt_coords, prompt_labels=prompt_labels, masks=masks, iou_preds=iou_preds,
+                                max_iou_pred_ind=max_iou_pred_ind, prompt_masks=prompt_masks))
+        self.check_coordinate_range()
+        return outputs
+
+    def __call__(self, *args, **kwargs):
+        """``model(coords, features, gt_masks, is_eval=True)`` like the reference's nn.Module (evaluation/eval_kitti.py:363)."""
+        return self.forward(*args, **kwargs)
 
     def eval(self):
         return self

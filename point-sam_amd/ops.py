@@ -260,3 +260,31 @@ def interp3(src, idx3, w3, out, rep):
     N = idx3.shape[1]
     check(_lib.load().psam_interp3(src.data_ptr(), idx3.data_ptr(), w3.data_ptr(), out.data_ptr(), rep, Z, N, G, C, _stream()), "psam_interp3")
     return out
+
+
+# ------------------------------------------------------------------------------------------ click simulation (eval protocol)
+def error_regions(gt: torch.Tensor, logits):
+    """gt [Z,N] uint8/bool, logits [Z,N] f32 or None -> (fn, fp) uint8 [Z,N].  common.py:388-405."""
+    gt = _chk(gt.to(torch.uint8), torch.uint8, "gt")
+    if logits is not None:
+        _chk(logits, name="logits")
+    fn, fp = torch.empty_like(gt), torch.empty_like(gt)
+    check(_lib.load().psam_error_regions(gt.data_ptr(), _p(logits), fn.data_ptr(), fp.data_ptr(), gt.numel(), _stream()), "psam_error_regions")
+    return fn, fp
+
+
+def border_farthest(xyz: torch.Tensor, region: torch.Tensor):
+    """xyz [B,N,3], region [Z,N] uint8 -> (idx [Z] int64, dist2 [Z]); -1 where the region or its complement is empty.
+    common.py:443-474."""
+    _chk(xyz, name="xyz")
+    region = _chk(region.to(torch.uint8), torch.uint8, "region")
+    B, N, _ = xyz.shape
+    Z = region.shape[0]
+    L = _lib.load()
+    nbytes = L.psam_border_farthest_workspace_bytes(Z, N)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=xyz.device)
+    idx = torch.empty(Z, dtype=torch.int64, device=xyz.device)
+    dist = torch.empty(Z, dtype=torch.float32, device=xyz.device)
+    check(L.psam_border_farthest(xyz.data_ptr(), region.data_ptr(), B, Z // B, N, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+          "psam_border_farthest")
+    return idx, dist

@@ -32,3 +32,8 @@ def golden_swiglu():
 @pytest.fixture(scope="session")
 def golden_gelu():
     return load_golden("ref_tiny_gelu")
+
+
+@pytest.fixture(scope="session")
+def golden_forward():
+    return load_golden("ref_tiny_forward_eval")

@@ -40,18 +40,27 @@ from point_sam_amd.weights import random_state_dict, state_dict_checksum  # noqa
 # ---------------------------------------------------------------------------- third-party stand-ins
 def _install_stubs():
     def batch_index_select(inp, index, dim):
+        # index [B, G] on dim=1 of [B, N, C] -> [B, G, C] (common.py:92);  index [B] on dim=1 of [B, C, N] -> [B, N] (pc_sam.py:178)
+        if index.dim() == dim:
+            idx = index.reshape(list(index.shape) + [1] * (inp.dim() - index.dim()))
+            shape = list(inp.shape)
+            shape[dim] = 1
+            return torch.gather(inp, dim, idx.expand(shape)).squeeze(dim)
         view = list(index.shape) + [1] * (inp.dim() - index.dim())
-        expand = list(inp.shape)
-        expand[dim] = -1
-        idx = index.reshape(view).expand(expand[: index.dim()] + list(inp.shape[index.dim():]))
+        idx = index.reshape(view).expand(list(index.shape) + list(inp.shape[index.dim():]))
         return torch.gather(inp, dim, idx)
 
     def sample_farthest_points(points, num_samples):
         return O.fps(points, num_samples)
 
     def chamfer_distance(a, b):
-        d = torch.cdist(a, b)
-        m1, i1 = d.min(dim=2)
+        # nearest-neighbour SQUARED distance a -> b by direct differences (what a CUDA chamfer kernel computes);
+        # only its arg-max and the comparison of two of its maxima are used by the reference (common.py:466-471)
+        d = a[:, :, None, :] - b[:, None, :, :]
+        d2 = d[..., 0] * d[..., 0]
+        d2 = d2 + d[..., 1] * d[..., 1]
+        d2 = d2 + d[..., 2] * d[..., 2]
+        m1, i1 = d2.min(dim=2)
         return m1, i1
 
     mods = {
@@ -200,7 +209,31 @@ def make_case(name, cfg_name, B, N, M, P, seed):
     print(name, {k: v.shape for k, v in arrays.items()}, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_forward_case(name, cfg_name, B, N, seed, iters):
+    """The reference's evaluation protocol: PointCloudSAM.forward(coords, features, gt_masks, is_eval=True)."""
+    cfg = get_config(cfg_name)
+    sd = random_state_dict(cfg, seed=seed)
+    model = build_reference_model(cfg, sd)
+    model.prompt_iters = iters
+    xyz, rgb, _, _ = O.synthetic_batch(B, N, seed=seed)
+    gt = torch.stack([xyz[..., 0] > 0.1, (xyz - torch.tensor([0.2, 0.1, -0.1])).norm(dim=-1) < 0.25], 1)  # [B, 2, N]: a half space and a small ball
+    with torch.no_grad():
+        outs = model(xyz, rgb, gt, is_eval=True)
+    arrays = dict(xyz=xyz.numpy(), rgb=rgb.numpy(), gt_masks=gt.numpy())
+    for i, o in enumerate(outs):
+        arrays[f"prompt_coords_{i}"] = o["prompt_coords"].numpy()
+        arrays[f"prompt_labels_{i}"] = o["prompt_labels"].numpy()
+        arrays[f"masks_{i}"] = o["masks"].numpy()
+        arrays[f"iou_preds_{i}"] = o["iou_preds"].numpy()
+        arrays[f"prompt_masks_{i}"] = o["prompt_masks"].numpy()
+    meta = dict(cfg=cfg_name, B=B, N=N, M=2, iters=iters, seed=seed, weights_checksum=state_dict_checksum(sd), torch=torch.__version__)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{name}.npz")
+    np.savez_compressed(path, meta=np.array(repr(meta)), **arrays)
+    print(name, os.path.getsize(path) // 1024, "KiB", [arrays[f"prompt_labels_{i}"][:, -1].tolist() for i in range(iters)])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     make_case("ref_tiny_swiglu", "tiny", B=2, N=1024, M=2, P=2, seed=7)
     make_case("ref_tiny_gelu", "tiny_gelu", B=1, N=777, M=1, P=1, seed=11)
+    make_forward_case("ref_tiny_forward_eval", "tiny", B=2, N=1024, seed=7, iters=4)

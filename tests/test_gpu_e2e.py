@@ -221,3 +221,29 @@ def test_cfg5_giant_five_click_loop(gpu):
         # the oracle feeds ITS best mask forward; do the same so both loops see identical prompts
         wm, wi = want[t]
         prompt_mask = (torch.gather(wm, 1, wi.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0] if t == 0 else wm[:, 0]).cuda()
+
+
+def test_forward_eval_protocol(gpu, golden_forward):
+    """model(coords, features, gt_masks, is_eval=True) -- the reference's evaluation entry point (eval_kitti.py:363) --
+    against the golden run of the reference's own PointCloudSAM.forward and against the oracle."""
+    meta, a = golden_forward
+    cfg = get_config(meta["cfg"])
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    for precision in ("f32", "bf16x6"):
+        model = gpu(cfg, sd, precision=precision)
+        model.prompt_iters = meta["iters"]
+        outs = model(a["xyz"].cuda(), a["rgb"].cuda(), a["gt_masks"].cuda(), is_eval=True)
+        assert len(outs) == meta["iters"]
+        for i, o in enumerate(outs):
+            assert torch.equal(o["prompt_coords"].cpu(), a[f"prompt_coords_{i}"]), f"iteration {i}: simulated click differs from the reference"
+            assert torch.equal(o["prompt_labels"].cpu(), a[f"prompt_labels_{i}"])
+            assert _maxerr(o["masks"], a[f"masks_{i}"]) < TOL and _maxerr(o["iou_preds"], a[f"iou_preds_{i}"]) < TOL
+            assert _maxerr(o["prompt_masks"], a[f"prompt_masks_{i}"]) < TOL
+    # sampler branches (false positives only / no error at all) against the oracle
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(2, 700, 3, generator=g) * 2 - 1
+    gt = torch.stack([pts[..., 0] > 0, pts[..., 1] > 0.3], 1)
+    for logits in (torch.full((4, 700), 5.0), torch.where(gt.reshape(4, 700), 5.0, -5.0), torch.randn(4, 700, generator=g)):
+        wc, wl = O.sample_eval_prompts(pts, gt, logits)
+        gc, gl = model.sample_prompts(pts.cuda(), gt.cuda(), logits.cuda(), is_eval=True)
+        assert torch.equal(gc.cpu(), wc) and torch.equal(gl.cpu(), wl)

@@ -334,3 +334,24 @@ def test_invalid_arguments_raise(ops):
         ops.linear(torch.zeros(8, 6, device="cuda"), torch.zeros(8, 6, device="cuda"))             # K % 4 != 0
     with pytest.raises(ops._lib.PointSamHipError):
         ops.fps(torch.zeros(1, 8, 3, device="cuda"), 9)                                             # G > N
+
+
+@pytest.mark.parametrize("N,B,rep", [(400, 1, 3), (3000, 2, 2), (32768, 1, 1)])
+def test_border_farthest_and_error_regions(ops, N, B, rep):
+    g = torch.Generator().manual_seed(N)
+    xyz, _ = _cloud(B, N, seed=N)
+    Z = B * rep
+    gt = torch.stack([(xyz[z // rep, :, z % 3] > 0.05 * z) for z in range(Z)])                  # [Z,N] bool
+    logits = torch.randn(Z, N, generator=g) + torch.where(gt, 0.8, -0.8)
+    fn, fp = ops.error_regions(cu(gt), cu(logits))
+    pred = logits > 0
+    assert torch.equal(fn.cpu().bool(), gt & ~pred) and torch.equal(fp.cpu().bool(), ~gt & pred)
+    fn0, fp0 = ops.error_regions(cu(gt), None)
+    assert torch.equal(fn0.cpu().bool(), gt) and not fp0.any()
+    regions = torch.cat([gt, gt & ~pred, ~gt & pred, torch.zeros(1, N, dtype=torch.bool).expand(Z, N), torch.ones(1, N, dtype=torch.bool).expand(Z, N)])
+    # kernel takes Z' = B*rep' regions: run each family separately
+    for name, reg in (("gt", gt), ("fn", gt & ~pred), ("fp", ~gt & pred), ("empty", torch.zeros(Z, N, dtype=torch.bool)), ("full", torch.ones(Z, N, dtype=torch.bool))):
+        idx, dist = ops.border_farthest(cu(xyz), cu(reg))
+        for z in range(Z):
+            wi, wd = O.border_farthest(xyz[z // rep], reg[z])
+            assert int(idx[z]) == wi and float(dist[z]) == wd, (name, z, int(idx[z]), wi, float(dist[z]), wd)

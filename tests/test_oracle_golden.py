@@ -104,3 +104,39 @@ def test_interp_weights_sum_to_one():
     ii, iw = O.interp_weights(xyz, centers, "exact")
     torch.testing.assert_close(iw.sum(-1), torch.ones(1, 500), atol=1e-6, rtol=0)
     assert ((ii >= 0) & (ii < 20)).all()
+
+
+def test_oracle_forward_eval_matches_reference(golden_forward):
+    """The evaluation protocol (encoder once, one simulated click per iteration from the error region, previous best
+    mask fed back) against PointCloudSAM.forward(..., is_eval=True) of the reference."""
+    meta, a = golden_forward
+    cfg = get_config(meta["cfg"])
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    assert state_dict_checksum(sd) == pytest.approx(meta["weights_checksum"], rel=1e-12)
+    outs = O.forward_eval(sd, cfg, a["xyz"], a["rgb"], a["gt_masks"], prompt_iters=meta["iters"], mode="reference")
+    assert len(outs) == meta["iters"]
+    for i, o in enumerate(outs):
+        assert torch.equal(o["prompt_coords"], a[f"prompt_coords_{i}"]), f"iteration {i}: sampled click differs"
+        assert torch.equal(o["prompt_labels"], a[f"prompt_labels_{i}"])
+        torch.testing.assert_close(o["masks"], a[f"masks_{i}"], atol=3e-4, rtol=1e-4)
+        torch.testing.assert_close(o["iou_preds"], a[f"iou_preds_{i}"], atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(o["prompt_masks"], a[f"prompt_masks_{i}"], atol=3e-4, rtol=1e-4)
+
+
+def test_border_farthest_branches():
+    """fn / fp / empty-region branches of the click sampler on hand-made predictions."""
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(1, 400, 3, generator=g) * 2 - 1
+    gt = (pts[..., 0] > 0)[:, None]                                    # [1,1,N]
+    n, d = O.border_farthest(pts[0], gt[0, 0])
+    x = pts[0].double()
+    d2 = ((x[gt[0, 0]][:, None] - x[~gt[0, 0]][None]) ** 2).sum(-1).min(1).values
+    assert n == int(gt[0, 0].nonzero()[d2.argmax()]) and abs(d - float(d2.max())) < 1e-6
+    assert O.border_farthest(pts[0], torch.zeros(400, dtype=torch.bool)) == (-1, -1.0)
+    assert O.border_farthest(pts[0], torch.ones(400, dtype=torch.bool)) == (-1, -1.0)
+    perfect = torch.where(gt[0], 5.0, -5.0)                              # no error anywhere -> sample from gt
+    c, l = O.sample_eval_prompts(pts, gt, perfect)
+    assert bool(l[0, 0]) and torch.equal(c[0, 0], pts[0][O.border_farthest(pts[0], gt[0, 0])[0]])
+    over = torch.full((1, 400), 5.0)                                     # predicts everything: only false positives
+    c, l = O.sample_eval_prompts(pts, gt, over)
+    assert not bool(l[0, 0])
