@@ -106,6 +106,16 @@ int32_t psam_gemm_bf16x6(const float* A, int64_t lda, int64_t sA1, int64_t sA2, 
                          int64_t ldc, int64_t sC1, int64_t sC2, const float* bias, const float* residual, int64_t ldr, int64_t sR1, int64_t sR2,
                          const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, int32_t batch1, int32_t batch2,
                          float alpha, int32_t act, psam_stream_t stream);
+/* bf16x6 GEMM against a PRE-PACKED static weight: psam_pack_weight_bf16x3 splits W[N,K] once (at model load) into the
+ * three bf16 planes stored in MFMA-fragment order; the GEMM then streams W fragments straight into registers (no LDS, no
+ * split arithmetic for the weight) and double-buffers only the activation operand in LDS.  Same result contract as
+ * psam_gemm_bf16x6. */
+size_t psam_packed_weight_bytes(int32_t N, int32_t K);
+int32_t psam_pack_weight_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* out, psam_stream_t stream);
+int32_t psam_gemm_bf16x6_pw(const float* A, int64_t lda, const void* Wpk, float* C, int64_t ldc, const float* bias, const float* residual,
+                            int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha,
+                            int32_t act, psam_stream_t stream);
+void psam_gemm_bf16x6_pw_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 void psam_gemm_bf16x6_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpointsam_hip.so")
+# PSAM_HIP_LIB: A/B tuning hook (another build of the SAME C ABI); there is still no non-HIP fallback
+LIB_PATH = os.environ.get("PSAM_HIP_LIB") or os.path.join(_HERE, "csrc", "libpointsam_hip.so")
 
 i32, i64, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 ptr, size_t = ctypes.c_void_p, ctypes.c_size_t
@@ -30,6 +31,10 @@ SIGNATURES = {
                             i32, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_bf16x6": (i32, [ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, ptr, i64, i64, i64, ptr, i64, i32,
                                i32, i32, i32, i32, i32, f32, i32, ptr]),
+    "psam_packed_weight_bytes": (size_t, [i32, i32]),
+    "psam_pack_weight_bf16x3": (i32, [ptr, i64, i32, i32, ptr, ptr]),
+    "psam_gemm_bf16x6_pw": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
+    "psam_gemm_bf16x6_pw_force_config": (None, [i32]),
     "psam_linear": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
     "psam_gemm_force_config": (None, [i32]),
     "psam_gemm_bf16x6_force_config": (None, [i32]),

@@ -20,6 +20,7 @@ SOURCES = [
     ("tokenizer.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
     ("gemm_split.hip", []),
+    ("gemm_packw.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("error.cpp", ["-x", "hip"]),

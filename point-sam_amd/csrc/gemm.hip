@@ -15,6 +15,7 @@
 // row feeds 4 MFMAs: lanes 0-31 take k = 8s..8s+3, lanes 32-63 take k = 8s+4..8s+7 (A and W use the same
 // permutation of k, so the sum over k is unchanged).
 #include "common.h"
+#include "gemm_epilogue.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -46,8 +47,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM * (GEMM_BK / 4) / 256;  // float4 loads per thread per slab
     constexpr int W_F4 = BN * (GEMM_BK / 4) / 256;
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * GEMM_BK];
-    __shared__ __attribute__((aligned(16))) float sW[2][BN * GEMM_BK];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * GEMM_BK];   // [A buf 0,1][W buf 0,1]; reused by the epilogue
+    float (*sA)[BM * GEMM_BK] = reinterpret_cast<float (*)[BM * GEMM_BK]>(smem);
+    float (*sW)[BN * GEMM_BK] = reinterpret_cast<float (*)[BN * GEMM_BK]>(smem + 2 * BM * GEMM_BK);
 
     // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous
     // range of tiles (they share A row panels / W column panels in that XCD's private L2).
@@ -164,58 +166,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     }
     if (t < nslabs) slab_body(t, 0, ra0, rw0, ra1, rw1);
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: LDS transpose -> row-contiguous float4 stores (gemm_epilogue.h).  act == 3 is the SwiGLU gate fused into fc1
+    // (timm SwiGLU: act(fc1_g x) * fc1_x x): the packed weight alternates 32-row blocks of fc1_g and fc1_x, so accumulator
+    // tile j=2q holds g and tile j=2q+1 holds x for the SAME 32 hidden units in the same lane/register; output has N/2 columns.
     float* C = p.C + z1 * p.sC1 + z2 * p.sC2;
     const float* R = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
-    if (p.act == 3) {
-        // SwiGLU gate fused into fc1 (timm SwiGLU: act(fc1_g x) * fc1_x x): the packed weight alternates 32-row blocks of
-        // fc1_g and fc1_x, so accumulator tile j=2q holds g and tile j=2q+1 holds x for the SAME 32 hidden units in
-        // the same lane/register.  Output has N/2 columns.
-        if constexpr (TN % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row0 = m0 + (wm * TM + i) * 32;
-#pragma unroll
-                for (int q = 0; q < TN / 2; ++q) {
-                    const int colg = n0 + (wn * TN + 2 * q) * 32 + r32;   // packed column of g; x is 32 further
-                    if (colg >= p.N) continue;
-                    const float bg = p.bias ? p.bias[colg] : 0.f, bx = p.bias ? p.bias[colg + 32] : 0.f;
-                    const int ocol = (n0 + (wn * TN + 2 * q) * 32) / 2 + r32;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row >= p.M) continue;
-                        C[(int64_t)row * p.ldc + ocol] = silu(acc[i][2 * q][r] + bg) * (acc[i][2 * q + 1][r] + bx);
-                    }
-                }
-            }
-        }
-        return;
-    }
-    const bool group_uniform = p.rowbias && (p.rowgroup & 31) == 0;  // a 32-row MFMA tile never straddles two groups
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row0 = m0 + (wm * TM + i) * 32;
-        const float* rb_tile = group_uniform ? p.rowbias + (int64_t)(row0 / p.rowgroup) * p.ldrb : nullptr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + r32;
-            if (col >= p.N) continue;
-            float bv = p.bias ? p.bias[col] : 0.f;
-            if (rb_tile) bv += rb_tile[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha + bv;
-                if (p.rowbias && !group_uniform) v += p.rowbias[(int64_t)(row / p.rowgroup) * p.ldrb + col];
-                if (p.act == 1) v = gelu_erf(v);
-                else if (p.act == 2) v = fmaxf(v, 0.f);
-                if (R) v += R[(int64_t)row * p.ldr + col];
-                C[(int64_t)row * p.ldc + col] = v;
-            }
-        }
-    }
+    static_assert(4 * gemm_epilogue_lds_floats_per_wave<TN>() <= 2 * (BM + BN) * GEMM_BK, "epilogue staging fits the operand LDS");
+    __syncthreads();   // every wave is done reading operand fragments
+    gemm_store_tile<TM, TN>(p, acc, smem + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32, n0 + wn * TN * 32, lane, C, R);
 }
 
 static int g_force_cfg = -1;  // test/bench hook: 0=128x128, 1=128x64, 2=64x64, -1=auto

@@ -1,0 +1,94 @@
+// Shared GEMM epilogue: accumulator tiles -> C through a wave-private LDS transpose, so that global memory sees full
+// 128..256-byte row segments (float4 per lane) instead of the MFMA layout's 4-byte column-strided scatter.
+//
+// Why: measured with per-workgroup cycle counters on the bf16x6 kernel (128x128 tile, K = 1024), the direct epilogue --
+// 64 global_store_dword per lane, each wave instruction touching 2 rows x 128 B, plus equally scattered residual loads --
+// took 37 k cycles per tile against 128 k for the whole K loop.  Here a wave stages 32 rows x (TN*32) columns at a time in
+// LDS (row stride +4 floats: conflict-free for the b32 writes and the b128 reads), reads them back as float4 with 16 (or
+// 8) lanes per row, applies bias / per-group row bias / activation / residual with vector loads, and stores float4.
+// C/D layout of v_mfma_f32_32x32x*: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma once
+#include "common.h"
+
+typedef float ep_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ep_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TN>
+constexpr int gemm_epilogue_lds_floats_per_wave() { return 32 * (TN * 32 + 4); }
+
+// ArgsT needs: M, N, act, alpha, bias, rowbias, ldrb, rowgroup, ldc, ldr.   C / R already offset for the batch.
+template <int TM, int TN, typename ArgsT>
+__device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], float* __restrict__ lw, int row_base, int col_base,
+                                                int lane, float* __restrict__ C, const float* __restrict__ R) {
+    const int r32 = lane & 31, h = lane >> 5;
+    const bool swiglu = p.act == 3;
+    // staged width: TN*32 columns, or TN*16 gated columns for the SwiGLU pairing (tile 2q = g, tile 2q+1 = x)
+    const int W = swiglu ? TN * 16 : TN * 32;
+    constexpr int LD = TN * 32 + 4;
+    const int c4n = W >> 2;                 // float4 per staged row: 16, 8 or 4
+    const int rpp = 64 / c4n;               // rows per read-back pass
+    const int out_col_base = swiglu ? col_base / 2 : col_base;
+    const int n_out = swiglu ? p.N / 2 : p.N;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (((uintptr_t)C & 15) == 0) && (!R || (((p.ldr & 3) == 0) && (((uintptr_t)R & 15) == 0))) &&
+                        (!p.rowbias || (((p.ldrb & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0))) && (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // ---- stage this 32-row stripe
+        if (swiglu) {
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int q = 0; q < TN / 2; ++q) {
+                    const int colg = col_base + 2 * q * 32 + r32;
+                    const float bg = (p.bias && colg < p.N) ? p.bias[colg] : 0.f;
+                    const float bx = (p.bias && colg + 32 < p.N) ? p.bias[colg + 32] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + q * 32 + r32] = silu(acc[i][2 * q][r] + bg) * (acc[i][2 * q + 1][r] + bx);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + j * 32 + r32] = acc[i][j][r] * p.alpha;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- read back row-major, finish, store
+        const int rl0 = lane / c4n, c4 = lane % c4n;
+        for (int rl = rl0; rl < 32; rl += rpp) {
+            const int row = row_base + i * 32 + rl;
+            const int col = out_col_base + c4 * 4;
+            if (row >= p.M || col >= n_out) continue;
+            ep_f32x4 v = *reinterpret_cast<const ep_f32x4*>(lw + rl * LD + c4 * 4);
+            if (vec_ok && col + 3 < n_out) {
+                if (!swiglu) {
+                    if (p.bias) v += *reinterpret_cast<const ep_f32x4*>(p.bias + col);
+                    if (p.rowbias) v += *reinterpret_cast<const ep_f32x4*>(p.rowbias + (int64_t)(row / p.rowgroup) * p.ldrb + col);
+                    if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                    else if (p.act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (R) v += *reinterpret_cast<const ep_f32x4*>(R + (int64_t)row * p.ldr + col);
+                }
+                *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= n_out) break;
+                    float o = v[e];
+                    if (!swiglu) {
+                        if (p.bias) o += p.bias[col + e];
+                        if (p.rowbias) o += p.rowbias[(int64_t)(row / p.rowgroup) * p.ldrb + col + e];
+                        if (p.act == 1) o = gelu_erf(o);
+                        else if (p.act == 2) o = fmaxf(o, 0.f);
+                        if (R) o += R[(int64_t)row * p.ldr + col + e];
+                    }
+                    C[(int64_t)row * p.ldc + col + e] = o;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the stripe is consumed before the next one overwrites it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}

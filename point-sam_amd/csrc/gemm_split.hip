@@ -14,6 +14,7 @@
 // 32x64), slabs of 32 k; LDS holds the three bf16 planes of both operands (48 / 36 KiB, single buffered); rows are 64 bytes with the
 // 16-byte chunk index XOR-swizzled by (row>>2)&3: conflict-free ds_read_b128 fragments and ds_write_b64 staging.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -208,55 +209,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p)
 #undef SG_STEP
 #undef SG_TERM
 
-    // ---- epilogue (C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    // ---- epilogue: LDS transpose -> row-contiguous float4 stores (gemm_epilogue.h)
     float* C = p.C + z1 * p.sC1 + z2 * p.sC2;
     const float* R = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
-    if (p.act == 3) {  // SwiGLU gate: accumulator tile j=2q holds g, j=2q+1 holds x of the same 32 hidden units (see gemm.hip)
-        if constexpr (TN % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row0 = m0 + (wm * TM + i) * 32;
-#pragma unroll
-                for (int q = 0; q < TN / 2; ++q) {
-                    const int colg = n0 + (wn * TN + 2 * q) * 32 + r32;
-                    if (colg >= p.N) continue;
-                    const float bg = p.bias ? p.bias[colg] : 0.f, bx = p.bias ? p.bias[colg + 32] : 0.f;
-                    const int ocol = (n0 + (wn * TN + 2 * q) * 32) / 2 + r32;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row >= p.M) continue;
-                        C[(int64_t)row * p.ldc + ocol] = silu(acc[i][2 * q][r] + bg) * (acc[i][2 * q + 1][r] + bx);
-                    }
-                }
-            }
-        }
-        return;
-    }
-    const bool group_uniform = p.rowbias && (p.rowgroup & 31) == 0;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row0 = m0 + (wm * TM + i) * 32;
-        const float* rb_tile = group_uniform ? p.rowbias + (int64_t)(row0 / p.rowgroup) * p.ldrb : nullptr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + r32;
-            if (col >= p.N) continue;
-            float bv = p.bias ? p.bias[col] : 0.f;
-            if (rb_tile) bv += rb_tile[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha + bv;
-                if (p.rowbias && !group_uniform) v += p.rowbias[(int64_t)(row / p.rowgroup) * p.ldrb + col];
-                if (p.act == 1) v = gelu_erf(v);
-                else if (p.act == 2) v = fmaxf(v, 0.f);
-                if (R) v += R[(int64_t)row * p.ldr + col];
-                C[(int64_t)row * p.ldc + col] = v;
-            }
-        }
-    }
+    static_assert(4 * gemm_epilogue_lds_floats_per_wave<TN>() * 4 <= 3 * PLANE_A + 3 * PLANE_W, "epilogue staging fits the operand LDS");
+    __syncthreads();   // every wave is done reading operand fragments
+    gemm_store_tile<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+                            n0 + wn * TN * 32, lane, C, R);
 }
 
 static int g_split_cfg = -1;  // tuning hook: 0 = 128x128 (2x2 waves of 64x64), 1 = 128x64 (4x1 waves of 32x64), -1 = auto

@@ -59,6 +59,20 @@ def _gemm_call(fn_args, flops, M, N, K, what):
     GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6" if split else "f32"))
 
 
+def _packed_gemm_call(fn_args, flops, M, N, K):
+    global _gemm_counter
+    L = _lib.load()
+    _gemm_counter += 1
+    if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
+        check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw")
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw")
+    e.record()
+    GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6"))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -160,8 +174,28 @@ def _row_view(t, name):
     return t.data_ptr(), t.stride(0)
 
 
+class PackedWeight:
+    """A static nn.Linear weight pre-split into bf16x3 planes in MFMA fragment order (csrc/gemm_packw.hip), plus the fp32
+    original for the launches that do not use the packed kernel (small M, "f32" mode)."""
+
+    def __init__(self, W: torch.Tensor):
+        wp, ldw = _row_view(W, "W")
+        self.fp32 = W
+        self.N, self.K = W.shape
+        L = _lib.load()
+        self.data = torch.empty(L.psam_packed_weight_bytes(self.N, self.K), dtype=torch.uint8, device=W.device)
+        check(L.psam_pack_weight_bf16x3(wp, ldw, self.N, self.K, self.data.data_ptr(), _stream()), "psam_pack_weight_bf16x3")
+
+    @property
+    def shape(self):
+        return (self.N, self.K)
+
+
 def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None):
     """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views."""
+    packed = None
+    if isinstance(W, PackedWeight):
+        packed, W = W, W.fp32
     xp, ldx = _row_view(x, "x")
     wp, ldw = _row_view(W, "W")
     M = x.shape[0]
@@ -169,11 +203,17 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
     if K is None:
         K = W.shape[1]
         assert x.shape[1] == K, (x.shape, W.shape)
+    elif packed is not None and K != packed.K:
+        packed = None
     if out is None:
         out = torch.empty(M, N // 2 if act == ACT_SWIGLU else N, dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
+    if packed is not None and GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
+        _packed_gemm_call((xp, ldx, packed.data.data_ptr(), op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup, M, N, K, 1.0, act, _stream()),
+                          2.0 * M * N * K, M, N, K)
+        return out
     _gemm_call((xp, ldx, 0, 0, wp, ldw, 0, 0, op, ldo, 0, 0, _p(bias), rp, ldr, 0, 0, rbp, ldrb, rowgroup, M, N, K, 1, 1, 1.0, act, _stream()),
                2.0 * M * N * K, M, N, K, "psam_gemm_f32")
     return out

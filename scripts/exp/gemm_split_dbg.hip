@@ -52,7 +52,7 @@ __device__ __forceinline__ void split3(const f32x2 x, unsigned& hi, unsigned& mi
 }
 
 __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p, unsigned long long* dbg) {
-    unsigned long long tstamp[6]; int nst = 0;
+    unsigned long long tstamp[6]; unsigned long long rt0 = 0, rt1 = 0; int nst = 0; const unsigned long long t_entry = __builtin_readcyclecounter(); unsigned long long t_loop0 = 0, t_loop1 = 0;
     // LDS: [A planes hi,mid,lo][W planes hi,mid,lo]
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SG_PLANE_A + 3 * SG_PLANE_W];
     unsigned char* sA = smem;
@@ -157,15 +157,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p,
     load_slab(0, ra0, rw0);
     split_regs(ra0, rw0);
     load_slab(SG_BK, ra0, rw0);
+    t_loop0 = __builtin_readcyclecounter();
     for (int t = 0; t < nslabs; ++t) {
-        if (t == 8) tstamp[0] = __builtin_readcyclecounter();
+        if (t == 8) { tstamp[0] = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
         __syncthreads();
         if (t == 8) tstamp[1] = __builtin_readcyclecounter();
         store_split();
         __syncthreads();
         if (t == 8) tstamp[2] = __builtin_readcyclecounter();
         if (t == 9) tstamp[4] = __builtin_readcyclecounter();
-        if (t == 24) tstamp[5] = __builtin_readcyclecounter();
+        if (t == 24) { tstamp[5] = __builtin_readcyclecounter(); rt1 = __builtin_amdgcn_s_memrealtime(); }
         load_frags(0, af0, wf0);
         load_frags(1, af1, wf1);
         SG_STEP(af0, wf0)
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p,
 #undef SG_STEP
 #undef SG_TERM
 
+    t_loop1 = __builtin_readcyclecounter();
     // ---- epilogue (C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     float* C = p.C + z1 * p.sC1 + z2 * p.sC2;
     const float* R = p.residual ? p.residual + z1 * p.sR1 + z2 * p.sR2 : nullptr;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p,
     if ((threadIdx.x & 63) == 0) {
         unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
         d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[4]; d[4] = tstamp[5];
-        d[5] = __builtin_amdgcn_s_getreg(63492); d[6] = __builtin_amdgcn_s_getreg((31<<11)|20); d[7] = __builtin_amdgcn_s_memrealtime();
+        d[5] = t_loop0 - t_entry; d[6] = t_loop1 - t_loop0; d[7] = __builtin_readcyclecounter() - t_loop1;
     }
 }
 

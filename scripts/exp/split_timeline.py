@@ -13,16 +13,4 @@ d=dbg.cpu()
 w0=d[:,0,:]
 barA=(w0[:,1]-w0[:,0]).double(); stage=(w0[:,2]-w0[:,1]).double(); slab=(w0[:,3]-w0[:,0]).double(); s16=((w0[:,4]-w0[:,3]).double())/15
 print("tiles",nt,"per-slab cycles (wave 0): wait@barrierA mean %.0f  store+barrierB mean %.0f  whole slab (t=8) mean %.0f  avg slab over t=9..24: %.0f (min %.0f max %.0f)"%(barA.mean(),stage.mean(),slab.mean(),s16.mean(),s16.min(),s16.max()))
-hw=w0[:,5]; xcc=w0[:,6]&0xf
-cuid=(xcc*128+((hw>>13)&7)*32+((hw>>12)&1)*16+((hw>>8)&0xf)).tolist()
-slot=(hw&0xf).tolist()
-print("wave-slot histogram of wave0:", sorted(collections.Counter(slot).items()))
-# phase offset between co-resident WGs: group by CU, compare tstamp[0] (shader clock is per-CU consistent?) for WGs whose lifetimes overlap (first round = lowest 512 block ids)
-by=collections.defaultdict(list)
-for i in range(min(nt,512)): by[cuid[i]].append(i)
-offs=[]
-for c,l in by.items():
-    if len(l)==2:
-        a,b2=l; offs.append(abs(int(w0[a,0])-int(w0[b2,0])))
-import statistics
-if offs: print("co-resident pairs: %d ; |t8(A)-t8(B)| cycles: median %.0f  mean %.0f  (slab period ~%.0f)"%(len(offs),statistics.median(offs),sum(offs)/len(offs),s16.mean()))
+print("cycles: prologue mean %.0f  loop mean %.0f  epilogue mean %.0f (max %.0f)"%(w0[:,5].double().mean(), w0[:,6].double().mean(), w0[:,7].double().mean(), w0[:,7].double().max()))

@@ -355,3 +355,49 @@ def test_border_farthest_and_error_regions(ops, N, B, rep):
         for z in range(Z):
             wi, wd = O.border_farthest(xyz[z // rep], reg[z])
             assert int(idx[z]) == wi and float(dist[z]) == wd, (name, z, int(idx[z]), wi, float(dist[z]), wd)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, -1])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 36), (640, 2752, 96), (512, 160, 2752)])
+def test_gemm_bf16x6_packed_weight(ops, cfg, M, N, K):
+    """Pre-packed-weight bf16x6 GEMM: same accuracy class as the f32-MFMA GEMM against fp64, ragged M/N, K tails, epilogues."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
+    W = torch.randn(N, K, generator=g) * torch.exp(torch.randn(1, K, generator=g)) / K ** 0.5
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    want = F.gelu(x.double() @ W.double().T + b.double()) + res.double()
+    scale = (x.double().abs() @ W.double().abs().T + 1.0)
+    Wd = cu(W)
+    pw = ops.PackedWeight(Wd)
+    L = ops._lib.load()
+    L.psam_gemm_bf16x6_pw_force_config(cfg)
+    try:
+        with ops.gemm_mode("bf16x6"):
+            y = ops.linear(cu(x), pw, cu(b), act=ops.ACT_GELU, residual=cu(res))
+        with ops.gemm_mode("f32"):
+            y32 = ops.linear(cu(x), pw, cu(b), act=ops.ACT_GELU, residual=cu(res))   # packed object falls back to its fp32 weight
+    finally:
+        L.psam_gemm_bf16x6_pw_force_config(-1)
+    e = ((y.cpu().double() - want).abs() / scale).max().item()
+    e32 = ((y32.cpu().double() - want).abs() / scale).max().item()
+    assert e < 3e-7 * math.sqrt(K) + 1e-7 and e < 4 * e32 + 1e-7, (e, e32)
+
+
+def test_gemm_bf16x6_packed_weight_swiglu_and_rowbias(ops):
+    g = torch.Generator().manual_seed(5)
+    M, D, H, Hp, grp = 384, 128, 170, 192, 64
+    x = torch.randn(M, D, generator=g)
+    Wg, Wx = torch.randn(H, D, generator=g) / D ** 0.5, torch.randn(H, D, generator=g) / D ** 0.5
+    bg, bx = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    pad = lambda t: torch.cat([t, torch.zeros((Hp - H,) + tuple(t.shape[1:]))], 0)
+    W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
+    b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
+    rb = torch.randn(M // grp, 2 * Hp, generator=g)
+    pw = ops.PackedWeight(cu(W1))
+    with ops.gemm_mode("bf16x6"):
+        u = ops.linear(cu(x), pw, cu(b1), act=ops.ACT_SWIGLU)
+        y = ops.linear(cu(x), pw, None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
+    want = F.silu(F.linear(x.double(), Wg.double(), bg.double())) * F.linear(x.double(), Wx.double(), bx.double())
+    _close(u[:, :H], want, 1e-4, what="packed swiglu epilogue")
+    assert (u[:, H:] == 0).all()
+    _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what="packed rowbias+relu")
