@@ -116,6 +116,16 @@ int32_t psam_gemm_bf16x6_pw(const float* A, int64_t lda, const void* Wpk, float*
                             int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha,
                             int32_t act, psam_stream_t stream);
 void psam_gemm_bf16x6_pw_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
+/* fp32-grade GEMM on the fp16 matrix pipe ("f16x3", 2-D form of the psam_gemm_f32 contract; same reference call sites).
+ * Each operand row is scaled by a power of two (scaleA[M], scaleW[N] from psam_row_scale_f16: row maximum into
+ * [2^14, 2^15); a static weight's scales are computed once) and split into hi + lo fp16 while its K slab is staged;
+ * hi*hi + hi*lo + lo*hi are accumulated in fp32 (dropped lo*lo and split residual <= 3*2^-22 relative per product) and
+ * the epilogue multiplies by 1/(scaleA[row] scaleW[col]) exactly. */
+int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* scale, psam_stream_t stream);
+int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,
+                        int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
+                        int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
+void psam_gemm_f16x3_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 void psam_gemm_bf16x6_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */

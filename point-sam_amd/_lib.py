@@ -38,6 +38,9 @@ SIGNATURES = {
     "psam_linear": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
     "psam_gemm_force_config": (None, [i32]),
     "psam_gemm_bf16x6_force_config": (None, [i32]),
+    "psam_row_scale_f16": (i32, [ptr, i64, i32, i32, ptr, ptr]),
+    "psam_gemm_f16x3": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
+    "psam_gemm_f16x3_force_config": (None, [i32]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
     "psam_swiglu_ln": (i32, [ptr, i64, i32, ptr, ptr, ptr, i64, i64, i32, f32, ptr]),
     "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),

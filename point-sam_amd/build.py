@@ -21,6 +21,7 @@ SOURCES = [
     ("gemm.hip", []),
     ("gemm_split.hip", []),
     ("gemm_packw.hip", []),
+    ("gemm_f16x3.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("error.cpp", ["-x", "hip"]),

@@ -16,8 +16,12 @@ typedef float ep_f32x4 __attribute__((ext_vector_type(4)));
 template <int TN>
 constexpr int gemm_epilogue_lds_floats_per_wave() { return 32 * (TN * 32 + 4); }
 
+// 1/s for a power-of-two scale s in [2^-125, 2^126] (exact): exponent field 254 - E
+__device__ __forceinline__ float inv_pow2(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
+
 // ArgsT needs: M, N, act, alpha, bias, rowbias, ldrb, rowgroup, ldc, ldr.   C / R already offset for the batch.
-template <int TM, int TN, typename ArgsT>
+// SCALED (gemm_f16x3.hip): ArgsT also has scaleA[M], scaleW[N]; the accumulator is multiplied by 1/(scaleA[row] scaleW[col]).
+template <int TM, int TN, bool SCALED = false, typename ArgsT>
 __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], float* __restrict__ lw, int row_base, int col_base,
                                                 int lane, float* __restrict__ C, const float* __restrict__ R) {
     const int r32 = lane & 31, h = lane >> 5;
@@ -31,8 +35,26 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     const int n_out = swiglu ? p.N / 2 : p.N;
     const bool vec_ok = ((p.ldc & 3) == 0) && (((uintptr_t)C & 15) == 0) && (!R || (((p.ldr & 3) == 0) && (((uintptr_t)R & 15) == 0))) &&
                         (!p.rowbias || (((p.ldrb & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0))) && (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+    float cmul[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        cmul[j] = swiglu ? 1.f : p.alpha;
+        if constexpr (SCALED) {
+            const int col = col_base + j * 32 + r32;
+            cmul[j] *= col < p.N ? inv_pow2(p.scaleW[col]) : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        if constexpr (SCALED) {   // un-scale in place (exact: powers of two)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float rm = row < p.M ? inv_pow2(p.scaleA[row]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] *= rm;
+            }
+        }
         // ---- stage this 32-row stripe
         if (swiglu) {
             if constexpr (TN % 2 == 0) {
@@ -43,14 +65,15 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     const float bx = (p.bias && colg + 32 < p.N) ? p.bias[colg + 32] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + q * 32 + r32] = silu(acc[i][2 * q][r] + bg) * (acc[i][2 * q + 1][r] + bx);
+                        lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + q * 32 + r32] =
+                            silu(acc[i][2 * q][r] * cmul[2 * q] + bg) * (acc[i][2 * q + 1][r] * cmul[2 * q + 1] + bx);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + j * 32 + r32] = acc[i][j][r] * p.alpha;
+                for (int r = 0; r < 16; ++r) lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + j * 32 + r32] = acc[i][j][r] * cmul[j];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,296 @@
+// fp32-GRADE GEMM on the fp16 matrix pipe ("f16x3"): same contract and epilogues as gemm.hip (2-D form),
+//
+//   C = act(alpha * A @ W^T + bias + rowbias[row / rowgroup]) + residual,      A, W, C fp32 in HBM.
+//
+// Every operand row is first scaled by a power of two s (exact) that puts its largest magnitude in [2^14, 2^15) --
+// psam_row_scale_f16 computes s per row; for a static weight once at load time -- then every element is split into two
+// fp16 numbers, s*x = hi + lo + e with hi = RNE_f16(s*x), lo = RNE_f16(s*x - hi) (the subtraction is exact, one FMA):
+// 11 + 11 significand bits plus the sign of lo, |e| <= 2^-22 |s*x| for elements within 2^-18 of the row maximum and
+// <= 2^-25 absolute (2^-39 of the row maximum) below that, where lo goes subnormal.  A product a*w is computed as
+// hi*hi + hi*lo + lo*hi (each fp16 x fp16 product is exact in fp32; v_mfma_f32_32x32x16_f16 accumulates in fp32); the
+// dropped lo*lo term is <= 2^-22 |a*w|.  The accumulator is multiplied by 1/(sA[row] sW[col]) (exact) in the epilogue.
+// Net: per-product relative error <= ~3*2^-22 with random sign, against 2^-24 for an exact fp32 product -- in a K-term dot
+// product both are buried under the fp32 accumulation round-off, and the measured error against an fp64 reference equals
+// that of the f32-MFMA kernel (tests/test_gpu_kernels.py, scripts/gemm_split_bench.py) at 3/16 of its matrix-pipe time
+// and half that of the bf16x6 scheme (gemm_split.hip, which needs no row scales and is exact to 2^-24 for any range).
+//
+// Kernel structure = gemm_split.hip with two planes instead of three: tile 128x128 (2x2 waves of 64x64) or 128x64 (4 waves
+// of 32x64), slabs of 32 k, split in registers while a slab moves global -> LDS, LDS rows of 64 bytes with the 16-byte
+// chunk XOR-swizzled by (row>>2)&3, epilogue through the LDS transpose of gemm_epilogue.h.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct F16x3Args {
+    const float* A; const float* W; float* C;
+    const float* bias; const float* residual; const float* rowbias;
+    const float* scaleA; const float* scaleW;       // per-row powers of two (psam_row_scale_f16)
+    int64_t lda, ldw, ldc, ldr, ldrb;
+    int M, N, K, rowgroup, act;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+constexpr int HG_BK = 32;
+constexpr int HG_ROWB = HG_BK * 2;                       // bytes per row of one fp16 plane
+
+// x (2 floats, already scaled) -> packed fp16 pairs hi, lo
+__device__ __forceinline__ void split2(const f32x2 x, const float s, unsigned& hi, unsigned& lo) {
+    const f32x2 xs = x * s;
+    const f16x2 h = __builtin_convertvector(xs, f16x2);
+    const f32x2 r = xs - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// ---------------------------------------------------------------------------------------------- row scales
+// scale[r] = 2^(14 - e), e = floor(log2(max_k |X[r,k]|)) clamped to [-100, 100]; 1 for an all-zero / non-finite row.
+__global__ __launch_bounds__(256) void row_scale_f16_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols, float* __restrict__ scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = X + (int64_t)row * ldx;
+    float m = 0.f;
+    if (((ldx & 3) == 0) && (((uintptr_t)X & 15) == 0)) {
+        const int c4 = cols >> 2;
+        for (int c = lane; c < c4; c += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + c * 4);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        for (int c = (c4 << 2) + lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[c]));
+    } else {
+        for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[c]));
+    }
+    m = wave_max(m);
+    if (lane == 0) {
+        const unsigned bits = __builtin_bit_cast(unsigned, m);
+        int e = (int)((bits >> 23) & 0xff) - 127;
+        float s = 1.f;
+        if (bits != 0 && e != 128) {           // finite, non-zero (subnormal maxima clamp to e = -100)
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            s = __builtin_bit_cast(float, (unsigned)(127 + 14 - e) << 23);
+        }
+        scale[row] = s;
+    }
+}
+
+PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* scale, hipStream_t stream) {
+    PSAM_REQUIRE(X && scale, PSAM_EINVAL, "psam_row_scale_f16: null pointer");
+    PSAM_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, PSAM_EINVAL, "psam_row_scale_f16: bad shape");
+    hipLaunchKernelGGL(row_scale_f16_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, scale);
+    return psam_launch_status("psam_row_scale_f16: launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM
+// WM x WN waves (4 in total), each TM x TN accumulator tiles of 32x32.  FDB: double-buffer the fragment registers
+// across the two k16 steps of a slab.
+template <int WM, int WN, int TM, int TN, bool FDB>
+__global__ __launch_bounds__(256) void gemm_f16x3_kernel(const F16x3Args p) {
+    static_assert(WM * WN == 4, "256-thread workgroup");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_F4 = BM * 8 / 256, W_F4 = BN * 8 / 256;   // float4 per thread per slab
+    constexpr int PLANE_A = BM * HG_ROWB, PLANE_W = BN * HG_ROWB;
+    constexpr int OPER_BYTES = 2 * PLANE_A + 2 * PLANE_W, EPI_BYTES = 4 * gemm_epilogue_lds_floats_per_wave<TN>() * 4;
+    // LDS: [A planes hi,lo][W planes hi,lo]; the epilogue staging reuses it
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES];
+    unsigned char* sA = smem;
+    unsigned char* sW = smem + 2 * PLANE_A;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const float* A = p.A;
+    const float* W = p.W;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // global -> register staging: thread (lr, lc4) owns 4 consecutive k of rows lr + 32 i of both operands
+    const int lr = tid >> 3, lc4 = tid & 7;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((((int64_t)p.M - 1) * p.lda + p.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((((int64_t)p.N - 1) * p.ldw + p.K) * 4), 0x00020000);
+    const int voA = (int)(((int64_t)(m0 + lr) * p.lda + lc4 * 4) * 4), voW = (int)(((int64_t)(n0 + lr) * p.ldw + lc4 * 4) * 4);
+    const int stepA = (int)(32 * p.lda * 4), stepW = (int)(32 * p.ldw * 4);
+    constexpr int OOB = 0x7ffffff0;
+    float sca[A_F4], scw[W_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) sca[i] = m0 + i * 32 + lr < p.M ? p.scaleA[m0 + i * 32 + lr] : 1.f;
+#pragma unroll
+    for (int i = 0; i < W_F4; ++i) scw[i] = n0 + i * 32 + lr < p.N ? p.scaleW[n0 + i * 32 + lr] : 1.f;
+    f32x4 ra0[A_F4], rw0[W_F4];
+    auto load_slab = [&](int k0) {
+        const bool kok = k0 + lc4 * 4 < p.K;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i)
+            ra0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (kok && m0 + i * 32 + lr < p.M) ? voA + i * stepA : OOB, k0 * 4, 0));
+#pragma unroll
+        for (int i = 0; i < W_F4; ++i)
+            rw0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (kok && n0 + i * 32 + lr < p.N) ? voW + i * stepW : OOB, k0 * 4, 0));
+    };
+    // LDS byte offset of this thread's 8-byte slot inside a plane: row lr (+32 i), 16-byte chunk lc4>>1 swizzled, half lc4&1
+    const int st_off = lr * HG_ROWB + ((((lc4 >> 1) ^ ((lr >> 2) & 3)) << 4) | ((lc4 & 1) << 3));
+    // split registers: [row stripe][plane hi/lo] -> 2 packed words (4 fp16)
+    u32x2 spa[A_F4][2], spw[W_F4][2];
+    auto split_regs = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            unsigned h0, l0, h1, l1;
+            split2(f32x2{ra0[i][0], ra0[i][1]}, sca[i], h0, l0);
+            split2(f32x2{ra0[i][2], ra0[i][3]}, sca[i], h1, l1);
+            spa[i][0] = u32x2{h0, h1}; spa[i][1] = u32x2{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < W_F4; ++i) {
+            unsigned h0, l0, h1, l1;
+            split2(f32x2{rw0[i][0], rw0[i][1]}, scw[i], h0, l0);
+            split2(f32x2{rw0[i][2], rw0[i][3]}, scw[i], h1, l1);
+            spw[i][0] = u32x2{h0, h1}; spw[i][1] = u32x2{l0, l1};
+        }
+    };
+    auto store_split = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) *reinterpret_cast<u32x2*>(sA + q * PLANE_A + i * 32 * HG_ROWB + st_off) = spa[i][q];
+#pragma unroll
+            for (int i = 0; i < W_F4; ++i) *reinterpret_cast<u32x2*>(sW + q * PLANE_W + i * 32 * HG_ROWB + st_off) = spw[i][q];
+        }
+    };
+    // fragment addresses: row r32 of 32-row tile, chunk (2s + h) swizzled
+    int frag_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) frag_off[s] = r32 * HG_ROWB + (((2 * s + h) ^ ((r32 >> 2) & 3)) << 4);
+    const unsigned char* a_base = sA + wm * TM * 32 * HG_ROWB;
+    const unsigned char* w_base = sW + wn * TN * 32 * HG_ROWB;
+    auto load_frags = [&](int s, f16x8 (&af)[TM][2], f16x8 (&wf)[TN][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const f16x8*>(a_base + q * PLANE_A + i * 32 * HG_ROWB + frag_off[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j][q] = *reinterpret_cast<const f16x8*>(w_base + q * PLANE_W + j * 32 * HG_ROWB + frag_off[s]);
+        }
+    };
+    // the two small partial products first (hi*lo, lo*hi), then hi*hi; term-major so that the accumulator tiles rotate
+#define HG_TERM(AF, WF, PA, PW)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][PA], WF[j][PW], acc[i][j], 0, 0, 0);
+#define HG_STEP(AF, WF) HG_TERM(AF, WF, 0, 1) HG_TERM(AF, WF, 1, 0) HG_TERM(AF, WF, 0, 0)
+
+    const int nslabs = (p.K + HG_BK - 1) / HG_BK;
+    // Pipeline (as gemm_split.hip).  At the top of slab t: sp = split slab t (registers); (ra0, rw0) = fp32 slab t+1 (landed
+    // or landing).  Slab t: [barrier: LDS free] sp -> LDS [barrier: LDS ready]; fragments of k16-step 0; then 2 x 3*TM*TN
+    // MFMAs, in whose shadow issue: the fragment reads of step 1, the split of slab t+1 into sp and the refill of the fp32
+    // registers with slab t+2.  Loads past K return zeros (bounds-checked descriptor) and are unconditional: counted vmcnt.
+    f16x8 af0[TM][2], wf0[TN][2], af1[TM][2], wf1[TN][2];
+    load_slab(0);
+    split_regs();
+    load_slab(HG_BK);
+    constexpr int NM = 3 * TM * TN, NFR = 2 * (TM + TN);
+    constexpr int NVALU = (A_F4 + W_F4) * 12 / (2 * NM) + 2;     // split VALU per MFMA slot (6 per float2, 2 float2 per float4)
+    for (int t = 0; t < nslabs; ++t) {
+        __syncthreads();
+        store_split();
+        __syncthreads();
+        load_frags(0, af0, wf0);
+        if (FDB) {
+            load_frags(1, af1, wf1);
+            HG_STEP(af0, wf0)
+            split_regs();                 // slab t+1
+            HG_STEP(af1, wf1)
+        } else {
+            HG_STEP(af0, wf0)
+            load_frags(1, af0, wf0);
+            split_regs();                 // slab t+1
+            HG_STEP(af0, wf0)
+        }
+        load_slab((t + 2) * HG_BK);
+        // requested issue order (one scheduling region: the loop body after the second barrier)
+        __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);      // fragments of step 0
+        if (FDB) {
+            static_assert(2 * NM >= NFR, "fragment reads hide behind the MFMAs");
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {                        // first MFMAs, fragment reads of step 1 behind them
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, NVALU, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * NM - NFR; ++i) {              // remaining MFMAs with the split arithmetic behind them
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, NVALU, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, NVALU, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, NVALU, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, A_F4 + W_F4, 0);
+    }
+#undef HG_STEP
+#undef HG_TERM
+
+    // ---- epilogue: un-scale, then LDS transpose -> row-contiguous float4 stores (gemm_epilogue.h)
+    __syncthreads();   // every wave is done reading operand fragments
+    gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+                                  n0 + wn * TN * 32, lane, p.C, p.residual);
+}
+
+static int g_f16x3_cfg = -1;  // tuning hook: 0 = 128x128 (2x2 waves of 64x64), 1 = 128x64 (4x1 waves of 32x64), 2 = 128x128 without fragment double
+// buffering (fewer registers), -1 = auto
+PSAM_API void psam_gemm_f16x3_force_config(int32_t cfg) { g_f16x3_cfg = cfg; }
+
+// C = act(alpha * A @ W^T + bias + rowbias[row/rowgroup]) + residual; scaleA[M], scaleW[N] from psam_row_scale_f16.
+PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,
+                                 int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
+                                 int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, hipStream_t stream) {
+    PSAM_REQUIRE(A && W && C && scaleA && scaleW, PSAM_EINVAL, "psam_gemm_f16x3: null pointer");
+    PSAM_REQUIRE(M > 0 && N > 0 && K > 0, PSAM_EINVAL, "psam_gemm_f16x3: bad shape");
+    PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_f16x3: bad activation code");
+    PSAM_REQUIRE(!rowbias || rowgroup > 0, PSAM_EINVAL, "psam_gemm_f16x3: rowbias needs rowgroup > 0");
+    PSAM_REQUIRE((K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, PSAM_EALIGN,
+                 "psam_gemm_f16x3: K, lda, ldw must be multiples of 4 and A, W 16-byte aligned");
+    PSAM_REQUIRE(((int64_t)M - 1) * lda + K < ((int64_t)1 << 29) - 8 && ((int64_t)N - 1) * ldw + K < ((int64_t)1 << 29) - 8, PSAM_EINVAL,
+                 "psam_gemm_f16x3: one operand matrix must span < 2 GiB (32-bit buffer offsets)");
+    PSAM_REQUIRE(act != 3 || ((N & 63) == 0 && !residual && !rowbias), PSAM_EINVAL,
+                 "psam_gemm_f16x3: SwiGLU epilogue needs N % 64 == 0, no residual/rowbias");
+    F16x3Args p;
+    p.A = A; p.W = W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias; p.scaleA = scaleA; p.scaleW = scaleW;
+    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
+    p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
+    int cfg = g_f16x3_cfg;
+    if (cfg < 0) cfg = (psam_cdiv(M, 128) * psam_cdiv(N, 128) >= 512 && K > 256) ? 0 : 1;
+    const int bn = cfg == 1 ? 64 : 128;
+    p.tiles_m = (int)psam_cdiv(M, 128);
+    p.tiles_n = (int)psam_cdiv(N, bn);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
+    else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
+    return psam_launch_status("psam_gemm_f16x3: launch failed");
+}

@@ -23,7 +23,9 @@ _gemm_counter = 0
 # matrix pipe with the exact 3-way operand split (fp32-accurate, see csrc/gemm_split.hip), small ones stay on "f32".
 GEMM_MODE = "f32"
 SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 64
-GEMM_MODES = ("f32", "bf16x6")
+GEMM_MODES = ("f32", "bf16x6", "f16x3")
+# "f16x3" = large 2-D GEMMs on the fp16 matrix pipe: power-of-two row scales + 2-way fp16 split, 3 partial products
+# (fp32-grade: same measured error vs fp64 as the f32 kernel, csrc/gemm_f16x3.hip); batched and small ones stay on "f32".
 
 
 class gemm_mode:
@@ -191,8 +193,44 @@ class PackedWeight:
         return (self.N, self.K)
 
 
-def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None):
-    """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views."""
+def row_scale_f16(x, K=None, out=None):
+    """Per-row power-of-two scales for the f16x3 GEMM (row maximum of x[:, :K] into [2^14, 2^15))."""
+    xp, ldx = _row_view(x, "x")
+    rows = x.shape[0]
+    if out is None:
+        out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().psam_row_scale_f16(xp, ldx, rows, x.shape[1] if K is None else K, out.data_ptr(), _stream()), "psam_row_scale_f16")
+    return out
+
+
+_WEIGHT_SCALES = {}   # static weights: (ptr, shape, ld, K, version) -> (scale tensor, weight kept alive)
+
+
+def weight_scale_f16(W, K):
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), K, W._version)
+    hit = _WEIGHT_SCALES.get(key)
+    if hit is None:
+        hit = _WEIGHT_SCALES[key] = (row_scale_f16(W, K), W)
+    return hit[0]
+
+
+def _f16x3_call(fn_args, flops, M, N, K):
+    global _gemm_counter
+    L = _lib.load()
+    _gemm_counter += 1
+    if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
+        check(L.psam_gemm_f16x3(*fn_args), "psam_gemm_f16x3")
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(L.psam_gemm_f16x3(*fn_args), "psam_gemm_f16x3")
+    e.record()
+    GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3"))
+
+
+def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None):
+    """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views.
+    x_scale: optional precomputed row_scale_f16(x, K) ("f16x3" mode; computed here otherwise)."""
     packed = None
     if isinstance(W, PackedWeight):
         packed, W = W, W.fp32
@@ -210,6 +248,12 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
+    if GEMM_MODE == "f16x3" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
+        sa = row_scale_f16(x, K) if x_scale is None else x_scale
+        sw = weight_scale_f16(W, K)
+        _f16x3_call((xp, ldx, sa.data_ptr(), wp, ldw, sw.data_ptr(), op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup, M, N, K, 1.0, act, _stream()),
+                    2.0 * M * N * K, M, N, K)
+        return out
     if packed is not None and GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
         _packed_gemm_call((xp, ldx, packed.data.data_ptr(), op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup, M, N, K, 1.0, act, _stream()),
                           2.0 * M * N * K, M, N, K)

@@ -41,7 +41,7 @@ constexpr int SG_PLANE_W = SG_BN * SG_ROWB;
 
 // x (2 floats) -> packed bf16 pairs hi, mid, lo with x == hi + mid + lo exactly
 template <int ABL> __device__ __forceinline__ void split3(const f32x2 x, unsigned& hi, unsigned& mid, unsigned& lo) {
-    if (ABL == 1) { hi = (__builtin_bit_cast(unsigned, x[0]) >> 16) | (__builtin_bit_cast(unsigned, x[1]) & 0xffff0000u); mid = 0; lo = 0; return; }
+    if (ABL == 1 || ABL >= 6) { hi = (__builtin_bit_cast(unsigned, x[0]) >> 16) | (__builtin_bit_cast(unsigned, x[1]) & 0xffff0000u); mid = 0; lo = 0; return; }
     const bf16x2 h = __builtin_convertvector(x, bf16x2);
     const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
     const bf16x2 m = __builtin_convertvector(r1, bf16x2);
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p)
     split_regs(ra0, rw0);
     load_slab(SG_BK, ra0, rw0);
     for (int t = 0; t < nslabs; ++t) {
-        if (ABL != 4) { __syncthreads(); store_split(); __syncthreads(); }
+        if (ABL != 4 && ABL < 5) { __syncthreads(); store_split(); __syncthreads(); }
+        if (ABL == 5 || ABL == 6) asm volatile("" ::: "memory");
         compute_slab();
         split_regs(ra0, rw0);                 // slab t+1
-        if (ABL != 3) load_slab((t + 2) * SG_BK, ra0, rw0);
+        if (ABL != 3 && ABL < 5) load_slab((t + 2) * SG_BK, ra0, rw0);
         // Ask the scheduler for: fragment reads + MFMAs of the first k16 step, then the second step's MFMAs with the
         // split arithmetic of the next slab in their shadow (as late as possible: its operands were loaded one slab
         // ago), then the global loads of slab t+2.
@@ -236,6 +237,9 @@ extern "C" __attribute__((visibility("default"))) int gemm_split_ablate(const fl
       case 2: hipLaunchKernelGGL((gemm_bf16x6_kernel<2>), grid, dim3(256), 0, stream, p); break;
       case 3: hipLaunchKernelGGL((gemm_bf16x6_kernel<3>), grid, dim3(256), 0, stream, p); break;
       case 4: hipLaunchKernelGGL((gemm_bf16x6_kernel<4>), grid, dim3(256), 0, stream, p); break;
+      case 5: hipLaunchKernelGGL((gemm_bf16x6_kernel<5>), grid, dim3(256), 0, stream, p); break;
+      case 6: hipLaunchKernelGGL((gemm_bf16x6_kernel<6>), grid, dim3(256), 0, stream, p); break;
+      case 7: hipLaunchKernelGGL((gemm_bf16x6_kernel<7>), grid, dim3(256), 0, stream, p); break;
     }
     return (int)hipGetLastError();
 }

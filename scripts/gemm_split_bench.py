@@ -12,9 +12,9 @@ for name, M, N, K in SHAPES:
     rows = torch.randint(0, M, (256,), generator=g).cuda()
     ref = (x[rows].double() @ W.double().T + b.double())
     line = f"{name:11s} {M:7d}x{N:5d}x{K:5d} |"
-    for mode in ("f32", "bf16x6:0", "bf16x6:1"):
+    for mode in ("f32", "bf16x6:0", "bf16x6:1", "f16x3:0", "f16x3:1", "f16x3:2"):
         if ":" in mode:
-            ops._lib.load().psam_gemm_bf16x6_force_config(int(mode[-1]))
+            getattr(ops._lib.load(), f"psam_gemm_{mode.split(':')[0]}_force_config")(int(mode[-1]))
         ops.GEMM_MODE = mode.split(":")[0]
         y = ops.linear(x, W, b)
         err = ((y[rows].double() - ref).abs().max() / ref.abs().max()).item()
@@ -24,6 +24,6 @@ for name, M, N, K in SHAPES:
         for _ in range(10): ops.linear(x, W, b, out=y)
         e.record(); torch.cuda.synchronize()
         ms = s.elapsed_time(e) / 10
-        line += f" {mode}: {ms*1e3:8.1f} us {2*M*N*K/ms/1e9:6.1f} TF relerr {err:.2e} |"
+        line += f" {mode}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:5.1f}TF err {err:.1e} |"
     ops.GEMM_MODE = "f32"
     print(line, flush=True)

@@ -65,7 +65,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_against_oracle(gpu, name, precision):
     mk, B, N, M = CASES[name]
@@ -229,7 +229,7 @@ def test_forward_eval_protocol(gpu, golden_forward):
     meta, a = golden_forward
     cfg = get_config(meta["cfg"])
     sd = random_state_dict(cfg, seed=meta["seed"])
-    for precision in ("f32", "bf16x6"):
+    for precision in ("f32", "bf16x6", "f16x3"):
         model = gpu(cfg, sd, precision=precision)
         model.prompt_iters = meta["iters"]
         outs = model(a["xyz"].cuda(), a["rgb"].cuda(), a["gt_masks"].cuda(), is_eval=True)

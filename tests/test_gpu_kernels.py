@@ -180,6 +180,80 @@ def test_gemm_bf16x6_matches_fp64_like_f32(ops, M, N, K):
     assert errs["bf16x6"] < 4 * errs["f32"] + 1e-7, errs
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 36), (520, 640, 2752)])
+def test_gemm_f16x3_matches_fp64_like_f32(ops, cfg, M, N, K):
+    """The scaled 2-way fp16 split GEMM must be in the accuracy class of the f32-MFMA GEMM (both against fp64): operands with
+    a wide dynamic range across rows AND along k, ragged M/N, K tail, bias + GELU + residual epilogue."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
+    W = torch.randn(N, K, generator=g) * torch.exp(torch.randn(1, K, generator=g)) / K ** 0.5
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    want = F.gelu(x.double() @ W.double().T + b.double()) + res.double()
+    scale = (x.double().abs() @ W.double().abs().T + 1.0)
+    L = ops._lib.load()
+    errs = {}
+    L.psam_gemm_f16x3_force_config(cfg)
+    try:
+        for mode in ("f32", "f16x3"):
+            with ops.gemm_mode(mode):
+                y = ops.linear(cu(x), cu(W), cu(b), act=ops.ACT_GELU, residual=cu(res))
+            errs[mode] = ((y.cpu().double() - want).abs() / scale).max().item()
+    finally:
+        L.psam_gemm_f16x3_force_config(-1)
+    assert errs["f16x3"] < 3e-7 * math.sqrt(K) + 1e-7, errs
+    assert errs["f16x3"] < 4 * errs["f32"] + 1e-7, errs
+
+
+def test_gemm_f16x3_extreme_row_scales(ops):
+    """Row scales make the fp16 split range-free: rows from 1e-28 to 1e+28, an all-zero row, and a row whose elements span
+    18 binary orders of magnitude (small elements go subnormal in the lo plane: absolute error 2^-39 of the row maximum)."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 512, 256, 256
+    x = torch.randn(M, K, generator=g)
+    x *= (10.0 ** torch.linspace(-28, 28, M)).unsqueeze(1)
+    x[7] = 0
+    x[9] = torch.randn(K, generator=g) * (2.0 ** -torch.arange(K).remainder(19).float())
+    W = torch.randn(N, K, generator=g) * (10.0 ** torch.linspace(-6, 6, N)).unsqueeze(1)
+    with ops.gemm_mode("f16x3"):
+        y = ops.linear(cu(x), cu(W)).cpu().double()
+    want = x.double() @ W.double().T
+    scale = x.double().abs() @ W.double().abs().T
+    assert torch.isfinite(y).all()
+    assert (y[7] == 0).all()
+    rel = ((y - want).abs() / scale.clamp_min(1e-300))
+    rel[7] = 0
+    assert rel.max().item() < 2e-6, rel.max().item()
+    s = ops.row_scale_f16(cu(x)).cpu()
+    assert s[7] == 1 and (torch.log2(s) == torch.log2(s).round()).all()
+    m = x.abs().amax(1) * s
+    ok = (m >= 2.0 ** 14) & (m < 2.0 ** 15)
+    ok[7] = True
+    assert ok.all()
+
+
+def test_gemm_f16x3_epilogues(ops):
+    g = torch.Generator().manual_seed(3)
+    M, D, H, Hp, grp = 384, 128, 170, 192, 64
+    x = torch.randn(M, D, generator=g)
+    Wg, Wx = torch.randn(H, D, generator=g) / D ** 0.5, torch.randn(H, D, generator=g) / D ** 0.5
+    bg, bx = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    pad = lambda t: torch.cat([t, torch.zeros((Hp - H,) + tuple(t.shape[1:]))], 0)
+    W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
+    b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
+    rb = torch.randn(M // grp, 2 * Hp, generator=g)
+    with ops.gemm_mode("f16x3"):
+        u = ops.linear(cu(x), cu(W1), cu(b1), act=ops.ACT_SWIGLU)
+        y = ops.linear(cu(x), cu(W1), None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
+        xs = ops.row_scale_f16(cu(x))
+        y2 = ops.linear(cu(x), cu(W1), None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp, x_scale=xs)
+    want = F.silu(F.linear(x.double(), Wg.double(), bg.double())) * F.linear(x.double(), Wx.double(), bx.double())
+    _close(u[:, :H], want, 1e-4, what="f16x3 swiglu epilogue")
+    assert (u[:, H:] == 0).all()
+    _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what="f16x3 rowbias+relu")
+    assert torch.equal(y, y2)
+
+
 def test_gemm_bf16x6_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
