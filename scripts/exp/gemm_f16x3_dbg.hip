@@ -91,7 +91,8 @@ PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, i
 // WM x WN waves (4 in total), each TM x TN accumulator tiles of 32x32.  FDB: double-buffer the fragment registers
 // across the two k16 steps of a slab.
 template <int WM, int WN, int TM, int TN, bool FDB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void gemm_f16x3_kernel(const F16x3Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void gemm_f16x3_kernel(const F16x3Args p, unsigned long long* dbg) {
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter(); unsigned long long c1 = 0, c2 = 0;
     static_assert(WM * WN == 4, "256-thread workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM * 8 / 256, W_F4 = BN * 8 / 256;   // float4 per thread per slab
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
     load_slab(HG_BK);
     constexpr int NM = 3 * TM * TN, NFR = 2 * (TM + TN);
     constexpr int NVALU = (A_F4 + W_F4) * 12 / (2 * NM) + 2;     // split VALU per MFMA slot (6 per float2, 2 float2 per float4)
+    c1 = __builtin_readcyclecounter();
     for (int t = 0; t < nslabs; ++t) {
         __syncthreads();
         store_split();
@@ -255,12 +257,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
 #undef HG_STEP
 #undef HG_TERM
 
+    c2 = __builtin_readcyclecounter();
     // ---- epilogue: un-scale, then LDS transpose -> row-contiguous float4 stores (gemm_epilogue.h)
     __syncthreads();   // every wave is done reading operand fragments
     gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
                                   n0 + wn * TN * 32, lane, p.C, p.residual);
+    if (threadIdx.x == 0) { unsigned long long* d = dbg + (size_t)blockIdx.x * 8; const unsigned long long c3 = __builtin_readcyclecounter();
+        d[0] = rt0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = c1 - c0; d[3] = c2 - c1; d[4] = c3 - c2;
+        d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20); d[7] = tile; }
 }
 
+static unsigned long long* g_dbg = nullptr;
+PSAM_API void dbg_set_buffer(unsigned long long* b) { g_dbg = b; }
 static int g_f16x3_cfg = -1;  // tuning hook: 0 = 128x128 (2x2 waves of 64x64), 1 = 128x64 (4x1 waves of 32x64), 2 = 128x128 without fragment double
 // buffering (fewer registers), -1 = auto
 PSAM_API void psam_gemm_f16x3_force_config(int32_t cfg) { g_f16x3_cfg = cfg; }
@@ -289,8 +297,10 @@ PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scale
     p.tiles_m = (int)psam_cdiv(M, 128);
     p.tiles_n = (int)psam_cdiv(N, bn);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
-    else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
+    if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p, g_dbg);
+    else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p, g_dbg);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p, g_dbg);
     return psam_launch_status("psam_gemm_f16x3: launch failed");
 }
+
+void psam_set_error(const char*) {}
