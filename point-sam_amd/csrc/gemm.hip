@@ -42,7 +42,7 @@ constexpr int GEMM_BK = 32;   // K slab: one 128-byte row segment per operand ro
 __device__ __forceinline__ int lds_chunk_off(int row, int chunk) { return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 template <int WM, int WN, int TM, int TN>  // WM x WN waves (WM*WN == 4), each TM x TN MFMA tiles of 32x32
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void gemm_nt_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     static_assert(WM * WN == 4, "256-thread workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM * (GEMM_BK / 4) / 256;  // float4 loads per thread per slab

@@ -91,7 +91,7 @@ PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, i
 // WM x WN waves (4 in total), each TM x TN accumulator tiles of 32x32.  FDB: double-buffer the fragment registers
 // across the two k16 steps of a slab.
 template <int WM, int WN, int TM, int TN, bool FDB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void gemm_f16x3_kernel(const F16x3Args p) {
+__global__ __launch_bounds__(256) void gemm_f16x3_kernel(const F16x3Args p) {
     static_assert(WM * WN == 4, "256-thread workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM * 8 / 256, W_F4 = BN * 8 / 256;   // float4 per thread per slab
@@ -261,8 +261,151 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
                                   n0 + wn * TN * 32, lane, p.C, p.residual);
 }
 
+// ---------------------------------------------------------------------------------------------- pipelined 128x128 kernel
+// Same arithmetic, software-pipelined across k slabs (measured on the kernel above: a lone workgroup spends 2100 cycles per
+// slab for 768 cycles of MFMA -- barrier, LDS write, barrier and fragment latency are all exposed between the MFMA bursts).
+// LDS is double buffered (2 x 32 KiB), ONE barrier per slab, and every data movement of slab t+1 / t+3 is issued in the
+// shadow of the 24 MFMAs of slab t:
+//   top of slab t:  LDS[t&1] = split slab t;  F0 = fragments (t, k16 step 0);  R[(t+1)&1] = fp32 slab t+1;  R[t&1] <- slab t+2 in flight
+//   region A:  F1 <- LDS[t&1] (step 1)      | 12 MFMAs of step 0 (F0) + 4 of step 1 (F1)
+//              split R[(t+1)&1] -> LDS[(t+1)&1];  R[(t+1)&1] <- global slab t+3 (two slab periods to land)
+//   barrier    (LDS[(t+1)&1] complete; every wave has its F1, so LDS[t&1] may be overwritten next slab)
+//   region B:  F0 <- LDS[(t+1)&1] (step 0 of slab t+1)     | remaining 8 MFMAs of step 1
+template <int DUMMY>
+__global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p) {
+    constexpr int TM = 2, TN = 2, WN = 2;
+    constexpr int BM = 128, BN = 128;
+    constexpr int NF4 = 4;                                     // float4 per thread per slab per operand
+    constexpr int PLANE = 128 * HG_ROWB;                       // 8 KiB
+    constexpr int STAGE = 4 * PLANE;                           // A hi, A lo, W hi, W lo
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = tid >> 3, lc4 = tid & 7;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((((int64_t)p.M - 1) * p.lda + p.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((((int64_t)p.N - 1) * p.ldw + p.K) * 4), 0x00020000);
+    const int voA = (int)(((int64_t)(m0 + lr) * p.lda + lc4 * 4) * 4), voW = (int)(((int64_t)(n0 + lr) * p.ldw + lc4 * 4) * 4);
+    const int stepA = (int)(32 * p.lda * 4), stepW = (int)(32 * p.ldw * 4);
+    constexpr int OOB = 0x7ffffff0;
+    float sca[NF4], scw[NF4];
+    int offA[NF4], offW[NF4];                                  // row-bound check folded into the offset once
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+        const bool oka = m0 + i * 32 + lr < p.M, okw = n0 + i * 32 + lr < p.N;
+        sca[i] = oka ? p.scaleA[m0 + i * 32 + lr] : 1.f;
+        scw[i] = okw ? p.scaleW[n0 + i * 32 + lr] : 1.f;
+        offA[i] = oka ? voA + i * stepA : OOB;
+        offW[i] = okw ? voW + i * stepW : OOB;
+    }
+    f32x4 ra[2][NF4], rw[2][NF4];
+    auto load_slab = [&](int k0, f32x4 (&a)[NF4], f32x4 (&w)[NF4]) {
+        const bool kok = k0 + lc4 * 4 < p.K;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kok ? offA[i] : OOB, k0 * 4, 0));
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) w[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? offW[i] : OOB, k0 * 4, 0));
+    };
+    const int st_off = lr * HG_ROWB + ((((lc4 >> 1) ^ ((lr >> 2) & 3)) << 4) | ((lc4 & 1) << 3));
+    auto split_store = [&](int buf, const f32x4 (&a)[NF4], const f32x4 (&w)[NF4]) {
+        unsigned char* st = smem + buf * STAGE + st_off;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            unsigned h0, l0, h1, l1;
+            split2(f32x2{a[i][0], a[i][1]}, sca[i], h0, l0);
+            split2(f32x2{a[i][2], a[i][3]}, sca[i], h1, l1);
+            *reinterpret_cast<u32x2*>(st + i * 32 * HG_ROWB) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(st + PLANE + i * 32 * HG_ROWB) = u32x2{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            unsigned h0, l0, h1, l1;
+            split2(f32x2{w[i][0], w[i][1]}, scw[i], h0, l0);
+            split2(f32x2{w[i][2], w[i][3]}, scw[i], h1, l1);
+            *reinterpret_cast<u32x2*>(st + 2 * PLANE + i * 32 * HG_ROWB) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(st + 3 * PLANE + i * 32 * HG_ROWB) = u32x2{l0, l1};
+        }
+    };
+    int frag_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) frag_off[s] = r32 * HG_ROWB + (((2 * s + h) ^ ((r32 >> 2) & 3)) << 4);
+    const int a_off = wm * TM * 32 * HG_ROWB, w_off = 2 * PLANE + wn * TN * 32 * HG_ROWB;
+    auto load_frags = [&](int buf, int s, f16x8 (&af)[TM][2], f16x8 (&wf)[TN][2]) {
+        const unsigned char* b = smem + buf * STAGE + frag_off[s];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const f16x8*>(b + a_off + q * PLANE + i * 32 * HG_ROWB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j][q] = *reinterpret_cast<const f16x8*>(b + w_off + q * PLANE + j * 32 * HG_ROWB);
+        }
+    };
+#define HP_TERM(AF, WF, PA, PW)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][PA], WF[j][PW], acc[i][j], 0, 0, 0);
+
+    f16x8 af0[TM][2], wf0[TN][2], af1[TM][2], wf1[TN][2];
+    const int nslabs = (p.K + HG_BK - 1) / HG_BK;
+    auto slab_body = [&](int t, int buf, f32x4 (&a_next)[NF4], f32x4 (&w_next)[NF4]) {
+        // ---- region A
+        load_frags(buf, 1, af1, wf1);
+        HP_TERM(af0, wf0, 0, 1) HP_TERM(af0, wf0, 1, 0) HP_TERM(af0, wf0, 0, 0)
+        split_store(buf ^ 1, a_next, w_next);                  // slab t+1
+        load_slab((t + 3) * HG_BK, a_next, w_next);            // registers free again: slab t+3
+        HP_TERM(af1, wf1, 0, 1)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // F1 reads first
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 8, 0);
+        __syncthreads();
+        // ---- region B
+        load_frags(buf ^ 1, 0, af0, wf0);                      // (after the last slab: the all-zero slab, unused)
+        HP_TERM(af1, wf1, 1, 0) HP_TERM(af1, wf1, 0, 0)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+    };
+    load_slab(0, ra[0], rw[0]);
+    load_slab(HG_BK, ra[1], rw[1]);
+    split_store(0, ra[0], rw[0]);
+    load_slab(2 * HG_BK, ra[0], rw[0]);
+    __syncthreads();
+    load_frags(0, 0, af0, wf0);
+    int t = 0;
+    for (; t + 1 < nslabs; t += 2) {   // straight-line pairs: every vmcnt wait stays counted
+        slab_body(t, 0, ra[1], rw[1]);
+        slab_body(t + 1, 1, ra[0], rw[0]);
+    }
+    if (t < nslabs) slab_body(t, 0, ra[1], rw[1]);
+#undef HP_TERM
+
+    __syncthreads();   // every wave is done reading operand fragments
+    gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+                                  n0 + wn * TN * 32, lane, p.C, p.residual);
+}
+
 static int g_f16x3_cfg = -1;  // tuning hook: 0 = 128x128 (2x2 waves of 64x64), 1 = 128x64 (4x1 waves of 32x64), 2 = 128x128 without fragment double
-// buffering (fewer registers), -1 = auto
+// buffering (fewer registers), 3 = 128x128 software-pipelined (double-buffered LDS), -1 = auto
 PSAM_API void psam_gemm_f16x3_force_config(int32_t cfg) { g_f16x3_cfg = cfg; }
 
 // C = act(alpha * A @ W^T + bias + rowbias[row/rowgroup]) + residual; scaleA[M], scaleW[N] from psam_row_scale_f16.
@@ -291,6 +434,7 @@ PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scale
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
     else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
+    else if (cfg == 3) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<0>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
     return psam_launch_status("psam_gemm_f16x3: launch failed");
 }

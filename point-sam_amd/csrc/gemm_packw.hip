@@ -86,7 +86,7 @@ PSAM_API int32_t psam_pack_weight_bf16x3(const float* W, int64_t ldw, int32_t N,
 
 // ---------------------------------------------------------------------------------------------- GEMM
 template <int TM, int TN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void gemm_bf16x6_pw_kernel(const PackWArgs p) {
+__global__ __launch_bounds__(256) void gemm_bf16x6_pw_kernel(const PackWArgs p) {
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int A_F4 = BM * 8 / 256;
     constexpr int PLANE_A = BM * PW_ROWB;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void split3(const f32x2 x, unsigned& hi, unsigned& mi
 // WM x WN waves (4 in total), each TM x TN accumulator tiles of 32x32.  FDB: double-buffer the fragment registers
 // across the two k16 steps of a slab (costs 12*(TM+TN) VGPRs).
 template <int WM, int WN, int TM, int TN, bool FDB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void gemm_bf16x6_kernel(const SplitGemmArgs p) {
+__global__ __launch_bounds__(256) void gemm_bf16x6_kernel(const SplitGemmArgs p) {
     static_assert(WM * WN == 4, "256-thread workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = BM * 8 / 256, W_F4 = BN * 8 / 256;   // float4 per thread per slab

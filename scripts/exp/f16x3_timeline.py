@@ -7,7 +7,7 @@ L.psam_row_scale_f16.argtypes=[ctypes.c_void_p,ctypes.c_int64,ctypes.c_int32,cty
 L.dbg_set_buffer.argtypes=[ctypes.c_void_p]; L.psam_gemm_f16x3_force_config.argtypes=[ctypes.c_int32]
 st=torch.cuda.current_stream().cuda_stream
 for (M,N,K) in [(4096,3072,1024),(4096,5504,1024),(4096,1024,2752)]:
-  for cfg in (0,1):
+  for cfg in (0,1,3):
     x=torch.randn(M,K,device="cuda"); W=torch.randn(N,K,device="cuda"); y=torch.empty(M,N,device="cuda")
     sa=torch.empty(M,device="cuda"); sw=torch.empty(N,device="cuda")
     L.psam_row_scale_f16(x.data_ptr(),K,M,K,sa.data_ptr(),st); L.psam_row_scale_f16(W.data_ptr(),K,N,K,sw.data_ptr(),st)

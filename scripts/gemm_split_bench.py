@@ -12,7 +12,7 @@ for name, M, N, K in SHAPES:
     rows = torch.randint(0, M, (256,), generator=g).cuda()
     ref = (x[rows].double() @ W.double().T + b.double())
     line = f"{name:11s} {M:7d}x{N:5d}x{K:5d} |"
-    for mode in ("f32", "bf16x6:0", "bf16x6:1", "f16x3:0", "f16x3:1", "f16x3:2"):
+    for mode in ("f32", "bf16x6:0", "bf16x6:1", "f16x3:0", "f16x3:1", "f16x3:2", "f16x3:3"):
         if ":" in mode:
             getattr(ops._lib.load(), f"psam_gemm_{mode.split(':')[0]}_force_config")(int(mode[-1]))
         ops.GEMM_MODE = mode.split(":")[0]

@@ -180,7 +180,7 @@ def test_gemm_bf16x6_matches_fp64_like_f32(ops, M, N, K):
     assert errs["bf16x6"] < 4 * errs["f32"] + 1e-7, errs
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 36), (520, 640, 2752)])
 def test_gemm_f16x3_matches_fp64_like_f32(ops, cfg, M, N, K):
     """The scaled 2-way fp16 split GEMM must be in the accuracy class of the f32-MFMA GEMM (both against fp64): operands with
