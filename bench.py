@@ -50,8 +50,8 @@ def main():
     ap.add_argument("--groups", type=int, default=512)
     ap.add_argument("--group-size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=8, help="clouds per GPU per step")
-    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "f16x3"],
-                    help="arithmetic of the large GEMMs; both are fp32-accurate and pass the same parity tests (DESIGN.md section 4)")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3"],
+                    help="arithmetic of the large GEMMs; all three are fp32-grade and pass the same parity tests (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run FPS/kNN of each batch inline instead of one batch ahead on a side stream")
     ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")

@@ -135,6 +135,9 @@ void psam_gemm_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64, 2
  * at common.py:488,494, timm blocks, transformer.py:59,128-138, mask_decoder.py:55. */
 int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                        int64_t rows, int32_t cols, float eps, int32_t act, psam_stream_t stream);
+/* Same, plus row_scale[rows] (optional): the power-of-two f16x3 scale of every OUTPUT row (psam_row_scale_f16 fused in). */
+int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
+                          int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, psam_stream_t stream);
 
 /* out = LayerNorm_H(SiLU(gx[:,0:H]) * gx[:,xoff:xoff+H]), zero-padded to ldo columns.
  * Replaces timm SwiGLU (act, mul, norm) inside eva02 blocks (called through pc_encoder.py:138-139). */

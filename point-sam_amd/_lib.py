@@ -42,6 +42,7 @@ SIGNATURES = {
     "psam_gemm_f16x3": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3_force_config": (None, [i32]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
+    "psam_layernorm_rs": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, ptr]),
     "psam_swiglu_ln": (i32, [ptr, i64, i32, ptr, ptr, ptr, i64, i64, i32, f32, ptr]),
     "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),

@@ -68,16 +68,7 @@ __global__ __launch_bounds__(256) void row_scale_f16_kernel(const float* __restr
         for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[c]));
     }
     m = wave_max(m);
-    if (lane == 0) {
-        const unsigned bits = __builtin_bit_cast(unsigned, m);
-        int e = (int)((bits >> 23) & 0xff) - 127;
-        float s = 1.f;
-        if (bits != 0 && e != 128) {           // finite, non-zero (subnormal maxima clamp to e = -100)
-            e = e < -100 ? -100 : (e > 100 ? 100 : e);
-            s = __builtin_bit_cast(float, (unsigned)(127 + 14 - e) << 23);
-        }
-        scale[row] = s;
-    }
+    if (lane == 0) scale[row] = f16_row_scale(m);
 }
 
 PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* scale, hipStream_t stream) {
@@ -427,7 +418,8 @@ PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scale
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     int cfg = g_f16x3_cfg;
-    if (cfg < 0) cfg = (psam_cdiv(M, 128) * psam_cdiv(N, 128) >= 512 && K > 256) ? 0 : 1;
+    // measured (scripts/gemm_split_bench.py): the software-pipelined 128x128 kernel wins on every shape of the path
+    if (cfg < 0) cfg = N > 64 ? 3 : 1;
     const int bn = cfg == 1 ? 64 : 128;
     p.tiles_m = (int)psam_cdiv(M, 128);
     p.tiles_n = (int)psam_cdiv(N, bn);

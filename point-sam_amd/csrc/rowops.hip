@@ -14,10 +14,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NREG>  // NREG*64 >= cols for the register path; NREG == 0 -> streaming path
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
                                                         const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
-                                                        int64_t ldy, int64_t rows, int cols, float eps, int act) {
+                                                        int64_t ldy, int64_t rows, int cols, float eps, int act, float* __restrict__ rscale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
+    float amax = 0.f;
     const float* xr = x + row * ldx;
     const float* rr = res ? res + row * ldr : nullptr;
     float* yr = y + row * ldy;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 float o = (v[i] - mean) * r * w[c] + b[c];
                 if (act == 1) o = gelu_erf(o);
                 yr[c] = o;
+                amax = fmaxf(amax, fabsf(o));
             }
         }
     } else {
@@ -63,8 +65,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float o = (t - mean) * r * w[c] + b[c];
             if (act == 1) o = gelu_erf(o);
             yr[c] = o;
+            amax = fmaxf(amax, fabsf(o));
         }
     }
+    if (rscale) { amax = wave_max(amax); if (lane == 0) rscale[row] = f16_row_scale(amax); }
 }
 
 // float4 variant: NV4*256 >= cols; rows must be 16-byte aligned with ld >= round_up(cols, 4) (the last, partial float4 of
@@ -72,10 +76,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NV4>
 __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
                                                            const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
-                                                           int64_t ldy, int64_t rows, int cols, float eps, int act) {
+                                                           int64_t ldy, int64_t rows, int cols, float eps, int act, float* __restrict__ rscale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
+    float amax = 0.f;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ldx);
     const f32x4* rr = res ? reinterpret_cast<const f32x4*>(res + row * ldr) : nullptr;
     float* yrow = y + row * ldy;
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
             f32x4 o = (v[i] - mean) * r * w4 + b4;
             if (act == 1) { o[0] = gelu_erf(o[0]); o[1] = gelu_erf(o[1]); o[2] = gelu_erf(o[2]); o[3] = gelu_erf(o[3]); }
             *reinterpret_cast<f32x4*>(yrow + c * 4) = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         } else if (c * 4 < cols) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -123,14 +129,17 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
                     float o = (v[i][e] - mean) * r * w[c * 4 + e] + b[c * 4 + e];
                     if (act == 1) o = gelu_erf(o);
                     yrow[c * 4 + e] = o;
+                    amax = fmaxf(amax, fabsf(o));
                 }
             }
         }
     }
+    if (rscale) { amax = wave_max(amax); if (lane == 0) rscale[row] = f16_row_scale(amax); }
 }
 
-PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
-                                int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, hipStream_t stream) {
+// row_scale (optional, [rows]): the f16x3 GEMM's power-of-two row scale of the OUTPUT rows (psam_row_scale_f16 fused in).
+PSAM_API int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                   int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, hipStream_t stream) {
     PSAM_REQUIRE(x && w && b && y, PSAM_EINVAL, "psam_layernorm: null pointer");
     PSAM_REQUIRE(rows > 0 && cols > 0, PSAM_EINVAL, "psam_layernorm: bad shape");
     PSAM_REQUIRE(act == 0 || act == 1, PSAM_EINVAL, "psam_layernorm: act must be 0 or 1 (GELU)");
@@ -139,7 +148,7 @@ PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, i
     const bool vec = cols >= 256 && cols <= 4096 && ((ldx | ldy | (res ? ldr : 0)) & 3) == 0 && ldx >= c4 && ldy >= c4 && (!res || ldr >= c4) &&
                      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)w | (uintptr_t)b) & 15) == 0;
     if (vec) {
-#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act)
+#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale)
         if (cols <= 256) LNV_LAUNCH(1);
         else if (cols <= 512) LNV_LAUNCH(2);
         else if (cols <= 1024) LNV_LAUNCH(4);
@@ -148,7 +157,7 @@ PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, i
 #undef LNV_LAUNCH
         return psam_launch_status("psam_layernorm: launch failed");
     }
-#define LN_LAUNCH(R) hipLaunchKernelGGL(layernorm_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act)
+#define LN_LAUNCH(R) hipLaunchKernelGGL(layernorm_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale)
     if (cols <= 128) LN_LAUNCH(2);
     else if (cols <= 256) LN_LAUNCH(4);
     else if (cols <= 512) LN_LAUNCH(8);
@@ -157,6 +166,11 @@ PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, i
     else LN_LAUNCH(0);
 #undef LN_LAUNCH
     return psam_launch_status("psam_layernorm: launch failed");
+}
+
+PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, hipStream_t stream) {
+    return psam_layernorm_rs(x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

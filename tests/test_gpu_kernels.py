@@ -232,6 +232,18 @@ def test_gemm_f16x3_extreme_row_scales(ops):
     assert ok.all()
 
 
+@pytest.mark.parametrize("cols", [128, 300, 1024, 2752, 5000])
+def test_layernorm_emits_f16x3_row_scale(ops, cols):
+    g = torch.Generator().manual_seed(cols)
+    x = (torch.randn(77, cols, generator=g) * torch.exp(3 * torch.randn(77, 1, generator=g))).cuda()
+    w, b = torch.randn(cols, generator=g).cuda(), torch.randn(cols, generator=g).cuda()
+    for act in (ops.ACT_NONE, ops.ACT_GELU):
+        rs = torch.empty(77, device="cuda")
+        y = ops.layernorm(x, w, b, 1e-5, act=act, scale_out=rs)
+        assert torch.equal(rs, ops.row_scale_f16(y))
+        assert torch.equal(y, ops.layernorm(x, w, b, 1e-5, act=act))
+
+
 def test_gemm_f16x3_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
