@@ -145,15 +145,16 @@ def main():
                 note = ("fp32-equivalent peak of the scheme = bf16 dense MFMA peak 2500 TFLOP/s / 6 executed products; "
                         f"executed matrix-pipe rate = {ach * 6:.0f} TFLOP/s = {ach * 6 / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak")
             traffic = None
+            tfile = "r01_v8_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
             try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_traffic.json")))
-                key = "void gemm_bf16x6_kernel<2, 2, 2, 2, true>" if kind == "bf16x6" else None
+                tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
+                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<0>"}.get(kind)
                 if key and key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
             except (OSError, ValueError, KeyError):
                 traffic = None
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "traffic_note": "bytes/launch of the 128x128-tile instantiation, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_v6_traffic.json" if traffic else None,
+                        "traffic": traffic, "traffic_note": f"bytes/launch of the 128x128-tile kernel, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
                         "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
                         "sampling": f"every {ops.GEMM_PROFILE_EVERY}th GEMM launch of the timed region, HIP events on the launch stream",
                         "avg_launch_ms": round(tot_ms / len(sel), 4), "avg_launch_gflop": round(tot_fl / len(sel) / 1e9, 3)}

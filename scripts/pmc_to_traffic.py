@@ -1,0 +1,23 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv (separate passes) -> per-kernel HBM bytes per launch (profiles/*_traffic.json).
+The derived counters are in KiB (bytes = value * 1024); FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of the
+wide coalesced reads).  Usage: python scripts/pmc_to_traffic.py TAG profiles/TAG_traffic.json (after scripts/gpu_pmc.sh TAG)."""
+import csv, json, sys, collections, glob, os
+def per_kernel(path):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0]
+        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return acc
+tag = sys.argv[1]
+fetch = per_kernel(glob.glob(f"gpurun_out/pmc_fetch_{tag}/**/*counter_collection.csv", recursive=True)[0])
+write = per_kernel(glob.glob(f"gpurun_out/pmc_write_{tag}/**/*counter_collection.csv", recursive=True)[0])
+out = {}
+for k, (v, n) in sorted(fetch.items(), key=lambda kv: -kv[1][0]):
+    if k not in write or n < 2 or not ("gemm" in k or "attn" in k or "fps" in k or "knn" in k or "layernorm" in k): continue
+    f = v / n * 1024; w = write[k][0] / write[k][1] * 1024
+    out[k] = {"launches": n, "FETCH_SIZE_bytes_per_launch_raw": int(f), "fetch_bytes_per_launch_corrected_x2": int(2 * f),
+              "WRITE_SIZE_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(2 * f + w)}
+out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; FETCH_SIZE doubled per "
+                "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); counts memory-side (fabric) requests, Infinity-Cache hits included")
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
