@@ -150,6 +150,11 @@ int32_t psam_swiglu_ln(const float* gx, int64_t ldg, int32_t xoff, const float* 
 int32_t psam_attention_f32(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                            int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
                            float scale, psam_stream_t stream);
+/* Same contract on the fp16 matrix pipe with fp32-grade products (power-of-two scaling + hi/lo fp16 split of Q, K, V and of the
+ * probabilities, 3 MFMA products each; csrc/attention.hip).  head_dim in {64, 128}. */
+int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                           int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                           float scale, psam_stream_t stream);
 
 /* Same contraction for the decoder's token-sized problems (any hd, few queries or few keys).
  * Replaces Attention.forward's matmul-softmax-matmul: pc_sam/model/transformer.py:226-233. */

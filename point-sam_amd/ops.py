@@ -294,8 +294,9 @@ def swiglu_ln(gx, xoff, H, w, b, eps, out):
 def attention(q, k, v, out, B, H, Lq, Lk, hd, scale):
     """q/k/v/out: 2-D row views [B*L, >=H*hd] (may be column slices of a fused qkv buffer)."""
     qp, ldq = _row_view(q, "q"); kp, ldk = _row_view(k, "k"); vp, ldv = _row_view(v, "v"); op, ldo = _row_view(out, "out")
-    check(_lib.load().psam_attention_f32(qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale,
-                                         _stream()), "psam_attention_f32")
+    L = _lib.load()
+    fn = L.psam_attention_f16x3 if (GEMM_MODE == "f16x3" and hd in (64, 128)) else L.psam_attention_f32
+    check(fn(qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale, _stream()), "psam_attention")
     return out
 
 

@@ -392,6 +392,41 @@ def test_flash_attention(ops, hd, H, Lq, Lk):
     _close(out.view(B, Lq, D), want, 2e-5, what=f"flash hd={hd}")
 
 
+@pytest.mark.parametrize("hd,H,Lq,Lk", [(64, 4, 512, 512), (64, 2, 130, 70), (64, 3, 33, 200), (128, 2, 200, 129), (64, 1, 5, 64)])
+def test_flash_attention_f16x3(ops, hd, H, Lq, Lk):
+    """fp16-split flash attention: same tolerance as the f32-MFMA kernel against an fp64 SDPA; q/k/v with very different
+    magnitudes per tensor and per row (the scales are per query row / per 64-key tile)."""
+    g = torch.Generator().manual_seed(hd + Lq)
+    B, D = 2, H * hd
+    q = torch.randn(B, Lq, D, generator=g) * torch.exp(torch.randn(B, Lq, 1, generator=g)) * 37.0
+    k = torch.randn(B, Lk, D, generator=g) * 1e-3
+    v = torch.randn(B, Lk, D, generator=g) * torch.exp(2 * torch.randn(B, Lk, 1, generator=g)) * 1e4
+    scale = hd ** -0.5 * 40.0      # logits of a few units
+    out = torch.empty(B * Lq, D, device="cuda")
+    with ops.gemm_mode("f16x3"):
+        ops.attention(cu(q).view(-1, D), cu(k).view(-1, D), cu(v).view(-1, D), out, B, H, Lq, Lk, hd, scale)
+    want = _sdpa(q, k, v, H, scale)
+    err = (out.view(B, Lq, D).cpu().double() - want).abs().max().item() / want.abs().max().item()
+    out32 = torch.empty_like(out)
+    ops.attention(cu(q).view(-1, D), cu(k).view(-1, D), cu(v).view(-1, D), out32, B, H, Lq, Lk, hd, scale)
+    err32 = (out32.view(B, Lq, D).cpu().double() - want).abs().max().item() / want.abs().max().item()
+    print(f"\n[flash f16x3 hd={hd} Lq={Lq} Lk={Lk}] rel err {err:.2e} (f32 kernel {err32:.2e})")
+    assert err < 2e-6 and err < 4 * err32 + 2e-7, (err, err32)
+
+
+def test_flash_attention_f16x3_spike(ops):
+    g = torch.Generator().manual_seed(9)
+    B, H, hd, L = 1, 1, 64, 256
+    q, k, v = (torch.randn(B, L, hd, generator=g) for _ in range(3))
+    k[0, 200] = q[0, 7] * 4.0
+    v[0, 130:] *= 1000.0           # V tile scales change by 2^10 mid-sequence
+    out = torch.empty(B * L, hd, device="cuda")
+    with ops.gemm_mode("f16x3"):
+        ops.attention(cu(q).view(L, hd), cu(k).view(L, hd), cu(v).view(L, hd), out, B, H, L, L, hd, 1.0)
+    want = _sdpa(q, k, v, H, 1.0)
+    assert ((out.view(B, L, hd).cpu().double() - want).abs().max() / want.abs().max()).item() < 2e-6
+
+
 def test_flash_attention_running_max_spike(ops):
     """Forces the rescale branch: one key dominates late in the sequence."""
     g = torch.Generator().manual_seed(9)
