@@ -25,14 +25,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float inv = 1.0f / (float)cols;
     if (NREG > 0) {
         float v[NREG > 0 ? NREG : 1];
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {   // unconditional loads (clamped index), see layernorm_v4_kernel
+            const int c = i * 64 + lane;
+            v[i] = xr[c < cols ? c : cols - 1];
+        }
+        if (rr) {
+#pragma unroll
+            for (int i = 0; i < NREG; ++i) {
+                const int c = i * 64 + lane;
+                v[i] += rr[c < cols ? c : cols - 1];
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NREG; ++i) {
-            const int c = i * 64 + lane;
-            float t = 0.f;
-            if (c < cols) { t = xr[c]; if (rr) t += rr[c]; }
-            v[i] = t;
-            s += t;
+            if (i * 64 + lane >= cols) v[i] = 0.f;
+            s += v[i];
         }
         const float mean = wave_sum(s) * inv;
         float q = 0.f;
@@ -86,20 +95,29 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
     float* yrow = y + row * ldy;
     const int c4n = (cols + 3) >> 2;
     const float inv = 1.0f / (float)cols;
+    // Loads are UNCONDITIONAL (index clamped to the last float4 of the row, value masked afterwards): a load under an
+    // exec-mask branch makes the compiler wait vmcnt(0) at the join, which serialised the 11..16 loads of a row
+    // (one full memory round trip each).
     f32x4 v[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = xr[c < c4n ? c : c4n - 1];
+    }
+    if (rr) {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = i * 64 + lane;
+            v[i] += rr[c < c4n ? c : c4n - 1];
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = i * 64 + lane;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (c < c4n) {
-            t = xr[c];
-            if (rr) t += rr[c];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (c * 4 + e >= cols) t[e] = 0.f;
-        }
-        v[i] = t;
-        s += (t[0] + t[1]) + (t[2] + t[3]);
+        for (int e = 0; e < 4; ++e) if (c * 4 + e >= cols) v[i][e] = 0.f;
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) * inv;
     float q = 0.f;
@@ -113,11 +131,13 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
         }
     }
     const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+    const int cfull = cols >> 2;    // float4 groups entirely inside the row (cols >= 256 on this path, so cfull >= 64)
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = i * 64 + lane;
+        const int cl = c < cfull ? c : cfull - 1;    // unconditional (clamped) weight loads: no wait per group
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + cl * 4), b4 = *reinterpret_cast<const f32x4*>(b + cl * 4);
         if (c * 4 + 3 < cols) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + c * 4), b4 = *reinterpret_cast<const f32x4*>(b + c * 4);
             f32x4 o = (v[i] - mean) * r * w4 + b4;
             if (act == 1) { o[0] = gelu_erf(o[0]); o[1] = gelu_erf(o[1]); o[2] = gelu_erf(o[2]); o[3] = gelu_erf(o[3]); }
             *reinterpret_cast<f32x4*>(yrow + c * 4) = o;
@@ -194,7 +214,9 @@ __global__ __launch_bounds__(256) void swiglu_ln_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < NREG; ++i) {
             const int c = i * 64 + lane;
-            u[i] = c < H ? silu(g[c]) * x[c] : 0.f;
+            const int cc = c < H ? c : H - 1;        // unconditional loads (clamped), see layernorm_v4_kernel
+            const float gv = g[cc], xv = x[cc];
+            u[i] = c < H ? silu(gv) * xv : 0.f;
             s += u[i];
         }
         const float mean = wave_sum(s) * inv;
