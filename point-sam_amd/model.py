@@ -59,9 +59,12 @@ class PointCloudSAM:
     """HIP implementation behind the reference's ``PointCloudSAM`` inference interface."""
 
     def __init__(self, cfg: ModelConfig, state_dict, device="cuda", precision: str = "f32"):
-        """precision: arithmetic of the large GEMMs -- "f32" (v_mfma_f32_32x32x2_f32, exact fp32 products) or "bf16x6"
-        (exact 3-way bf16 split of both operands, 6 partial products on the bf16 matrix pipe, fp32 accumulation:
-        fp32-GEMM accuracy at 6/16 of the matrix-pipe time; see csrc/gemm_split.hip)."""
+        """precision: arithmetic of the large GEMMs (and, for "f16x3", of the encoder attention) --
+        "f32": v_mfma_f32_32x32x2_f32, exact fp32 products;
+        "bf16x6": exact 3-way bf16 split of both operands, 6 partial products on the bf16 matrix pipe (csrc/gemm_split.hip);
+        "f16x3": power-of-two row scales + 2-way fp16 split, 3 partial products on the fp16 matrix pipe
+        (csrc/gemm_f16x3.hip, csrc/attention.hip) -- the fastest; bench.py's default.
+        All three accumulate in fp32, keep fp32 tensors in HBM and meet the same parity tests at the same error level."""
         check_state_dict(cfg, state_dict)
         if precision not in ops.GEMM_MODES:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")

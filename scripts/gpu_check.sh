@@ -14,7 +14,7 @@ for t in $FUNCS_K; do
   echo "== kernels::$t" >> $LOG
   timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "$t" 2>&1 | tail -40 >> $LOG
 done
-FUNCS_E="test_evaluation_harness test_forward_eval_protocol test_cfg3_large_scene_tokenizer_and_run test_cfg5_giant_five_click_loop test_batch_pipeline_matches_predict_masks test_against_reference_golden test_against_oracle test_properties_full_size test_predictor_click_loop test_out_of_range_coordinates_raise"
+FUNCS_E="test_evaluation_harness test_forward_eval_protocol test_cfg3_large_scene_tokenizer_and_run test_cfg5_giant_five_click_loop test_batch_pipeline_matches_predict_masks test_against_reference_golden test_against_oracle test_properties_full_size test_predictor_click_loop test_demo_server_segment_route test_out_of_range_coordinates_raise"
 for t in $FUNCS_E; do
   echo "== e2e::$t" >> $LOG
   timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -s --tb=short -p no:cacheprovider -k "$t" 2>&1 | tail -40 >> $LOG

@@ -139,6 +139,47 @@ def test_predictor_click_loop(gpu):
     assert _maxerr(m, want[0][0]) < TOL
 
 
+def test_demo_server_segment_route(gpu):
+    """The demo back end (point_sam_amd/demo_server.py) over HTTP on the HIP predictor: /sampled_pointcloud + four /segment
+    clicks reproduce the oracle's click loop (demo/app.py:177-206), the encoder runs once."""
+    import http.client, json, threading
+    from point_sam_amd.predictor import PointSAMPredictor
+    from point_sam_amd.demo_server import DemoSession, serve
+    cfg = get_config("tiny")
+    sd = random_state_dict(cfg, 3)
+    pred = PointSAMPredictor(gpu(cfg, sd, precision="f16x3"))
+    xyz, rgb, _, _ = O.synthetic_batch(1, 1500, seed=8)
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, 1500, (4,), generator=g)
+    labels = [1, 0, 1, 1]
+    want = O.click_loop(sd, cfg, xyz, rgb, xyz[:, idx], torch.tensor([labels]))
+    sess = DemoSession(pred)
+    srv = serve(sess, "127.0.0.1", 0)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    try:
+        def post(path, body):
+            c = http.client.HTTPConnection("127.0.0.1", srv.server_address[1], timeout=120)
+            c.request("POST", path, json.dumps(body), {"Content-Type": "application/json"})
+            r = c.getresponse()
+            return r.status, json.loads(r.read())
+        flat = lambda t: {str(i): float(v) for i, v in enumerate(t.flatten().tolist())}
+        assert post("/sampled_pointcloud", {"points": flat(xyz[0]), "colors": flat(rgb[0])}) == (200, {"response": "success"})
+        state = None
+        for t in range(4):
+            st, out = post("/segment", {"prompt_point": xyz[0, idx[t]].tolist(), "prompt_label": labels[t]})
+            assert st == 200
+            best = want[t][1][0].argmax()
+            margin = want[t][0][0, best].abs() > 1e-3                      # ignore points whose logit is within tolerance of 0
+            assert torch.equal(torch.tensor(out["seg"])[margin], (want[t][0][0, best] > 0)[margin]), t
+            assert _maxerr(sess.prompt_mask, want[t][0][:, best]) < TOL
+            state = state or pred._state
+            assert pred._state is state, "encoder must be cached across clicks"
+        st, out = post("/segment", {"prompt_point": [2.0, 0.0, 0.0], "prompt_label": 1})
+        assert st == 400 and "ValueError" in out["error"]                   # prompts outside [-1,1]^3 (prompt_encoder.py:44-46)
+    finally:
+        srv.shutdown()
+
+
 def test_out_of_range_coordinates_raise(gpu):
     cfg = get_config("tiny")
     model = gpu(cfg, random_state_dict(cfg, 3))
