@@ -74,6 +74,13 @@ int32_t psam_group_gather(const float* xyz, const float* feats, const float* cen
 int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W, const float* bias,
                       const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
                       float* out, psam_stream_t stream);
+/* Both with the grouper's `radius` option (KNNGrouper.radius, common.py:107-108; MaskEncoder.radius, common.py:161-164;
+ * configs/model/enc_with_radius.yaml): relative coordinates divided by radius; radius <= 0 = none. */
+int32_t psam_group_gather_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B, int32_t rep,
+                            int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, psam_stream_t stream);
+int32_t psam_patch_l1_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W, const float* bias,
+                        const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
+                        float radius, float* out, psam_stream_t stream);
 
 /* Click simulation of the evaluation protocol.  psam_error_regions: fn = gt & !(logit > 0), fp = !gt & (logit > 0)
  * (logits == NULL: fn = gt, fp = 0) -- sample_fixed_points, pc_sam/model/common.py:388-405.  psam_border_farthest: per

@@ -130,23 +130,25 @@ def knn_numpy(centers: np.ndarray, xyz: np.ndarray, k: int) -> np.ndarray:
     return np.argsort(d2, axis=1, kind="stable")[:, :k].astype(np.int64)
 
 
-def group_points(xyz, features, centers, knn_idx) -> torch.Tensor:
-    """[B,G,K,3+C]: neighbour xyz relative to its center, then neighbour features (common.py:99-120,
-    radius=None, centralize_features=False as in configs/model/*.yaml)."""
+def group_points(xyz, features, centers, knn_idx, radius=None) -> torch.Tensor:
+    """[B,G,K,3+C]: neighbour xyz relative to its center (divided by `radius` when given, common.py:107-108), then neighbour
+    features (common.py:99-120; centralize_features=False as in every configs/model/*.yaml)."""
     B, N, _ = xyz.shape
     G, K = knn_idx.shape[1:]
     flat = (knn_idx + torch.arange(B).view(B, 1, 1) * N).reshape(-1)
     nbr_xyz = xyz.reshape(-1, 3)[flat].reshape(B, G, K, 3) - centers.unsqueeze(2)
+    if radius is not None:
+        nbr_xyz = nbr_xyz / radius
     nbr_f = features.reshape(-1, features.shape[-1])[flat].reshape(B, G, K, -1)
     return torch.cat([nbr_xyz, nbr_f], dim=-1)
 
 
-def knn_grouper(xyz, features, num_groups, group_size, mode="exact") -> Dict[str, torch.Tensor]:
+def knn_grouper(xyz, features, num_groups, group_size, mode="exact", radius=None) -> Dict[str, torch.Tensor]:
     """KNNGrouper.forward (common.py:73-123)."""
     fps_idx = fps(xyz, num_groups)
     centers = batch_index_select(xyz, fps_idx)
     _, knn_idx = knn(centers, xyz, group_size, mode)
-    return dict(features=group_points(xyz, features, centers, knn_idx), centers=centers, knn_idx=knn_idx, fps_idx=fps_idx)
+    return dict(features=group_points(xyz, features, centers, knn_idx, radius), centers=centers, knn_idx=knn_idx, fps_idx=fps_idx)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -204,7 +206,7 @@ def eva_block(sd, p: str, x: torch.Tensor, vit) -> torch.Tensor:
 
 def pc_encoder(sd, cfg, coords, features, mode="exact"):
     """PointCloudEncoder.forward (pc_encoder.py:118-145) -> (embeddings [B,G,E], patches dict)."""
-    patches = knn_grouper(coords, features, cfg.num_groups, cfg.group_size, mode)
+    patches = knn_grouper(coords, features, cfg.num_groups, cfg.group_size, mode, getattr(cfg, "radius", None))
     emb = patch_encoder(sd, "pc_encoder.patch_embed.patch_encoder", patches["features"], cfg.ln_eps)
     patches["embeddings"] = emb
     x = _lin(sd, "pc_encoder.patch_proj", emb)
@@ -244,7 +246,7 @@ def mask_encoder(sd, cfg, masks: Optional[torch.Tensor], coords, centers, knn_id
         return sd["mask_encoder.no_mask_embed.weight"].reshape(1, 1, -1).expand(centers.shape[0], centers.shape[1], -1)
     B = coords.shape[0]
     rep = masks.shape[0] // B
-    rel = group_points(coords, coords, centers, knn_idx)[..., :3]  # [B,G,K,3]
+    rel = group_points(coords, coords, centers, knn_idx, getattr(cfg, "radius", None))[..., :3]  # [B,G,K,3]
     rel = rel.repeat_interleave(rep, dim=0)
     kidx = knn_idx.repeat_interleave(rep, dim=0)
     logit = torch.gather(masks, 1, kidx.reshape(masks.shape[0], -1)).reshape(*kidx.shape, 1)

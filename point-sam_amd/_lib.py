@@ -22,7 +22,9 @@ SIGNATURES = {
     "psam_knn": (i32, [ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
     "psam_three_nn": (i32, [ptr, ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_group_gather": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, ptr]),
+    "psam_group_gather_r": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),
     "psam_patch_l1": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, ptr, ptr]),
+    "psam_patch_l1_r": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),
     "psam_error_regions": (i32, [ptr, ptr, ptr, ptr, i64, ptr]),
     "psam_border_farthest_workspace_bytes": (size_t, [i32, i32]),
     "psam_border_farthest": (i32, [ptr, ptr, i32, i32, i32, ptr, ptr, ptr, size_t, ptr]),

@@ -40,6 +40,7 @@ class ModelConfig:
     num_multimask: int = 3       # mask_decoder.py:26
     prompt_iters: int = 5
     ln_eps: float = 1e-5         # torch.nn.LayerNorm default used by every non-timm LayerNorm
+    radius: float = None         # KNNGrouper.radius and MaskEncoder.radius (configs/model/enc_with_radius.yaml: 0.1 both); None = off
 
     @property
     def num_mask_tokens(self) -> int:
@@ -65,6 +66,9 @@ CONFIGS = {
     "giant": ModelConfig(VIT_GIANT, 512, 64, prompt_iters=10),
     "tiny": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3),
     "tiny_gelu": ModelConfig(VIT_TINY_GELU, 32, 16, prompt_iters=3),
+    # configs/model/enc_with_radius.yaml on top of default.yaml / on the tiny test transformer
+    "large_radius": ModelConfig(VIT_LARGE, 1024, 256, prompt_iters=5, radius=0.1),
+    "tiny_radius": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3, radius=0.1),
 }
 
 

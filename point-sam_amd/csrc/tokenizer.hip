@@ -414,7 +414,7 @@ PSAM_API int32_t psam_three_nn(const float* xyz, const float* centers, int32_t B
 // ------------------------------------------------------------------------------------------------
 __global__ void group_gather_kernel(const float* __restrict__ xyz, const float* __restrict__ feats, const float* __restrict__ centers,
                                     const int64_t* __restrict__ knn_idx, int rep, int N, int G, int K, int C, int64_t total,
-                                    float* __restrict__ out) {
+                                    float inv_radius, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int64_t row = t;  // (bf, g, k)
@@ -426,19 +426,26 @@ __global__ void group_gather_kernel(const float* __restrict__ xyz, const float* 
     const float* p = xyz + (b * N + n) * 3;
     const float* c = centers + (b * G + g) * 3;
     float* o = out + row * (3 + C);
-    o[0] = p[0] - c[0]; o[1] = p[1] - c[1]; o[2] = p[2] - c[2];
+    o[0] = (p[0] - c[0]) * inv_radius; o[1] = (p[1] - c[1]) * inv_radius; o[2] = (p[2] - c[2]) * inv_radius;   // inv_radius == 1: exact
     const float* f = feats + (bf * N + n) * C;
     for (int i = 0; i < C; ++i) o[3 + i] = f[i];
 }
 
-PSAM_API int32_t psam_group_gather(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
-                                   int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float* out, hipStream_t stream) {
+// radius > 0: relative coordinates are divided by it (KNNGrouper.radius / MaskEncoder.radius, configs/model/enc_with_radius.yaml;
+// as ATen does for a scalar divisor: multiply by the fp32 reciprocal); radius <= 0: none.
+PSAM_API int32_t psam_group_gather_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
+                                     int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, hipStream_t stream) {
     PSAM_REQUIRE(xyz && feats && centers && knn_idx && out, PSAM_EINVAL, "psam_group_gather: null pointer");
     PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0 && C > 0, PSAM_EINVAL, "psam_group_gather: bad shape");
     const int64_t total = (int64_t)B * rep * G * K;
     hipLaunchKernelGGL(group_gather_kernel, dim3((unsigned)psam_cdiv(total, 256)), dim3(256), 0, stream, xyz, feats, centers, knn_idx,
-                       rep, N, G, K, C, total, out);
+                       rep, N, G, K, C, total, radius > 0.f ? 1.0f / radius : 1.0f, out);
     return psam_launch_status("psam_group_gather: launch failed");
+}
+
+PSAM_API int32_t psam_group_gather(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
+                                   int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float* out, hipStream_t stream) {
+    return psam_group_gather_r(xyz, feats, centers, knn_idx, B, rep, N, G, K, C, 0.f, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__
                                                        const float* __restrict__ centers, const int64_t* __restrict__ knn_idx,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, int rep,
-                                                       int N, int G, int K, int64_t rows, float* __restrict__ out) {
+                                                       int N, int G, int K, int64_t rows, float inv_radius, float* __restrict__ out) {
     constexpr int C = CIN - 3;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__
         const float* p = xyz + (b * N + n) * 3;
         const float* c = centers + (b * G + g) * 3;
         float in[CIN];
-        in[0] = p[0] - c[0]; in[1] = p[1] - c[1]; in[2] = p[2] - c[2];
+        in[0] = (p[0] - c[0]) * inv_radius; in[1] = (p[1] - c[1]) * inv_radius; in[2] = (p[2] - c[2]) * inv_radius;
         const float* f = feats + (bf * N + n) * C;
 #pragma unroll
         for (int i = 0; i < C; ++i) in[3 + i] = f[i];
@@ -487,9 +494,9 @@ __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__
 }
 
 // W [128, 3+C] (nn.Linear layout), bias/lnw/lnb [128]; out [B*rep*G*K, 128].  C in {1, 3}.
-PSAM_API int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,
-                               const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
-                               int32_t G, int32_t K, int32_t C, float* out, hipStream_t stream) {
+PSAM_API int32_t psam_patch_l1_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,
+                                 const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
+                                 int32_t G, int32_t K, int32_t C, float radius, float* out, hipStream_t stream) {
     PSAM_REQUIRE(xyz && feats && centers && knn_idx && W && bias && lnw && lnb && out, PSAM_EINVAL, "psam_patch_l1: null pointer");
     PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0, PSAM_EINVAL, "psam_patch_l1: bad shape");
     PSAM_REQUIRE(C == 1 || C == 3, PSAM_EINVAL, "psam_patch_l1: C must be 1 (mask logit) or 3 (rgb)");
@@ -497,10 +504,16 @@ PSAM_API int32_t psam_patch_l1(const float* xyz, const float* feats, const float
     const int64_t blocks = rows / 4 < 8192 ? (rows + 3) / 4 : 8192;
 #define L1_LAUNCH(CIN)                                                                                                              \
     hipLaunchKernelGGL(patch_l1_kernel<CIN>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, feats, centers, knn_idx, W, bias, lnw, \
-                       lnb, eps, rep, N, G, K, rows, out)
+                       lnb, eps, rep, N, G, K, rows, radius > 0.f ? 1.0f / radius : 1.0f, out)
     if (C == 3) L1_LAUNCH(6); else L1_LAUNCH(4);
 #undef L1_LAUNCH
     return psam_launch_status("psam_patch_l1: launch failed");
+}
+
+PSAM_API int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,
+                               const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
+                               int32_t G, int32_t K, int32_t C, float* out, hipStream_t stream) {
+    return psam_patch_l1_r(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, B, rep, N, G, K, C, 0.f, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

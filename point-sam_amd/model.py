@@ -128,7 +128,7 @@ class PointCloudSAM:
         K = knn_idx.shape[2]
         h0 = self.cfg.patch_hidden[0]
         h1 = ops.patch_l1(coords, feats, centers, knn_idx, w[prefix + ".conv1.0.weight"], w[prefix + ".conv1.0.bias"],
-                          w[prefix + ".conv1.1.weight"], w[prefix + ".conv1.1.bias"], eps)
+                          w[prefix + ".conv1.1.weight"], w[prefix + ".conv1.1.bias"], eps, radius=self.cfg.radius)
         h2 = self._lin(prefix + ".conv1.3", h1)
         del h1
         y1 = ops.group_max(h2, K)

@@ -128,7 +128,7 @@ def three_nn(xyz: torch.Tensor, centers: torch.Tensor, eps: float = 1e-8):
     return idx, w
 
 
-def group_gather(xyz, feats, centers, knn_idx):
+def group_gather(xyz, feats, centers, knn_idx, radius=None):
     """feats [B*rep,N,C] -> [B*rep,G,K,3+C].  common.py:99-120 / 126-187."""
     _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64)
     B, N, _ = xyz.shape
@@ -136,12 +136,12 @@ def group_gather(xyz, feats, centers, knn_idx):
     G, K = knn_idx.shape[1:]
     C = feats.shape[-1]
     out = torch.empty(B * rep, G, K, 3 + C, dtype=torch.float32, device=xyz.device)
-    check(_lib.load().psam_group_gather(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), B, rep, N, G, K, C,
-                                        out.data_ptr(), _stream()), "psam_group_gather")
+    check(_lib.load().psam_group_gather_r(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), B, rep, N, G, K, C,
+                                          float(radius or 0.0), out.data_ptr(), _stream()), "psam_group_gather")
     return out
 
 
-def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None):
+def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None, radius=None):
     """Fused gather + Linear(3+C,128) + LayerNorm + GELU -> [B*rep*G*K, 128].  common.py:486-489."""
     _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64); _chk(W)
     B, N, _ = xyz.shape
@@ -152,8 +152,9 @@ def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None):
     rows = B * rep * G * K
     if out is None:
         out = torch.empty(rows, 128, dtype=torch.float32, device=xyz.device)
-    check(_lib.load().psam_patch_l1(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), W.data_ptr(), bias.data_ptr(),
-                                    lnw.data_ptr(), lnb.data_ptr(), eps, B, rep, N, G, K, C, out.data_ptr(), _stream()), "psam_patch_l1")
+    check(_lib.load().psam_patch_l1_r(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                      lnw.data_ptr(), lnb.data_ptr(), eps, B, rep, N, G, K, C, float(radius or 0.0), out.data_ptr(), _stream()),
+          "psam_patch_l1")
     return out
 
 

@@ -35,5 +35,10 @@ def golden_gelu():
 
 
 @pytest.fixture(scope="session")
+def golden_radius():
+    return load_golden("ref_tiny_radius")
+
+
+@pytest.fixture(scope="session")
 def golden_forward():
     return load_golden("ref_tiny_forward_eval")

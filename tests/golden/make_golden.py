@@ -163,9 +163,9 @@ def build_reference_model(cfg, sd):
 
     model = PointCloudSAM(
         pc_encoder=PointCloudEncoder(
-            PatchEmbed(cfg.in_channels, cfg.patch_out, cfg.num_groups, cfg.group_size), StandInEva(cfg.vit), cfg.embed_dim
+            PatchEmbed(cfg.in_channels, cfg.patch_out, cfg.num_groups, cfg.group_size, radius=cfg.radius), StandInEva(cfg.vit), cfg.embed_dim
         ),
-        mask_encoder=MaskEncoder(cfg.embed_dim),
+        mask_encoder=MaskEncoder(cfg.embed_dim, radius=cfg.radius),
         mask_decoder=MaskDecoder(cfg.embed_dim, TwoWayTransformer(cfg.dec_depth, cfg.embed_dim, cfg.dec_heads, cfg.dec_mlp)),
         prompt_iters=cfg.prompt_iters,
     )
@@ -236,4 +236,5 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     make_case("ref_tiny_swiglu", "tiny", B=2, N=1024, M=2, P=2, seed=7)
     make_case("ref_tiny_gelu", "tiny_gelu", B=1, N=777, M=1, P=1, seed=11)
+    make_case("ref_tiny_radius", "tiny_radius", B=2, N=900, M=1, P=2, seed=5)
     make_forward_case("ref_tiny_forward_eval", "tiny", B=2, N=1024, seed=7, iters=4)

@@ -28,7 +28,7 @@ def _maxerr(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 
 
-@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu"])
+@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius"])
 def test_against_reference_golden(gpu, which, request):
     meta, a = request.getfixturevalue(which)
     cfg = get_config(meta["cfg"])
