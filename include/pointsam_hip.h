@@ -132,6 +132,14 @@ int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t co
 int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,
                         int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
                         int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
+/* f16x2-packed operands: same [R, K] container of 32-bit words (leading dimension ld), every group of four consecutive k holding
+ * [hi0..hi3 | lo0..lo3] fp16 of the row-scaled values -- the two 8-byte LDS slots the GEMM stages, so a packed operand needs no
+ * split arithmetic in the GEMM.  Static weights are packed once at load; producers (LayerNorm) can emit the form directly.
+ * P == X (in place) is allowed.  psam_gemm_f16x3_ex: a_packed / w_packed say which operand is in that form. */
+int32_t psam_pack_rows_f16x2(const float* X, int64_t ldx, const float* scale, int32_t rows, int32_t K, void* P, int64_t ldp, psam_stream_t stream);
+int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw, const float* scaleW,
+                           int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias,
+                           int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
 void psam_gemm_f16x3_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);

@@ -26,6 +26,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct F16x3Args {
     const float* A; const float* W; float* C;
@@ -76,6 +77,34 @@ PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, i
     PSAM_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, PSAM_EINVAL, "psam_row_scale_f16: bad shape");
     hipLaunchKernelGGL(row_scale_f16_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, scale);
     return psam_launch_status("psam_row_scale_f16: launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------- packed operands
+// "f16x2-packed" rows: the container is still one 32-bit word per element ([R, K] with leading dimension ld), but every group of
+// four consecutive k holds [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (fp16) of the row-scaled values -- exactly the two 8-byte LDS
+// slots the GEMM stages, so a packed operand moves global -> VGPR -> LDS with no arithmetic.  Static weights are packed once;
+// in place (P == X) is allowed.
+__global__ __launch_bounds__(256) void pack_rows_f16x2_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ scale, int rows,
+                                                              int k4, unsigned* __restrict__ P, int64_t ldp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)rows * k4) return;
+    const int r = (int)(t / k4), g = (int)(t % k4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + g * 4);
+    const float s = scale[r];
+    unsigned h0, l0, h1, l1;
+    split2(f32x2{v[0], v[1]}, s, h0, l0);
+    split2(f32x2{v[2], v[3]}, s, h1, l1);
+    *reinterpret_cast<u32x4*>(P + (int64_t)r * ldp + g * 4) = u32x4{h0, h1, l0, l1};
+}
+
+PSAM_API int32_t psam_pack_rows_f16x2(const float* X, int64_t ldx, const float* scale, int32_t rows, int32_t K, void* P, int64_t ldp,
+                                      hipStream_t stream) {
+    PSAM_REQUIRE(X && scale && P, PSAM_EINVAL, "psam_pack_rows_f16x2: null pointer");
+    PSAM_REQUIRE(rows > 0 && K > 0 && (K & 3) == 0 && ldx >= K && ldp >= K, PSAM_EINVAL, "psam_pack_rows_f16x2: bad shape (K % 4 == 0)");
+    PSAM_REQUIRE(((ldx | ldp) & 3) == 0 && (((uintptr_t)X | (uintptr_t)P) & 15) == 0, PSAM_EALIGN, "psam_pack_rows_f16x2: 16-byte alignment");
+    const int64_t total = (int64_t)rows * (K / 4);
+    hipLaunchKernelGGL(pack_rows_f16x2_kernel, dim3((unsigned)psam_cdiv(total, 256)), dim3(256), 0, stream, X, ldx, scale, rows, K / 4, (unsigned*)P, ldp);
+    return psam_launch_status("psam_pack_rows_f16x2: launch failed");
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const F16x3Args p) {
 //              split R[(t+1)&1] -> LDS[(t+1)&1];  R[(t+1)&1] <- global slab t+3 (two slab periods to land)
 //   barrier    (LDS[(t+1)&1] complete; every wave has its F1, so LDS[t&1] may be overwritten next slab)
 //   region B:  F0 <- LDS[(t+1)&1] (step 0 of slab t+1)     | remaining 8 MFMAs of step 1
-template <int DUMMY>
+template <bool APK, bool WPK>   // operand already f16x2-packed (psam_pack_rows_f16x2): staged without arithmetic
 __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p) {
     constexpr int TM = 2, TN = 2, WN = 2;
     constexpr int BM = 128, BN = 128;
@@ -313,24 +342,25 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
         for (int i = 0; i < NF4; ++i) w[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? offW[i] : OOB, k0 * 4, 0));
     };
     const int st_off = lr * HG_ROWB + ((((lc4 >> 1) ^ ((lr >> 2) & 3)) << 4) | ((lc4 & 1) << 3));
+    auto stage4 = [&](unsigned char* st, const f32x4 v, const float sc, const bool packed) {   // one float4 -> its hi and lo 8-byte slots
+        if (packed) {
+            const u32x4 raw = __builtin_bit_cast(u32x4, v);
+            *reinterpret_cast<u32x2*>(st) = u32x2{raw[0], raw[1]};
+            *reinterpret_cast<u32x2*>(st + PLANE) = u32x2{raw[2], raw[3]};
+        } else {
+            unsigned h0, l0, h1, l1;
+            split2(f32x2{v[0], v[1]}, sc, h0, l0);
+            split2(f32x2{v[2], v[3]}, sc, h1, l1);
+            *reinterpret_cast<u32x2*>(st) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(st + PLANE) = u32x2{l0, l1};
+        }
+    };
     auto split_store = [&](int buf, const f32x4 (&a)[NF4], const f32x4 (&w)[NF4]) {
         unsigned char* st = smem + buf * STAGE + st_off;
 #pragma unroll
-        for (int i = 0; i < NF4; ++i) {
-            unsigned h0, l0, h1, l1;
-            split2(f32x2{a[i][0], a[i][1]}, sca[i], h0, l0);
-            split2(f32x2{a[i][2], a[i][3]}, sca[i], h1, l1);
-            *reinterpret_cast<u32x2*>(st + i * 32 * HG_ROWB) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(st + PLANE + i * 32 * HG_ROWB) = u32x2{l0, l1};
-        }
+        for (int i = 0; i < NF4; ++i) stage4(st + i * 32 * HG_ROWB, a[i], sca[i], APK);
 #pragma unroll
-        for (int i = 0; i < NF4; ++i) {
-            unsigned h0, l0, h1, l1;
-            split2(f32x2{w[i][0], w[i][1]}, scw[i], h0, l0);
-            split2(f32x2{w[i][2], w[i][3]}, scw[i], h1, l1);
-            *reinterpret_cast<u32x2*>(st + 2 * PLANE + i * 32 * HG_ROWB) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(st + 3 * PLANE + i * 32 * HG_ROWB) = u32x2{l0, l1};
-        }
+        for (int i = 0; i < NF4; ++i) stage4(st + 2 * PLANE + i * 32 * HG_ROWB, w[i], scw[i], WPK);
     };
     int frag_off[2];
 #pragma unroll
@@ -352,29 +382,68 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
 
     f16x8 af0[TM][2], wf0[TN][2], af1[TM][2], wf1[TN][2];
     const int nslabs = (p.K + HG_BK - 1) / HG_BK;
-    auto slab_body = [&](int t, int buf, f32x4 (&a_next)[NF4], f32x4 (&w_next)[NF4]) {
-        // ---- region A
-        load_frags(buf, 1, af1, wf1);
-        HP_TERM(af0, wf0, 0, 1) HP_TERM(af0, wf0, 1, 0) HP_TERM(af0, wf0, 0, 0)
-        split_store(buf ^ 1, a_next, w_next);                  // slab t+1
-        load_slab((t + 3) * HG_BK, a_next, w_next);            // registers free again: slab t+3
-        HP_TERM(af1, wf1, 0, 1)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // F1 reads first
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    // Hand-interleaved slab body.  The compiler's own order (even with sched_group_barrier requests) clumped the MFMAs
+    // (12 back to back, then ~150 VALU/LDS instructions with the matrix pipe idle); here every slot is ONE MFMA followed by one
+    // chunk of the split work (half a float4: scale, cvt_pk, exact residual, cvt_pk -- ~6 VALU ~ the 32 cycles the MFMA
+    // occupies the pipe) and sched_barrier(0) pins the order.  16 chunks (8 float4 x 2 halves) ride on the first 16 MFMAs.
+    auto mfma = [&](int m, const f16x8 (&af)[TM][2], const f16x8 (&wf)[TN][2]) {   // m in [0, 12): term-major
+        constexpr int PA[3] = {0, 1, 0}, PW[3] = {1, 0, 0};                        // hi*lo, lo*hi, hi*hi
+        const int term = m >> 2, i = (m >> 1) & 1, j = m & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PA[term]], wf[j][PW[term]], acc[i][j], 0, 0, 0);
+    };
+    unsigned ph0, pl0;   // first half of the float4 being split
+    // chunk c in [0, 16): half of float4 q = c>>1 (0..3 = A stripes, 4..7 = W stripes) of slab t+1; the odd chunk also stores the
+    // float4's two 8-byte slots and immediately re-issues the register's global load for slab t+3 (knext): every load gets
+    // ~2 slab periods to land instead of ~1.3 when all eight are issued after the last chunk.
+    auto split_chunk = [&](int c, int buf, int knext, f32x4 (&a)[NF4], f32x4 (&w)[NF4]) {
+        const int q = c >> 1;
+        const bool isw = q >= NF4;
+        const int i = isw ? q - NF4 : q;
+        const f32x4 v = isw ? w[i] : a[i];
+        const float sc = isw ? scw[i] : sca[i];
+        const bool packed = isw ? WPK : APK;
+        if ((c & 1) == 0) {
+            if (!packed) split2(f32x2{v[0], v[1]}, sc, ph0, pl0);
+        } else {
+            unsigned char* st = smem + buf * STAGE + st_off + (isw ? 2 * PLANE : 0) + i * 32 * HG_ROWB;
+            if (packed) {
+                const u32x4 raw = __builtin_bit_cast(u32x4, v);
+                *reinterpret_cast<u32x2*>(st) = u32x2{raw[0], raw[1]};
+                *reinterpret_cast<u32x2*>(st + PLANE) = u32x2{raw[2], raw[3]};
+            } else {
+                unsigned h1, l1;
+                split2(f32x2{v[2], v[3]}, sc, h1, l1);
+                *reinterpret_cast<u32x2*>(st) = u32x2{ph0, h1};
+                *reinterpret_cast<u32x2*>(st + PLANE) = u32x2{pl0, l1};
+            }
+            const bool kok = knext + lc4 * 4 < p.K;
+            if (isw) w[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? offW[i] : OOB, knext * 4, 0));
+            else a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kok ? offA[i] : OOB, knext * 4, 0));
         }
-        __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);
-        __builtin_amdgcn_sched_group_barrier(0x20, 8, 0);
+    };
+    auto slab_body = [&](int t, int buf, f32x4 (&a_next)[NF4], f32x4 (&w_next)[NF4]) {
+        // ---- region A: F1 <- LDS[buf]; 12 MFMAs of step 0 + 4 of step 1, the split of slab t+1 into LDS[buf^1] behind them
+        load_frags(buf, 1, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            mfma(m, af0, wf0);
+            split_chunk(m, buf ^ 1, (t + 3) * HG_BK, a_next, w_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            mfma(m, af1, wf1);
+            split_chunk(12 + m, buf ^ 1, (t + 3) * HG_BK, a_next, w_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
-        // ---- region B
-        load_frags(buf ^ 1, 0, af0, wf0);                      // (after the last slab: the all-zero slab, unused)
-        HP_TERM(af1, wf1, 1, 0) HP_TERM(af1, wf1, 0, 0)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+        // ---- region B: F0 <- LDS[buf^1] (slab t+1, step 0; after the last slab the all-zero slab, unused); last 8 MFMAs
+        load_frags(buf ^ 1, 0, af0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 4; m < 12; ++m) mfma(m, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
     };
     load_slab(0, ra[0], rw[0]);
     load_slab(HG_BK, ra[1], rw[1]);
@@ -400,9 +469,11 @@ static int g_f16x3_cfg = -1;  // tuning hook: 0 = 128x128 (2x2 waves of 64x64), 
 PSAM_API void psam_gemm_f16x3_force_config(int32_t cfg) { g_f16x3_cfg = cfg; }
 
 // C = act(alpha * A @ W^T + bias + rowbias[row/rowgroup]) + residual; scaleA[M], scaleW[N] from psam_row_scale_f16.
-PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,
-                                 int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
-                                 int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, hipStream_t stream) {
+// a_packed / w_packed: that operand is the f16x2-packed form of the row-scaled matrix (psam_pack_rows_f16x2 with the same scales).
+PSAM_API int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw,
+                                    const float* scaleW, int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual,
+                                    int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K,
+                                    float alpha, int32_t act, hipStream_t stream) {
     PSAM_REQUIRE(A && W && C && scaleA && scaleW, PSAM_EINVAL, "psam_gemm_f16x3: null pointer");
     PSAM_REQUIRE(M > 0 && N > 0 && K > 0, PSAM_EINVAL, "psam_gemm_f16x3: bad shape");
     PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_f16x3: bad activation code");
@@ -414,11 +485,12 @@ PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scale
     PSAM_REQUIRE(act != 3 || ((N & 63) == 0 && !residual && !rowbias), PSAM_EINVAL,
                  "psam_gemm_f16x3: SwiGLU epilogue needs N % 64 == 0, no residual/rowbias");
     F16x3Args p;
-    p.A = A; p.W = W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias; p.scaleA = scaleA; p.scaleW = scaleW;
+    p.A = (const float*)A; p.W = (const float*)W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias; p.scaleA = scaleA; p.scaleW = scaleW;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     int cfg = g_f16x3_cfg;
     // measured (scripts/gemm_split_bench.py): the software-pipelined 128x128 kernel wins on every shape of the path
+    if (a_packed || w_packed) cfg = 3;   // packed operands exist only in the pipelined kernel
     if (cfg < 0) cfg = N > 64 ? 3 : 1;
     const int bn = cfg == 1 ? 64 : 128;
     p.tiles_m = (int)psam_cdiv(M, 128);
@@ -426,7 +498,17 @@ PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scale
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
     else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
-    else if (cfg == 3) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<0>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
+    else if (cfg == 3) {
+        if (a_packed && w_packed) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<true, true>), grid, dim3(256), 0, stream, p);
+        else if (a_packed) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<true, false>), grid, dim3(256), 0, stream, p);
+        else if (w_packed) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<false, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    } else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
     return psam_launch_status("psam_gemm_f16x3: launch failed");
+}
+
+PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,
+                                 int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
+                                 int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, hipStream_t stream) {
+    return psam_gemm_f16x3_ex(A, lda, scaleA, 0, W, ldw, scaleW, 0, C, ldc, bias, residual, ldr, rowbias, ldrb, rowgroup, M, N, K, alpha, act, stream);
 }

@@ -215,23 +215,52 @@ def weight_scale_f16(W, K):
     return hit[0]
 
 
+def pack_rows_f16x2(x, scale, K=None, out=None):
+    """f16x2-packed form of the row-scaled x[:, :K] (csrc/gemm_f16x3.hip): same fp32-sized container, [hi x4 | lo x4] per 4 k."""
+    xp, ldx = _row_view(x, "x")
+    rows = x.shape[0]
+    K = x.shape[1] if K is None else K
+    if out is None:
+        out = torch.empty(rows, K, dtype=torch.float32, device=x.device)
+    op, ldo = _row_view(out, "out")
+    check(_lib.load().psam_pack_rows_f16x2(xp, ldx, scale.data_ptr(), rows, K, op, ldo, _stream()), "psam_pack_rows_f16x2")
+    return out
+
+
+_WEIGHT_PACKED = {}
+
+
+def weight_packed_f16(W, K):
+    """(packed weight, row scales) of a static weight, computed once."""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), K, W._version)
+    hit = _WEIGHT_PACKED.get(key)
+    if hit is None:
+        sw = weight_scale_f16(W, K)
+        hit = _WEIGHT_PACKED[key] = (pack_rows_f16x2(W, sw, K), sw, W)
+    return hit[0], hit[1]
+
+
+PACK_WEIGHTS = True   # "f16x3": stage pre-packed weights (no split arithmetic for W in the GEMM); False = split W on the fly
+
+
 def _f16x3_call(fn_args, flops, M, N, K):
     global _gemm_counter
     L = _lib.load()
     _gemm_counter += 1
     if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
-        check(L.psam_gemm_f16x3(*fn_args), "psam_gemm_f16x3")
+        check(L.psam_gemm_f16x3_ex(*fn_args), "psam_gemm_f16x3")
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    check(L.psam_gemm_f16x3(*fn_args), "psam_gemm_f16x3")
+    check(L.psam_gemm_f16x3_ex(*fn_args), "psam_gemm_f16x3")
     e.record()
     GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3"))
 
 
-def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None):
+def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False):
     """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views.
-    x_scale: optional precomputed row_scale_f16(x, K) ("f16x3" mode; computed here otherwise)."""
+    x_scale: optional precomputed row_scale_f16(x, K) ("f16x3" mode; computed here otherwise); x_packed: x is already the
+    f16x2-packed form of the row-scaled activations (x_scale required; "f16x3" mode only)."""
     packed = None
     if isinstance(W, PackedWeight):
         packed, W = W, W.fp32
@@ -251,10 +280,16 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
     if GEMM_MODE == "f16x3" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
         sa = row_scale_f16(x, K) if x_scale is None else x_scale
-        sw = weight_scale_f16(W, K)
-        _f16x3_call((xp, ldx, sa.data_ptr(), wp, ldw, sw.data_ptr(), op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup, M, N, K, 1.0, act, _stream()),
-                    2.0 * M * N * K, M, N, K)
+        if PACK_WEIGHTS:
+            wpk, sw = weight_packed_f16(W, K)
+            wp, ldw, wflag = wpk.data_ptr(), wpk.stride(0), 1
+        else:
+            sw, wflag = weight_scale_f16(W, K), 0
+        _f16x3_call((xp, ldx, sa.data_ptr(), 1 if x_packed else 0, wp, ldw, sw.data_ptr(), wflag, op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup,
+                     M, N, K, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K)
         return out
+    if x_packed:
+        raise ValueError("x_packed activations can only feed an f16x3 GEMM (M, N, K above the split thresholds)")
     if packed is not None and GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
         _packed_gemm_call((xp, ldx, packed.data.data_ptr(), op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup, M, N, K, 1.0, act, _stream()),
                           2.0 * M * N * K, M, N, K)

@@ -1,6 +1,6 @@
 import ctypes, os, torch
 here=os.path.dirname(os.path.abspath(__file__))
-names={0:"full",1:"no MFMA",2:"cheap split",3:"no gload in loop",4:"no split/ds_write",5:"no barrier",6:"mfma+ds_read only",7:"gloads+barrier only",8:"gloads only"}
+names={0:"full",1:"no MFMA",2:"cheap split",3:"no gload in loop",4:"no ds_write",5:"no barrier",6:"mfma+dsread+split only",7:"loads+split+barrier (no mfma, no dswrite)",8:"loads+split only"}
 st=torch.cuda.current_stream().cuda_stream
 libs={}
 for n in names:

@@ -68,16 +68,7 @@ __global__ __launch_bounds__(256) void row_scale_f16_kernel(const float* __restr
         for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[c]));
     }
     m = wave_max(m);
-    if (lane == 0) {
-        const unsigned bits = __builtin_bit_cast(unsigned, m);
-        int e = (int)((bits >> 23) & 0xff) - 127;
-        float s = 1.f;
-        if (bits != 0 && e != 128) {           // finite, non-zero (subnormal maxima clamp to e = -100)
-            e = e < -100 ? -100 : (e > 100 ? 100 : e);
-            s = __builtin_bit_cast(float, (unsigned)(127 + 14 - e) << 23);
-        }
-        scale[row] = s;
-    }
+    if (lane == 0) scale[row] = f16_row_scale(m);
 }
 
 PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* scale, hipStream_t stream) {
@@ -368,29 +359,61 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p,
 
     f16x8 af0[TM][2], wf0[TN][2], af1[TM][2], wf1[TN][2];
     const int nslabs = (p.K + HG_BK - 1) / HG_BK;
-    auto slab_body = [&](int t, int buf, f32x4 (&a_next)[NF4], f32x4 (&w_next)[NF4]) {
-        // ---- region A
-        load_frags(buf, 1, af1, wf1);
-        HP_TERM(af0, wf0, 0, 1) HP_TERM(af0, wf0, 1, 0) HP_TERM(af0, wf0, 0, 0)
-        split_store(buf ^ 1, a_next, w_next);                  // slab t+1
-        load_slab((t + 3) * HG_BK, a_next, w_next);            // registers free again: slab t+3
-        HP_TERM(af1, wf1, 0, 1)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // F1 reads first
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    // Hand-interleaved slab body.  The compiler's own order (even with sched_group_barrier requests) clumped the MFMAs
+    // (12 back to back, then ~150 VALU/LDS instructions with the matrix pipe idle); here every slot is ONE MFMA followed by one
+    // chunk of the split work (half a float4: scale, cvt_pk, exact residual, cvt_pk -- ~6 VALU ~ the 32 cycles the MFMA
+    // occupies the pipe) and sched_barrier(0) pins the order.  16 chunks (8 float4 x 2 halves) ride on the first 16 MFMAs.
+    auto mfma = [&](int m, const f16x8 (&af)[TM][2], const f16x8 (&wf)[TN][2]) {   // m in [0, 12): term-major
+        constexpr int PA[3] = {0, 1, 0}, PW[3] = {1, 0, 0};                        // hi*lo, lo*hi, hi*hi
+        const int term = m >> 2, i = (m >> 1) & 1, j = m & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PA[term]], wf[j][PW[term]], acc[i][j], 0, 0, 0);
+    };
+    unsigned ph0, pl0;   // first half of the float4 being split
+    // chunk c in [0, 16): half of float4 q = c>>1 (0..3 = A stripes, 4..7 = W stripes) of slab t+1; the odd chunk also stores the
+    // float4's two 8-byte slots and immediately re-issues the register's global load for slab t+3 (knext): every load gets
+    // ~2 slab periods to land instead of ~1.3 when all eight are issued after the last chunk.
+    auto split_chunk = [&](int c, int buf, int knext, f32x4 (&a)[NF4], f32x4 (&w)[NF4]) {
+        const int q = c >> 1;
+        const bool isw = q >= NF4;
+        const int i = isw ? q - NF4 : q;
+        const f32x4 v = isw ? w[i] : a[i];
+        const float sc = isw ? scw[i] : sca[i];
+        if ((c & 1) == 0) {
+            split2(f32x2{v[0], v[1]}, sc, ph0, pl0);
+        } else {
+            unsigned h1, l1;
+            split2(f32x2{v[2], v[3]}, sc, h1, l1);
+            unsigned char* st = smem + buf * STAGE + st_off + (isw ? 2 * PLANE : 0) + i * 32 * HG_ROWB;
+            *reinterpret_cast<u32x2*>(st) = u32x2{ph0, h1};
+            *reinterpret_cast<u32x2*>(st + PLANE) = u32x2{pl0, l1};
+            const bool kok = knext + lc4 * 4 < p.K;
+            if (isw) w[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? offW[i] : OOB, knext * 4, 0));
+            else a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kok ? offA[i] : OOB, knext * 4, 0));
         }
-        __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);
-        __builtin_amdgcn_sched_group_barrier(0x20, 8, 0);
+    };
+    auto slab_body = [&](int t, int buf, f32x4 (&a_next)[NF4], f32x4 (&w_next)[NF4]) {
+        // ---- region A: F1 <- LDS[buf]; 12 MFMAs of step 0 + 4 of step 1, the split of slab t+1 into LDS[buf^1] behind them
+        load_frags(buf, 1, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            mfma(m, af0, wf0);
+            split_chunk(m, buf ^ 1, (t + 3) * HG_BK, a_next, w_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            mfma(m, af1, wf1);
+            split_chunk(12 + m, buf ^ 1, (t + 3) * HG_BK, a_next, w_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
-        // ---- region B
-        load_frags(buf ^ 1, 0, af0, wf0);                      // (after the last slab: the all-zero slab, unused)
-        HP_TERM(af1, wf1, 1, 0) HP_TERM(af1, wf1, 0, 0)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+        // ---- region B: F0 <- LDS[buf^1] (slab t+1, step 0; after the last slab the all-zero slab, unused); last 8 MFMAs
+        load_frags(buf ^ 1, 0, af0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 4; m < 12; ++m) mfma(m, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
     };
     load_slab(0, ra[0], rw[0]);
     load_slab(HG_BK, ra[1], rw[1]);
@@ -441,7 +464,8 @@ PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scale
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     int cfg = g_f16x3_cfg;
-    if (cfg < 0) cfg = (psam_cdiv(M, 128) * psam_cdiv(N, 128) >= 512 && K > 256) ? 0 : 1;
+    // measured (scripts/gemm_split_bench.py): the software-pipelined 128x128 kernel wins on every shape of the path
+    if (cfg < 0) cfg = N > 64 ? 3 : 1;
     const int bn = cfg == 1 ? 64 : 128;
     p.tiles_m = (int)psam_cdiv(M, 128);
     p.tiles_n = (int)psam_cdiv(N, bn);

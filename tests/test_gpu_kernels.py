@@ -244,6 +244,37 @@ def test_layernorm_emits_f16x3_row_scale(ops, cols):
         assert torch.equal(y, ops.layernorm(x, w, b, 1e-5, act=act))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (520, 640, 2752)])
+def test_gemm_f16x3_packed_operands(ops, M, N, K):
+    """Pre-packed (hi|lo fp16) operands give bit-identical results to splitting on the fly, for every packed/unpacked pairing."""
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    L = ops._lib.load()
+    sa, sw = ops.row_scale_f16(x), ops.row_scale_f16(W)
+    xp, wp = ops.pack_rows_f16x2(x, sa), ops.pack_rows_f16x2(W, sw)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for ap in (0, 1):
+        for wpk in (0, 1):
+            y = torch.empty(M, N, device="cuda")
+            rc = L.psam_gemm_f16x3_ex((xp if ap else x).data_ptr(), K, sa.data_ptr(), ap, (wp if wpk else W).data_ptr(), K, sw.data_ptr(), wpk, y.data_ptr(), N,
+                                      b.data_ptr(), res.data_ptr(), N, 0, 0, 0, M, N, K, 1.0, 1, st)
+            assert rc == 0, L.psam_last_error_string()
+            outs[(ap, wpk)] = y
+    L.psam_gemm_f16x3_force_config(3)
+    try:
+        with ops.gemm_mode("f16x3"):
+            ref = ops.linear(x, W, b, act=ops.ACT_GELU, residual=res)
+    finally:
+        L.psam_gemm_f16x3_force_config(-1)
+    for k, y in outs.items():
+        assert torch.equal(y, ref), k
+    xin = x.clone()
+    assert torch.equal(ops.pack_rows_f16x2(xin, sa, out=xin), xp)          # in place
+
+
 def test_gemm_f16x3_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
