@@ -151,6 +151,9 @@ void psam_gemm_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64, 2
 int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                        int64_t rows, int32_t cols, float eps, int32_t act, psam_stream_t stream);
 /* Same, plus row_scale[rows] (optional): the power-of-two f16x3 scale of every OUTPUT row (psam_row_scale_f16 fused in). */
+/* psam_layernorm_ex: pack != 0 writes y as the f16x2-packed form of the row-scaled output (needs row_scale; 256 <= cols <= 4096). */
+int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
+                          int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack, psam_stream_t stream);
 int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                           int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, psam_stream_t stream);
 

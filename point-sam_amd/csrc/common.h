@@ -51,6 +51,18 @@ __device__ __forceinline__ float f16_row_scale(float amax) {
     return __builtin_bit_cast(float, (unsigned)(127 + 14 - e) << 23);
 }
 
+// (x0, x1) * s (s = power-of-two row scale) -> packed fp16 pairs hi = RNE(s*x), lo = RNE(s*x - hi): the f16x3 operand split
+// (gemm_f16x3.hip); the residual is exact (one FMA).
+typedef float psam_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 psam_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void psam_split2_f16(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+    const psam_f32x2 xs = psam_f32x2{x0, x1} * s;
+    const psam_f16x2 h = __builtin_convertvector(xs, psam_f16x2);
+    const psam_f32x2 r = xs - __builtin_convertvector(h, psam_f32x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, psam_f16x2));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

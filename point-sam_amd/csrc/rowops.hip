@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NV4>
 __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
                                                            const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
-                                                           int64_t ldy, int64_t rows, int cols, float eps, int act, float* __restrict__ rscale) {
+                                                           int64_t ldy, int64_t rows, int cols, float eps, int act, float* __restrict__ rscale, int pack) {
     const int lane = threadIdx.x & 63;
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
@@ -132,6 +132,41 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
     }
     const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
     const int cfull = cols >> 2;    // float4 groups entirely inside the row (cols >= 256 on this path, so cfull >= 64)
+    if (pack) {
+        // f16x2-packed output for the f16x3 GEMM (gemm_f16x3.hip): the outputs stay in registers until the row maximum (hence
+        // the row scale) is known, then every float4 group is written as [hi x4 | lo x4]; columns >= cols of the last group are 0.
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = i * 64 + lane;
+            const int cl = c < cfull ? c : cfull - 1;
+            f32x4 w4 = *reinterpret_cast<const f32x4*>(w + cl * 4), b4 = *reinterpret_cast<const f32x4*>(b + cl * 4);
+            if (c == cfull && c * 4 < cols) {          // partial last group: element-wise weights
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int ce = c * 4 + e < cols ? c * 4 + e : cols - 1; w4[e] = w[ce]; b4[e] = b[ce]; }
+            }
+            f32x4 o = (v[i] - mean) * r * w4 + b4;
+            if (act == 1) { o[0] = gelu_erf(o[0]); o[1] = gelu_erf(o[1]); o[2] = gelu_erf(o[2]); o[3] = gelu_erf(o[3]); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c * 4 + e >= cols) o[e] = 0.f;
+            v[i] = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        }
+        amax = wave_max(amax);
+        const float sc = f16_row_scale(amax);
+        if (lane == 0) rscale[row] = sc;
+        typedef unsigned ln_u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = i * 64 + lane;
+            if (c * 4 < cols) {
+                unsigned h0, l0, h1, l1;
+                psam_split2_f16(v[i][0], v[i][1], sc, h0, l0);
+                psam_split2_f16(v[i][2], v[i][3], sc, h1, l1);
+                *reinterpret_cast<ln_u32x4*>(yrow + c * 4) = ln_u32x4{h0, h1, l0, l1};
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = i * 64 + lane;
@@ -158,8 +193,11 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
 }
 
 // row_scale (optional, [rows]): the f16x3 GEMM's power-of-two row scale of the OUTPUT rows (psam_row_scale_f16 fused in).
-PSAM_API int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
-                                   int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, hipStream_t stream) {
+// pack != 0: y receives the f16x2-packed form of the row-scaled output (psam_pack_rows_f16x2 fused in; needs row_scale and the
+// float4 path: 256 <= cols <= 4096, 16-byte aligned rows) -- the A operand of psam_gemm_f16x3_ex with a_packed = 1.
+PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                   int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack,
+                                   hipStream_t stream) {
     PSAM_REQUIRE(x && w && b && y, PSAM_EINVAL, "psam_layernorm: null pointer");
     PSAM_REQUIRE(rows > 0 && cols > 0, PSAM_EINVAL, "psam_layernorm: bad shape");
     PSAM_REQUIRE(act == 0 || act == 1, PSAM_EINVAL, "psam_layernorm: act must be 0 or 1 (GELU)");
@@ -167,8 +205,9 @@ PSAM_API int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res
     const int64_t c4 = ((int64_t)cols + 3) & ~(int64_t)3;
     const bool vec = cols >= 256 && cols <= 4096 && ((ldx | ldy | (res ? ldr : 0)) & 3) == 0 && ldx >= c4 && ldy >= c4 && (!res || ldr >= c4) &&
                      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)w | (uintptr_t)b) & 15) == 0;
+    PSAM_REQUIRE(!pack || (vec && row_scale), PSAM_EINVAL, "psam_layernorm: packed output needs row_scale and the float4 path (256 <= cols <= 4096, aligned)");
     if (vec) {
-#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale)
+#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale, pack)
         if (cols <= 256) LNV_LAUNCH(1);
         else if (cols <= 512) LNV_LAUNCH(2);
         else if (cols <= 1024) LNV_LAUNCH(4);
@@ -190,7 +229,12 @@ PSAM_API int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res
 
 PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
                                 int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, hipStream_t stream) {
-    return psam_layernorm_rs(x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, nullptr, stream);
+    return psam_layernorm_ex(x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, nullptr, 0, stream);
+}
+
+PSAM_API int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                   int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, hipStream_t stream) {
+    return psam_layernorm_ex(x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

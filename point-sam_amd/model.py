@@ -146,23 +146,28 @@ class PointCloudSAM:
         vit = self.cfg.vit
         D, H, hd = vit.dim, vit.heads, vit.head_dim
         p = blk.p
-        # "f16x3" GEMMs need a power-of-two scale per operand row: the LayerNorms that feed them emit it for free
-        rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if self.precision == "f16x3" else None
-        h = self._ln(p + ".norm1", x, vit.ln_eps, scale_out=rs)
-        qkv = ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs)
+        # "f16x3" GEMMs need a power-of-two scale per operand row and stage hi/lo fp16 planes: the LayerNorms that feed them emit
+        # the scale and (when the float4 LN path applies) the packed planes directly, so the GEMM does no split arithmetic for A
+        f16 = self.precision == "f16x3"
+        rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if f16 else None
+        big = x.shape[0] >= ops.SPLIT_MIN_M and D >= ops.SPLIT_MIN_N
+        pk = f16 and big and ops.layernorm_can_pack(D)
+        h = self._ln(p + ".norm1", x, vit.ln_eps, scale_out=rs, pack=pk)
+        qkv = ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs, x_packed=pk)
         o = torch.empty_like(x)
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5)
         self._lin(p + ".attn.proj", o, residual=x, out=x)
-        self._ln(p + ".norm2", x, vit.ln_eps, out=h, scale_out=rs)
+        self._ln(p + ".norm2", x, vit.ln_eps, out=h, scale_out=rs, pack=pk)
         if vit.swiglu:
             # fc1 with the SiLU gate fused in the GEMM epilogue -> u [M, Hp] (pad columns exactly 0), inner LayerNorm over
             # the first H columns in place, then fc2 over K = Hp (zero-padded weight columns)
-            u = ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs)
+            u = ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=pk)
             Hh = vit.mlp_hidden
-            ops.layernorm(u[:, :Hh], self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, out=u[:, :Hh], scale_out=rs)
-            ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=rs)
+            pk2 = f16 and big and ops.layernorm_can_pack(Hh)
+            ops.layernorm(u[:, :Hh], self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, out=u[:, :Hh], scale_out=rs, pack=pk2)
+            ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=rs, x_packed=pk2)
         else:
-            g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs)
+            g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=pk)
             ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
         return x
 

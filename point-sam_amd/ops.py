@@ -306,17 +306,22 @@ def gemm_batched(A, W, out, M, N, K, lda, ldw, ldc, sA, sW, sC, batch, alpha=1.0
     return out
 
 
-def layernorm(x, w, b, eps, act=ACT_NONE, residual=None, out=None, scale_out=None):
+def layernorm_can_pack(cols: int) -> bool:
+    return 256 <= cols <= 4096
+
+
+def layernorm(x, w, b, eps, act=ACT_NONE, residual=None, out=None, scale_out=None, pack=False):
     """y = act(LN(x + residual)) over the last dim of a 2-D row view.  scale_out ([rows] fp32, optional) receives the f16x3
-    row scales of y (what row_scale_f16(y) would compute), for the GEMM that consumes y."""
+    row scales of y (what row_scale_f16(y) would compute), for the GEMM that consumes y.  pack=True: out receives the f16x2-packed
+    form of the scaled rows instead of fp32 (linear(..., x_scale=scale_out, x_packed=True))."""
     xp, ldx = _row_view(x, "x")
     rows, cols = x.shape
     if out is None:
         out = torch.empty(rows, cols, dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
-    check(_lib.load().psam_layernorm_rs(xp, ldx, rp, ldr, w.data_ptr(), b.data_ptr(), op, ldo, rows, cols, eps, act, _p(scale_out), _stream()),
-          "psam_layernorm")
+    check(_lib.load().psam_layernorm_ex(xp, ldx, rp, ldr, w.data_ptr(), b.data_ptr(), op, ldo, rows, cols, eps, act, _p(scale_out), 1 if pack else 0,
+                                        _stream()), "psam_layernorm")
     return out
 
 

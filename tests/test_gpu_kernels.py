@@ -275,6 +275,34 @@ def test_gemm_f16x3_packed_operands(ops, M, N, K):
     assert torch.equal(ops.pack_rows_f16x2(xin, sa, out=xin), xp)          # in place
 
 
+@pytest.mark.parametrize("cols,ld", [(1024, 1024), (2730, 2752), (300, 304), (4096, 4096)])
+def test_layernorm_packed_output(ops, cols, ld):
+    """LayerNorm with pack=True == LayerNorm followed by row_scale_f16 + pack_rows_f16x2 (bit for bit), also in place on a padded
+    buffer (the SwiGLU output of the EVA02 blocks: 2730 of 2752 columns, pad columns zero)."""
+    g = torch.Generator().manual_seed(cols)
+    buf = torch.zeros(300, ld)
+    buf[:, :cols] = torch.randn(300, cols, generator=g) * torch.exp(torch.randn(300, 1, generator=g))
+    w, b = torch.randn(cols, generator=g).cuda(), torch.randn(cols, generator=g).cuda()
+    x = buf.cuda()
+    y = ops.layernorm(x[:, :cols], w, b, 1e-6, out=torch.zeros_like(x)[:, :cols])
+    ybuf = torch.zeros_like(x); ybuf[:, :cols] = y
+    sa = ops.row_scale_f16(ybuf)
+    want = ops.pack_rows_f16x2(ybuf, sa)
+    rs = torch.empty(300, device="cuda")
+    xin = x.clone()
+    ops.layernorm(xin[:, :cols], w, b, 1e-6, out=xin[:, :cols], scale_out=rs, pack=True)      # in place, padded
+    assert torch.equal(rs, sa)
+    if cols % 4 == 0:
+        assert torch.equal(xin.view(torch.int32), want.view(torch.int32))
+    else:   # the ragged last group is evaluated element-wise in the unpacked kernel (FMA contraction may differ by an ulp)
+        full = (cols // 4) * 4
+        assert torch.equal(xin[:, :full].view(torch.int32), want[:, :full].view(torch.int32))
+        assert torch.equal(xin[:, full + 4:].view(torch.int32), want[:, full + 4:].view(torch.int32))
+        h = xin[:, full:full + 4].contiguous().view(torch.float16).float()          # [rows, 8]: hi x4 | lo x4
+        dec = (h[:, :4] + h[:, 4:]) / rs[:, None]
+        assert torch.allclose(dec[:, : cols - full], y[:, full:], rtol=2e-6, atol=1e-7) and (dec[:, cols - full:] == 0).all()
+
+
 def test_gemm_f16x3_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
