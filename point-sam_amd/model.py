@@ -122,6 +122,14 @@ class PointCloudSAM:
     def _ln(self, name, x, eps, **kw):
         return ops.layernorm(x, self.w[name + ".weight"], self.w[name + ".bias"], eps, **kw)
 
+    def _ln_feeds_gemm(self, x, consumer):
+        """(pack, row-scale buffer) for a LayerNorm whose only consumer is a large "f16x3" GEMM over all of its columns: the LN
+        kernel then emits the GEMM's row scales and, on its float4 path, the packed hi|lo operand itself."""
+        if (self.precision != "f16x3" or x.shape[0] < ops.SPLIT_MIN_M or x.shape[1] < ops.SPLIT_MIN_K
+                or self.w[consumer + ".weight"].shape[0] < ops.SPLIT_MIN_N):
+            return False, None
+        return ops.layernorm_can_pack(x.shape[1]), torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+
     def _patch_encoder(self, prefix, coords, feats, centers, knn_idx):
         """PatchEncoder.forward on gathered groups (common.py:499-506) -> [B*rep*G, Cout]."""
         w, eps = self.w, self.cfg.ln_eps
@@ -137,8 +145,9 @@ class PointCloudSAM:
         g1 = ops.linear(y1, w2a[:, :h0], w[prefix + ".conv2.0.bias"])
         h3 = ops.linear(h2, w2a[:, h0:], None, rowbias=g1, rowgroup=K)
         del h2
-        self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3)
-        h4 = self._lin(prefix + ".conv2.3", h3)
+        pk, rs = self._ln_feeds_gemm(h3, prefix + ".conv2.3")
+        self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3, scale_out=rs, pack=pk)
+        h4 = self._lin(prefix + ".conv2.3", h3, x_scale=rs, x_packed=pk)
         del h3
         return ops.group_max(h4, K)
 
@@ -307,8 +316,9 @@ class PointCloudSAM:
         up = torch.empty(Z * N, E, device=self.device)
         ops.interp3(keys.view(Z, G, E), st.interp_index, st.interp_weight, up, rep)
         u1 = self._lin("mask_decoder.output_upscaling.0", up)
-        self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1)
-        self._lin("mask_decoder.output_upscaling.3", u1, act=ACT_GELU, out=up)
+        pk, rs = self._ln_feeds_gemm(u1, "mask_decoder.output_upscaling.3")
+        self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1, scale_out=rs, pack=pk)
+        self._lin("mask_decoder.output_upscaling.3", u1, act=ACT_GELU, out=up, x_scale=rs, x_packed=pk)
         sel = list(range(1, nmt)) if multimask_output else [0]
         C = len(sel)
         hyper = torch.empty(Z, C, E, device=self.device)
