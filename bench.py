@@ -113,6 +113,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
+    t_enqueued = time.perf_counter() - t0      # host time to issue every launch of the timed region (no sync inside)
     fence()
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
@@ -136,7 +137,7 @@ def main():
                 peak, kernel, note = F32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "f32-input MFMA dense peak"
             elif kind == "f16x3":
                 peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-                kernel = "gemm_f16x3_kernel (v_mfma_f32_32x32x16_f16, row-scaled 2-way fp16 split, 3 partial products per fp32-grade product)"
+                kernel = "gemm_f16x3_pipe_kernel (v_mfma_f32_32x32x16_f16, row-scaled 2-way fp16 split, 3 partial products per fp32-grade product)"
                 note = ("fp32-equivalent peak of the scheme = fp16 dense MFMA peak 2500 TFLOP/s / 3 executed products; "
                         f"executed matrix-pipe rate = {ach * 3:.0f} TFLOP/s = {ach * 3 / BF16_MFMA_PEAK_TFLOPS:.3f} of the fp16 peak")
             else:
@@ -145,10 +146,10 @@ def main():
                 note = ("fp32-equivalent peak of the scheme = bf16 dense MFMA peak 2500 TFLOP/s / 6 executed products; "
                         f"executed matrix-pipe rate = {ach * 6:.0f} TFLOP/s = {ach * 6 / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak")
             traffic = None
-            tfile = "r01_v8_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
+            tfile = "r01_v9_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
             try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
                 tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
-                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<0>"}.get(kind)
+                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<true, true>"}.get(kind)
                 if key and key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
             except (OSError, ValueError, KeyError):
@@ -168,7 +169,8 @@ def main():
                       "f16x3": "f32 (fp32 in/out/accumulate; large GEMMs as row-scaled 2-way fp16 split x 3 MFMA products, fp32-grade error)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"ViT-{args.config} N={N} g={args.groups}x{args.group_size} batch={B}/GPU 1 point prompt multimask",
-                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None, "gemm_precision": args.precision, "weights": "seeded random init (no checkpoint offline)"},
+                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None,
+                       "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3), "gemm_precision": args.precision, "weights": "seeded random init (no checkpoint offline)"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -13,9 +13,10 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU = 0, 1, 2, 3
 
 # Measurement hook (bench.py): when GEMM_PROFILE is a list, every GEMM_PROFILE_EVERY-th GEMM launch is bracketed by two
 # HIP events on the launch stream and (start, end, flops, M, N, K) is appended.  Sampling keeps the perturbation of the
-# timed region small (an event pair costs ~20 us of host+queue time; 260 pairs per step were a 17 % slowdown).
+# timed region small (an event pair costs ~20 us of host time and the host issues ~400 launches per 14 ms step: bracketing every
+# launch cost 17 %, every 7th still 7 %; every 29th is below the run-to-run noise).
 GEMM_PROFILE = None
-GEMM_PROFILE_EVERY = 7
+GEMM_PROFILE_EVERY = 29
 _gemm_counter = 0
 
 
