@@ -140,6 +140,14 @@ int32_t psam_pack_rows_f16x2(const float* X, int64_t ldx, const float* scale, in
 int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw, const float* scaleW,
                            int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias,
                            int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
+/* Same with a split-K workspace: tiles of an under-filled launch are computed by two workgroups over half of K each, the partner's
+ * accumulators handed to the owner through `ws` and added in a fixed order (bit-reproducible).  ws: psam_gemm_f16x3_workspace_bytes()
+ * bytes, zeroed ONCE; epoch: non-zero and unique per call on that workspace; one workspace per concurrently used stream. */
+size_t psam_gemm_f16x3_workspace_bytes(void);
+int32_t psam_gemm_f16x3_ws(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw, const float* scaleW,
+                           int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias,
+                           int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, void* ws, size_t ws_bytes,
+                           uint32_t epoch, psam_stream_t stream);
 void psam_gemm_f16x3_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);

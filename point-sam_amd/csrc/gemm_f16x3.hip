@@ -36,6 +36,8 @@ struct F16x3Args {
     int M, N, K, rowgroup, act;
     float alpha;
     int tiles_m, tiles_n;
+    // split-K over two workgroups for the tiles >= split_from (pipelined kernel): partner partials through `ws`, see the kernel
+    int split_from; unsigned epoch; float* ws; unsigned* flags;
 };
 
 constexpr int HG_BK = 32;
@@ -300,8 +302,20 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
     constexpr int STAGE = 4 * PLANE;                           // A hi, A lo, W hi, W lo
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
+    // Workgroup -> (tile, K half).  Tiles below split_from are computed whole (half = -1).  A tile >= split_from is computed by TWO
+    // workgroups, each over half of the k slabs: with fewer than 2 tiles per CU that doubles the resident workgroups (latency
+    // hiding) and with a last round at most half full it halves that round.  The partner (half 1) parks its accumulators in `ws`
+    // and raises the tile's flag to this launch's epoch; the owner (half 0) adds them to its own in a FIXED order (own + partner:
+    // bit-reproducible, unlike atomics on C) and runs the epilogue.  Partners are 8 workgroup ids apart: the same XCD under the
+    // round-robin dispatch, so the partial normally never leaves that XCD's L2; the fences are agent-scope regardless.
     const int ntiles = p.tiles_m * p.tiles_n;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x, half = -1;
+    if (tile >= p.split_from) {
+        const int sidx = tile - p.split_from;                  // 16 q + 8 half + x  ->  split tile 8 q + x
+        half = (sidx >> 3) & 1;
+        tile = p.split_from + ((sidx >> 4) << 3) + (sidx & 7);
+    }
+    const int split_idx = tile - p.split_from;
     if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
 
@@ -381,7 +395,10 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][PA], WF[j][PW], acc[i][j], 0, 0, 0);
 
     f16x8 af0[TM][2], wf0[TN][2], af1[TM][2], wf1[TN][2];
-    const int nslabs = (p.K + HG_BK - 1) / HG_BK;
+    const int nslabs_all = (p.K + HG_BK - 1) / HG_BK;
+    const int kbeg = half == 1 ? (nslabs_all + 1) / 2 : 0;                       // first slab of this workgroup's range
+    const int nslabs = half < 0 ? nslabs_all : (half == 0 ? (nslabs_all + 1) / 2 : nslabs_all - kbeg);
+    // (the pipeline stages up to three slabs past the end of its range: never multiplied, and inside the descriptor bounds or zero)
     // Hand-interleaved slab body.  The compiler's own order (even with sched_group_barrier requests) clumped the MFMAs
     // (12 back to back, then ~150 VALU/LDS instructions with the matrix pipe idle); here every slot is ONE MFMA followed by one
     // chunk of the split work (half a float4: scale, cvt_pk, exact residual, cvt_pk -- ~6 VALU ~ the 32 cycles the MFMA
@@ -428,13 +445,13 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
             mfma(m, af0, wf0);
-            split_chunk(m, buf ^ 1, (t + 3) * HG_BK, a_next, w_next);
+            split_chunk(m, buf ^ 1, (kbeg + t + 3) * HG_BK, a_next, w_next);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             mfma(m, af1, wf1);
-            split_chunk(12 + m, buf ^ 1, (t + 3) * HG_BK, a_next, w_next);
+            split_chunk(12 + m, buf ^ 1, (kbeg + t + 3) * HG_BK, a_next, w_next);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -445,10 +462,10 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
         for (int m = 4; m < 12; ++m) mfma(m, af1, wf1);
         __builtin_amdgcn_sched_barrier(0);
     };
-    load_slab(0, ra[0], rw[0]);
-    load_slab(HG_BK, ra[1], rw[1]);
+    load_slab(kbeg * HG_BK, ra[0], rw[0]);
+    load_slab((kbeg + 1) * HG_BK, ra[1], rw[1]);
     split_store(0, ra[0], rw[0]);
-    load_slab(2 * HG_BK, ra[0], rw[0]);
+    load_slab((kbeg + 2) * HG_BK, ra[0], rw[0]);
     __syncthreads();
     load_frags(0, 0, af0, wf0);
     int t = 0;
@@ -459,6 +476,35 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
     if (t < nslabs) slab_body(t, 0, ra[1], rw[1]);
 #undef HP_TERM
 
+    if (half >= 0) {   // split-K hand-over: [split tile][wave][tile i][tile j][reg][lane] floats, 256-byte rows per wave instruction
+        // Every access to the partial and the flag is an AGENT-scope relaxed atomic (sc1: written through / read at the device
+        // coherence point), ordered by plain waitcnt + barrier -- coherent across XCDs without the bulk L2 write-back / invalidate
+        // of an agent-scope release/acquire FENCE (measured: with fences the split launches were 2x slower than unsplit ones).
+        float* part = p.ws + ((size_t)split_idx * 4 + wave) * (TM * TN * 16 * 64) + lane;
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __hip_atomic_store(part + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = wait for this wave's stores to be acknowledged
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.flags + split_idx, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0)
+            while (__hip_atomic_load(p.flags + split_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] += __hip_atomic_load(part + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();   // every wave is done reading operand fragments
     gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
                                   n0 + wn * TN * 32, lane, p.C, p.residual);
@@ -470,10 +516,25 @@ PSAM_API void psam_gemm_f16x3_force_config(int32_t cfg) { g_f16x3_cfg = cfg; }
 
 // C = act(alpha * A @ W^T + bias + rowbias[row/rowgroup]) + residual; scaleA[M], scaleW[N] from psam_row_scale_f16.
 // a_packed / w_packed: that operand is the f16x2-packed form of the row-scaled matrix (psam_pack_rows_f16x2 with the same scales).
-PSAM_API int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw,
+static int f16x3_slots() {   // resident 64-KiB-LDS workgroups on the device: 2 per CU
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+    }
+    return slots;
+}
+constexpr size_t F16X3_FLAG_BYTES = 16384, F16X3_PART_BYTES = 4 * 4 * 16 * 64 * sizeof(float);   // per split tile: 4 waves x 4 acc tiles
+
+// Workspace for the split-K hand-over of psam_gemm_f16x3_ws: zero it ONCE (flags), then pass it with a launch-unique, non-zero,
+// never-repeating `epoch` to every call that uses it; one workspace per stream that runs such GEMMs concurrently.
+PSAM_API size_t psam_gemm_f16x3_workspace_bytes(void) { return F16X3_FLAG_BYTES + (size_t)(f16x3_slots() / 2) * F16X3_PART_BYTES; }
+
+PSAM_API int32_t psam_gemm_f16x3_ws(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw,
                                     const float* scaleW, int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual,
                                     int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K,
-                                    float alpha, int32_t act, hipStream_t stream) {
+                                    float alpha, int32_t act, void* ws, size_t ws_bytes, uint32_t epoch, hipStream_t stream) {
     PSAM_REQUIRE(A && W && C && scaleA && scaleW, PSAM_EINVAL, "psam_gemm_f16x3: null pointer");
     PSAM_REQUIRE(M > 0 && N > 0 && K > 0, PSAM_EINVAL, "psam_gemm_f16x3: bad shape");
     PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_f16x3: bad activation code");
@@ -495,7 +556,20 @@ PSAM_API int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* sca
     const int bn = cfg == 1 ? 64 : 128;
     p.tiles_m = (int)psam_cdiv(M, 128);
     p.tiles_n = (int)psam_cdiv(N, bn);
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    const int ntiles = p.tiles_m * p.tiles_n;
+    // split-K policy (pipelined kernel, workspace given): all tiles when there are fewer than two per slot-pair (N = 1024 GEMMs at
+    // M = 4096: 256 tiles on 512 slots), else the tiles of a last round that is at most half full (qkv: 768 = 512 + 256)
+    int nsplit = 0;
+    if (cfg == 3 && ws && K >= 16 * HG_BK) {
+        const int slots = f16x3_slots(), rem = ntiles % slots;
+        if (2 * ntiles <= slots) nsplit = ntiles;
+        else if (rem > 0 && 2 * rem <= slots) nsplit = rem;
+        nsplit &= ~7;
+        PSAM_REQUIRE(nsplit == 0 || (epoch != 0 && ws_bytes >= F16X3_FLAG_BYTES + (size_t)nsplit * F16X3_PART_BYTES && (size_t)nsplit * 4 <= F16X3_FLAG_BYTES),
+                     PSAM_EINVAL, "psam_gemm_f16x3_ws: workspace too small (psam_gemm_f16x3_workspace_bytes) or epoch == 0");
+    }
+    p.split_from = ntiles - nsplit; p.epoch = epoch; p.flags = (unsigned*)ws; p.ws = (float*)((char*)ws + F16X3_FLAG_BYTES);
+    const dim3 grid((unsigned)(cfg == 3 ? ntiles + nsplit : ntiles));
     if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
     else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
     else if (cfg == 3) {
@@ -505,6 +579,14 @@ PSAM_API int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* sca
         else hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<false, false>), grid, dim3(256), 0, stream, p);
     } else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
     return psam_launch_status("psam_gemm_f16x3: launch failed");
+}
+
+PSAM_API int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw,
+                                    const float* scaleW, int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual,
+                                    int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K,
+                                    float alpha, int32_t act, hipStream_t stream) {
+    return psam_gemm_f16x3_ws(A, lda, scaleA, a_packed, W, ldw, scaleW, w_packed, C, ldc, bias, residual, ldr, rowbias, ldrb, rowgroup, M, N, K, alpha,
+                              act, nullptr, 0, 0, stream);
 }
 
 PSAM_API int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,

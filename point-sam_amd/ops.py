@@ -244,16 +244,37 @@ def weight_packed_f16(W, K):
 PACK_WEIGHTS = True   # "f16x3": stage pre-packed weights (no split arithmetic for W in the GEMM); False = split W on the fly
 
 
-def _f16x3_call(fn_args, flops, M, N, K):
+# "f16x3": let under-filled launches split K over workgroup pairs (csrc/gemm_f16x3.hip).  Correct and bit-reproducible, but
+# measured SLOWER than the unsplit launches on this path (proj 41 -> 49 us, qkv 98 -> 112 us: the 64 KiB per-tile hand-over
+# through device-coherent accesses costs more than the better occupancy gains), so it is off.
+SPLIT_K = False
+_F16X3_WS = {}        # (device index, stream handle) -> [zeroed workspace tensor, launch counter]
+
+
+def _f16x3_workspace(device):
+    key = (device.index, _stream())
+    ent = _F16X3_WS.get(key)
+    if ent is None:
+        ent = _F16X3_WS[key] = [torch.zeros(_lib.load().psam_gemm_f16x3_workspace_bytes(), dtype=torch.uint8, device=device), 0]
+    ent[1] = ent[1] % 0xFFFFFFF0 + 1          # non-zero, unique per launch on this workspace
+    return ent[0], ent[1]
+
+
+def _f16x3_call(fn_args, flops, M, N, K, device):
     global _gemm_counter
     L = _lib.load()
     _gemm_counter += 1
+    if SPLIT_K:
+        ws, epoch = _f16x3_workspace(device)
+        fn_args = fn_args[:-1] + (ws.data_ptr(), ws.numel(), epoch, fn_args[-1])
+    else:
+        fn_args = fn_args[:-1] + (0, 0, 0, fn_args[-1])
     if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
-        check(L.psam_gemm_f16x3_ex(*fn_args), "psam_gemm_f16x3")
+        check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3")
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    check(L.psam_gemm_f16x3_ex(*fn_args), "psam_gemm_f16x3")
+    check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3")
     e.record()
     GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3"))
 
@@ -287,7 +308,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         else:
             sw, wflag = weight_scale_f16(W, K), 0
         _f16x3_call((xp, ldx, sa.data_ptr(), 1 if x_packed else 0, wp, ldw, sw.data_ptr(), wflag, op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup,
-                     M, N, K, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K)
+                     M, N, K, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K, x.device)
         return out
     if x_packed:
         raise ValueError("x_packed activations can only feed an f16x3 GEMM (M, N, K above the split thresholds)")

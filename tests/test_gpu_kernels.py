@@ -303,6 +303,35 @@ def test_layernorm_packed_output(ops, cols, ld):
         assert torch.allclose(dec[:, : cols - full], y[:, full:], rtol=2e-6, atol=1e-7) and (dec[:, cols - full:] == 0).all()
 
 
+@pytest.mark.parametrize("M,N,K,act", [(4096, 1024, 1024, 1), (4096, 1024, 2752, 0), (4096, 3072, 1024, 0), (2048, 1024, 512, 3), (1000, 392, 516, 1)])
+def test_gemm_f16x3_split_k(ops, M, N, K, act):
+    """Split-K over workgroup pairs (under-filled launches): accuracy class unchanged, bit-reproducible run to run (the owner
+    adds the partner's partial in a fixed order), and the workspace/epoch protocol survives many back-to-back launches."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = None if act == 3 else torch.randn(M, N, generator=g).cuda()
+    outs = {}
+    for split in (False, True):
+        ops.SPLIT_K = split
+        try:
+            with ops.gemm_mode("f16x3"):
+                ys = [ops.linear(x, W, b, act=act, residual=res) for _ in range(6)]
+        finally:
+            ops.SPLIT_K = False
+        assert all(torch.equal(ys[0], y) for y in ys[1:]), "not reproducible"
+        outs[split] = ys[0]
+    if act == 3:
+        return
+    want = x.double() @ W.double().T + b.double()
+    want = (F.gelu(want) if act == 1 else want) + res.double()
+    scale = x.double().abs() @ W.double().abs().T + 1.0
+    e0 = ((outs[False].double() - want).abs() / scale).max().item()
+    e1 = ((outs[True].double() - want).abs() / scale).max().item()
+    assert e1 < 2 * e0 + 1e-7, (e0, e1)
+
+
 def test_gemm_f16x3_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
