@@ -49,6 +49,7 @@ const char* psam_last_error_string(void);
 size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G);
 int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws, size_t ws_bytes,
                  psam_stream_t stream);
+void psam_fps_set_cooperative(int32_t on); /* test hook: 0 = never use the multi-workgroup kernel for N > 32768 */
 
 /* K nearest points of each center, ascending by (squared distance, index); the [G,N] distance matrix is never
  * materialised.  Replaces knn_points(centers, xyz, K) = torch.cdist + torch.topk: pc_sam/model/common.py:27-56,97.

@@ -18,6 +18,7 @@ SIGNATURES = {
     "psam_version": (i32, []),
     "psam_last_error_string": (ctypes.c_char_p, []),
     "psam_fps_workspace_bytes": (size_t, [i32, i32, i32]),
+    "psam_fps_set_cooperative": (None, [i32]),
     "psam_fps": (i32, [ptr, i32, i32, i32, ptr, ptr, ptr, size_t, ptr]),
     "psam_knn": (i32, [ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
     "psam_three_nn": (i32, [ptr, ptr, i32, i32, i32, f32, ptr, ptr, ptr]),

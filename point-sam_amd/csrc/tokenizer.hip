@@ -173,11 +173,137 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cooperative FPS for large clouds (N > 32768: cfg #3, N = 131072, G = 2048).  The single-workgroup kernel above streams
+// such a cloud from L2 on ONE CU (22 us per iteration, 45 ms per cloud); here W = npad / (4096 PPT4) workgroups share a cloud,
+// each keeping its 4096 PPT4 points and their running min-distances in registers.  Per iteration every workgroup publishes its
+// local (max min-distance, lowest index) candidate as one 64-bit key, all workgroups of the cloud meet at a counter barrier,
+// and each reduces the W keys itself (same winner everywhere: no second broadcast).  Keys, counter and flags are agent-scope
+// relaxed atomics (device-coherent, no bulk cache maintenance); a workgroup-scope release (plain waitcnt) orders the key store
+// before the arrival.  All B*W workgroups must be resident at once (checked on the host against the CU count).
+// Same arithmetic and tie-break as fps_kernel -> bit-identical indices.
+// ------------------------------------------------------------------------------------------------
+template <int PPT4>
+__global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float* __restrict__ xyz, const float* __restrict__ soa, int N, int64_t npad,
+                                                               int G, int W, unsigned long long* __restrict__ cand, unsigned* __restrict__ bar,
+                                                               int64_t* __restrict__ idx_out, float* __restrict__ centers_out) {
+    const int b = blockIdx.y, w = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* P = xyz + (int64_t)b * N * 3;
+    const float* soa_b = soa + (int64_t)b * 3 * npad;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)soa_b, 0, (int)(3 * npad * 4), 0x00020000);
+    const int plane_bytes = (int)(npad * 4);
+    __shared__ float s_val[2][FPS_WAVES];
+    __shared__ int s_idx[2][FPS_WAVES];
+    unsigned long long* cand_b = cand + (int64_t)b * 2 * 64;
+    unsigned* bar_b = bar + b;
+
+    f32x4 md[PPT4], rx[PPT4], ry[PPT4], rz[PPT4];
+#pragma unroll
+    for (int g = 0; g < PPT4; ++g) {
+        const int gg = w * PPT4 + g;
+        const int base = (gg * FPS_THREADS + tid) * 4;
+        md[g].x = base + 0 < N ? INFINITY : -1.0f;
+        md[g].y = base + 1 < N ? INFINITY : -1.0f;
+        md[g].z = base + 2 < N ? INFINITY : -1.0f;
+        md[g].w = base + 3 < N ? INFINITY : -1.0f;
+        const int off = gg * (FPS_THREADS * 16);
+        rx[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, off, 0));
+        ry[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, off + plane_bytes, 0));
+        rz[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, off + 2 * plane_bytes, 0));
+    }
+    int last = 0;
+    if (w == 0) {
+        if (tid == 0) idx_out[(int64_t)b * G] = 0;
+        if (tid < 3) centers_out[(int64_t)b * G * 3 + tid] = P[tid];
+    }
+    for (int j = 1; j < G; ++j) {
+        const float cx = P[(int64_t)last * 3 + 0], cy = P[(int64_t)last * 3 + 1], cz = P[(int64_t)last * 3 + 2];
+        float best = -1.0f;
+        int bslot = -1;
+#pragma unroll
+        for (int g = 0; g < PPT4; ++g) {
+            float d;
+            d = dist2_exact(rx[g].x, ry[g].x, rz[g].x, cx, cy, cz); md[g].x = fminf(md[g].x, d); if (md[g].x > best) { best = md[g].x; bslot = 4 * g; }
+            d = dist2_exact(rx[g].y, ry[g].y, rz[g].y, cx, cy, cz); md[g].y = fminf(md[g].y, d); if (md[g].y > best) { best = md[g].y; bslot = 4 * g + 1; }
+            d = dist2_exact(rx[g].z, ry[g].z, rz[g].z, cx, cy, cz); md[g].z = fminf(md[g].z, d); if (md[g].z > best) { best = md[g].z; bslot = 4 * g + 2; }
+            d = dist2_exact(rx[g].w, ry[g].w, rz[g].w, cx, cy, cz); md[g].w = fminf(md[g].w, d); if (md[g].w > best) { best = md[g].w; bslot = 4 * g + 3; }
+        }
+        int besti = bslot < 0 ? 0x7fffffff : (((w * PPT4 + (bslot >> 2)) * FPS_THREADS + tid) * 4 + (bslot & 3));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        const int slot = j & 1;
+        if (lane == 0) { s_val[slot][wave] = best; s_idx[slot][wave] = besti; }
+        __syncthreads();
+        if (wave == 0) {
+            float v = lane < FPS_WAVES ? s_val[slot][lane] : -2.0f;
+            int vi = lane < FPS_WAVES ? s_idx[slot][lane] : 0x7fffffff;
+#pragma unroll
+            for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(vi, o, 64);
+                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            }
+            if (lane == 0) {
+                // key: larger min-distance wins, then the LOWER index; a workgroup of pure padding (v < 0) publishes 0
+                const unsigned long long key = v < 0.f ? 0ull : (((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (0xffffffffu - (unsigned)vi));
+                __hip_atomic_store(cand_b + slot * 64 + w, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the key is acknowledged before the arrival
+                __hip_atomic_fetch_add(bar_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = (unsigned)j * (unsigned)W;
+                while (__hip_atomic_load(bar_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        unsigned long long k = lane < W ? __hip_atomic_load(cand_b + slot * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ok = __shfl_xor(k, o, 64);
+            k = ok > k ? ok : k;
+        }
+        last = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (w == 0) {
+            if (tid == 0) idx_out[(int64_t)b * G + j] = last;
+            if (tid < 3) centers_out[((int64_t)b * G + j) * 3 + tid] = P[(int64_t)last * 3 + tid];
+        }
+    }
+}
+
+__global__ void fps_coop_reset_kernel(unsigned* bar, int B) { if ((int)threadIdx.x < B) bar[threadIdx.x] = 0; }
+
+static int fps_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// cooperative layout: groups of 4096 points per workgroup, W <= 64 workgroups per cloud, all B*W resident
+static int fps_coop_ppt4(int B, int N, int* W) {
+    if (N <= 32768 || B > 1024) return 0;
+    const int64_t groups = fps_npad(N) / (4 * FPS_THREADS);
+    for (int ppt4 = 1; ppt4 <= 4; ppt4 *= 2) {
+        if (groups % ppt4 == 0 && groups / ppt4 <= 64 && (int64_t)B * (groups / ppt4) <= fps_num_cus()) { *W = (int)(groups / ppt4); return ppt4; }
+    }
+    return 0;
+}
+
 PSAM_API size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G) {
     (void)G;
     if (B <= 0 || N <= 0) return 0;
-    return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float);  // planar xyz (3) + streamed min-distance (1)
+    // planar xyz (3) + streamed min-distance (1) + cooperative hand-over: 2 x 64 candidate keys and one barrier counter per cloud
+    return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float) + (size_t)B * (2 * 64 * sizeof(unsigned long long) + 16);
 }
+
+static int g_fps_coop = 1;  // test hook: 0 forces the single-workgroup kernels
+PSAM_API void psam_fps_set_cooperative(int32_t on) { g_fps_coop = on; }
 
 // xyz [B,N,3] f32 -> fps_idx [B,G] i64 (start index 0), centers [B,G,3] f32 (fused batch_index_select).
 PSAM_API int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws,
@@ -191,6 +317,17 @@ PSAM_API int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int
     float* soa = (float*)ws;
     float* mdg = soa + (int64_t)B * 3 * npad;
     hipLaunchKernelGGL(fps_soa_kernel, dim3((unsigned)psam_cdiv(npad, 256), B), dim3(256), 0, stream, xyz, N, npad, soa);
+    int W = 0;
+    const int coop = g_fps_coop ? fps_coop_ppt4(B, N, &W) : 0;
+    if (coop) {
+        unsigned long long* cand = (unsigned long long*)(mdg + (int64_t)B * npad);
+        unsigned* bar = (unsigned*)(cand + (int64_t)B * 2 * 64);
+        hipLaunchKernelGGL(fps_coop_reset_kernel, dim3(1), dim3(1024), 0, stream, bar, B);
+#define FPS_COOP(P) hipLaunchKernelGGL(fps_coop_kernel<P>, dim3(W, B), dim3(FPS_THREADS), 0, stream, xyz, soa, N, npad, G, W, cand, bar, fps_idx, centers)
+        if (coop == 1) FPS_COOP(1); else if (coop == 2) FPS_COOP(2); else FPS_COOP(4);
+#undef FPS_COOP
+        return psam_launch_status("psam_fps: launch failed");
+    }
     const int groups = (int)(npad / (4 * FPS_THREADS));
 #define FPS_LAUNCH(P) \
     hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, soa, mdg, N, npad, G, fps_idx, centers)

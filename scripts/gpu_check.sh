@@ -9,7 +9,7 @@ LOG=gpurun_out/check.log
 echo "== rocminfo" >> $LOG; (rocminfo | grep -E "Marketing Name|gfx9" | head -4; nproc; free -g | head -2) >> $LOG 2>&1
 echo "== entry" >> $LOG
 timeout 600 python __graft_entry__.py >> $LOG 2>&1; echo "entry exit $?" >> $LOG
-FUNCS_K="test_fps_bit_exact test_knn_bit_exact test_knn_all_points_identical test_three_nn test_group_gather_and_patch_l1 test_gemm_shapes test_gemm_asymmetric_identity test_gemm_epilogues_and_views test_gemm_bf16x6 test_gemm_f16x3 test_gemm_swiglu_epilogue test_layernorm test_swiglu_ln test_group_max_pos_fourier_addbcast_interp test_flash_attention test_attention_small test_invalid_arguments_raise test_border_farthest_and_error_regions"
+FUNCS_K="test_fps_bit_exact test_fps_cooperative_bit_exact test_knn_bit_exact test_knn_all_points_identical test_three_nn test_group_gather_and_patch_l1 test_gemm_shapes test_gemm_asymmetric_identity test_gemm_epilogues_and_views test_gemm_bf16x6 test_gemm_f16x3 test_gemm_swiglu_epilogue test_layernorm test_swiglu_ln test_group_max_pos_fourier_addbcast_interp test_flash_attention test_attention_small test_invalid_arguments_raise test_border_farthest_and_error_regions"
 for t in $FUNCS_K; do
   echo "== kernels::$t" >> $LOG
   timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "$t" 2>&1 | tail -40 >> $LOG

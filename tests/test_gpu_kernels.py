@@ -57,6 +57,24 @@ def test_fps_bit_exact(ops, B, N, G, dup):
     assert torch.equal(centers.cpu(), O.batch_index_select(xyz, want))
 
 
+@pytest.mark.parametrize("B,N,G,dup", [(1, 131072, 2048, 0), (2, 70000, 300, 20000), (3, 33000, 64, 0), (1, 300000, 40, 0), (1, 600000, 24, 0)])
+def test_fps_cooperative_bit_exact(ops, B, N, G, dup):
+    """N > 32768: the multi-workgroup FPS (per-iteration candidate exchange + counter barrier across workgroups) must give the
+    oracle's indices bit for bit, and the same as the single-workgroup streaming kernel."""
+    xyz, _ = _cloud(B, N, seed=N + G, dup=dup)
+    want = O.fps(xyz, G)
+    idx, centers = ops.fps(cu(xyz), G)
+    assert torch.equal(idx.cpu(), want)
+    assert torch.equal(centers.cpu(), O.batch_index_select(xyz, want))
+    L = ops._lib.load()
+    L.psam_fps_set_cooperative(0)
+    try:
+        idx1, _ = ops.fps(cu(xyz), G)
+    finally:
+        L.psam_fps_set_cooperative(1)
+    assert torch.equal(idx1, idx)
+
+
 @pytest.mark.parametrize("B,N,G,K,dup", [(2, 1024, 32, 16, 0), (1, 777, 32, 16, 0), (2, 4096, 128, 32, 0), (1, 32768, 96, 64, 0),
                                          (1, 5000, 64, 64, 2500), (1, 3000, 16, 256, 0), (1, 100, 8, 100, 40), (1, 20000, 32, 1000, 0)])
 def test_knn_bit_exact(ops, B, N, G, K, dup):
