@@ -149,7 +149,8 @@ int32_t psam_gemm_f16x3_ws(const void* A, int64_t lda, const float* scaleA, int3
                            int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias,
                            int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, void* ws, size_t ws_bytes,
                            uint32_t epoch, psam_stream_t stream);
-void psam_gemm_f16x3_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
+void psam_gemm_f16x3_force_config(int32_t cfg);
+void psam_gemm_f16x3_force_deep(int32_t sets); /* tuning hook: 2/3/4 operand register sets (prefetch distance) in the pipelined kernel, -1 = auto */ /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 void psam_gemm_bf16x6_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */

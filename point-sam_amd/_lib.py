@@ -49,6 +49,7 @@ SIGNATURES = {
     "psam_gemm_f16x3_ws": (i32, [ptr, i64, ptr, i32, ptr, i64, ptr, i32, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, size_t,
                                  ctypes.c_uint32, ptr]),
     "psam_gemm_f16x3_force_config": (None, [i32]),
+    "psam_gemm_f16x3_force_deep": (None, [i32]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
     "psam_layernorm_rs": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, ptr]),
     "psam_layernorm_ex": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, i32, ptr]),

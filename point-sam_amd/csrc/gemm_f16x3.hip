@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const F16x3Args p) {
 //              split R[(t+1)&1] -> LDS[(t+1)&1];  R[(t+1)&1] <- global slab t+3 (two slab periods to land)
 //   barrier    (LDS[(t+1)&1] complete; every wave has its F1, so LDS[t&1] may be overwritten next slab)
 //   region B:  F0 <- LDS[(t+1)&1] (step 0 of slab t+1)     | remaining 8 MFMAs of step 1
-template <bool APK, bool WPK>   // operand already f16x2-packed (psam_pack_rows_f16x2): staged without arithmetic
+// APK / WPK: operand already f16x2-packed (psam_pack_rows_f16x2): staged without arithmetic.  NSETS: operand register sets =
+// prefetch distance in slabs (2 in production: ~215-230 registers, two workgroups per CU; 3 and 4 exist for measurement).
+template <bool APK, bool WPK, int NSETS>
 __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p) {
     constexpr int TM = 2, TN = 2, WN = 2;
     constexpr int BM = 128, BN = 128;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
         offA[i] = oka ? voA + i * stepA : OOB;
         offW[i] = okw ? voW + i * stepW : OOB;
     }
-    f32x4 ra[2][NF4], rw[2][NF4];
+    f32x4 ra[NSETS][NF4], rw[NSETS][NF4];
     auto load_slab = [&](int k0, f32x4 (&a)[NF4], f32x4 (&w)[NF4]) {
         const bool kok = k0 + lc4 * 4 < p.K;
 #pragma unroll
@@ -445,13 +447,13 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
             mfma(m, af0, wf0);
-            split_chunk(m, buf ^ 1, (kbeg + t + 3) * HG_BK, a_next, w_next);
+            split_chunk(m, buf ^ 1, (kbeg + t + 1 + NSETS) * HG_BK, a_next, w_next);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             mfma(m, af1, wf1);
-            split_chunk(12 + m, buf ^ 1, (kbeg + t + 3) * HG_BK, a_next, w_next);
+            split_chunk(12 + m, buf ^ 1, (kbeg + t + 1 + NSETS) * HG_BK, a_next, w_next);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -462,18 +464,22 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
         for (int m = 4; m < 12; ++m) mfma(m, af1, wf1);
         __builtin_amdgcn_sched_barrier(0);
     };
-    load_slab(kbeg * HG_BK, ra[0], rw[0]);
-    load_slab((kbeg + 1) * HG_BK, ra[1], rw[1]);
+    // slab s lives in register set s % NSETS: slabs 0..NSETS-1 first, then set 0 (staged as slab 0) is refilled with slab NSETS
+#pragma unroll
+    for (int u = 0; u < NSETS; ++u) load_slab((kbeg + u) * HG_BK, ra[u], rw[u]);
     split_store(0, ra[0], rw[0]);
-    load_slab((kbeg + 2) * HG_BK, ra[0], rw[0]);
+    load_slab((kbeg + NSETS) * HG_BK, ra[0], rw[0]);
     __syncthreads();
     load_frags(0, 0, af0, wf0);
+    constexpr int UNR = NSETS % 2 == 0 ? NSETS : 2 * NSETS;   // the LDS stage alternates per slab, the register set cycles per NSETS
     int t = 0;
-    for (; t + 1 < nslabs; t += 2) {   // straight-line pairs: every vmcnt wait stays counted
-        slab_body(t, 0, ra[1], rw[1]);
-        slab_body(t + 1, 1, ra[0], rw[0]);
+    for (; t + UNR <= nslabs; t += UNR) {       // straight-line groups: every vmcnt wait stays counted
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) slab_body(t + u, u & 1, ra[(u + 1) % NSETS], rw[(u + 1) % NSETS]);
     }
-    if (t < nslabs) slab_body(t, 0, ra[1], rw[1]);
+#pragma unroll
+    for (int u = 0; u < UNR - 1; ++u)
+        if (t + u < nslabs) slab_body(t + u, u & 1, ra[(u + 1) % NSETS], rw[(u + 1) % NSETS]);
 #undef HP_TERM
 
     if (half >= 0) {   // split-K hand-over: [split tile][wave][tile i][tile j][reg][lane] floats, 256-byte rows per wave instruction
@@ -513,6 +519,8 @@ __global__ __launch_bounds__(256) void gemm_f16x3_pipe_kernel(const F16x3Args p)
 static int g_f16x3_cfg = -1;  // tuning hook: 0 = 128x128 (2x2 waves of 64x64), 1 = 128x64 (4x1 waves of 32x64), 2 = 128x128 without fragment double
 // buffering (fewer registers), 3 = 128x128 software-pipelined (double-buffered LDS), -1 = auto
 PSAM_API void psam_gemm_f16x3_force_config(int32_t cfg) { g_f16x3_cfg = cfg; }
+static int g_f16x3_deep = -1;  // tuning hook: 2 / 3 / 4 force that many operand register sets in the pipelined kernel, -1 = auto
+PSAM_API void psam_gemm_f16x3_force_deep(int32_t sets) { g_f16x3_deep = sets; }
 
 // C = act(alpha * A @ W^T + bias + rowbias[row/rowgroup]) + residual; scaleA[M], scaleW[N] from psam_row_scale_f16.
 // a_packed / w_packed: that operand is the f16x2-packed form of the row-scaled matrix (psam_pack_rows_f16x2 with the same scales).
@@ -573,10 +581,21 @@ PSAM_API int32_t psam_gemm_f16x3_ws(const void* A, int64_t lda, const float* sca
     if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
     else if (cfg == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
     else if (cfg == 3) {
-        if (a_packed && w_packed) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<true, true>), grid, dim3(256), 0, stream, p);
-        else if (a_packed) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<true, false>), grid, dim3(256), 0, stream, p);
-        else if (w_packed) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<false, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<false, false>), grid, dim3(256), 0, stream, p);
+        // operand register sets (prefetch distance): 2.  Deeper (3: 246 registers on paper but the allocator spills the second
+        // wave per SIMD; 4: one wave per SIMD) was measured on one-tile-per-CU launches (proj, fc2) and on full launches: no gain
+        // on the former (35.2 / 33.8 / 34.2 us: not load-latency bound), 20-30 % slower on the latter (occupancy).  Hook kept.
+        const int deep = g_f16x3_deep >= 0 ? g_f16x3_deep : 2;
+#define PIPE_LAUNCH(AP, WP)                                                                                          \
+    do {                                                                                                             \
+        if (deep >= 4) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<AP, WP, 4>), grid, dim3(256), 0, stream, p);      \
+        else if (deep == 3) hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<AP, WP, 3>), grid, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((gemm_f16x3_pipe_kernel<AP, WP, 2>), grid, dim3(256), 0, stream, p);                \
+    } while (0)
+        if (a_packed && w_packed) PIPE_LAUNCH(true, true);
+        else if (a_packed) PIPE_LAUNCH(true, false);
+        else if (w_packed) PIPE_LAUNCH(false, true);
+        else PIPE_LAUNCH(false, false);
+#undef PIPE_LAUNCH
     } else hipLaunchKernelGGL((gemm_f16x3_kernel<4, 1, 1, 2, false>), grid, dim3(256), 0, stream, p);
     return psam_launch_status("psam_gemm_f16x3: launch failed");
 }
