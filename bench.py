@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3"],
                     help="arithmetic of the large GEMMs; all three are fp32-grade and pass the same parity tests (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="dense-stage HIP streams: batches in flight (1 = only the tokenizer of the next batch overlaps)")
     ap.add_argument("--no-pipeline", action="store_true", help="run FPS/kNN of each batch inline instead of one batch ahead on a side stream")
     ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")
     args = ap.parse_args()
@@ -78,7 +79,7 @@ def main():
     total = B * world
 
     from point_sam_amd.model import BatchPipeline
-    pipe = BatchPipeline(model) if not args.no_pipeline else None
+    pipe = BatchPipeline(model, dense_streams=args.streams) if not args.no_pipeline else None
 
     def finish(masks, iou):
         if world > 1:
@@ -94,9 +95,10 @@ def main():
             for _ in range(n):
                 out = finish(*model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False))
             return out
-        pipe.submit(xyz, rgb, prompt, labels, None, True)
+        for k in range(min(pipe.depth, n)):
+            pipe.submit(xyz, rgb, prompt, labels, None, True)
         for k in range(n):
-            if k + 1 < n:
+            if k + pipe.depth < n:
                 pipe.submit(xyz, rgb, prompt, labels, None, True)
             out = finish(*pipe.next())
         return out
@@ -117,6 +119,22 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
+    prof_excl = None
+    if prof is not None and pipe is not None and pipe.depth > 1:
+        # OUTSIDE the timed region: two more steps with ONE batch in flight, to show the dominant kernel's launch duration when it has
+        # the GPU to itself (with two batches in flight the kernels of the two dense streams time-share the CUs, so the per-launch
+        # duration measured in the timed region is longer although the machine does more work per second)
+        pipe1, every = BatchPipeline(model, dense_streams=1), ops.GEMM_PROFILE_EVERY
+        prof_excl, ops.GEMM_PROFILE_EVERY = [], 5
+        pipe1.submit(xyz, rgb, prompt, labels, None, True)
+        pipe1.next()
+        fence()
+        ops.GEMM_PROFILE = prof_excl
+        for _ in range(2):
+            pipe1.submit(xyz, rgb, prompt, labels, None, True)
+            pipe1.next()
+        fence()
+        ops.GEMM_PROFILE, ops.GEMM_PROFILE_EVERY = None, every
     model.check_coordinate_range()
     assert torch.isfinite(out[0]).all()
     if world > 1:
@@ -159,6 +177,17 @@ def main():
                         "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
                         "sampling": f"every {ops.GEMM_PROFILE_EVERY}th GEMM launch of the timed region, HIP events on the launch stream",
                         "avg_launch_ms": round(tot_ms / len(sel), 4), "avg_launch_gflop": round(tot_fl / len(sel) / 1e9, 3)}
+            # whole-path figure of SURVEY.md 8(d): algorithmic flops of the path (3.72e11 per cloud at this workload) / step time
+            if args.config == "large" and N == 32768 and args.groups == 512 and args.group_size == 64:
+                roofline["whole_path_achieved"] = round(3.72e11 * total / world / (elapsed / args.steps) / 1e12, 2)
+            if prof_excl:
+                sel2 = [(s.elapsed_time(e), f) for s, e, f, _, _, _, k in prof_excl if k == kind and f >= 1e9]
+                if sel2:
+                    a2 = sum(f for _, f in sel2) / (sum(m for m, _ in sel2) * 1e-3) / 1e12
+                    roofline["one_batch_in_flight"] = {"achieved": round(a2, 2), "frac": round(a2 / peak, 4), "sampled_launches": len(sel2),
+                                                       "note": "same kernel, 2 extra steps AFTER the timed region with one batch in flight (no time-sharing between dense streams)"}
+                    roofline["note"] = (f"{pipe.depth} batches in flight on {pipe.depth} dense HIP streams: their kernels time-share the CUs, so the per-launch duration "
+                                        "(achieved, frac) is longer than the same launch alone (one_batch_in_flight) while the throughput (value) is higher")
 
     if rank == 0:
         res = {
@@ -169,7 +198,7 @@ def main():
                       "f16x3": "f32 (fp32 in/out/accumulate; large GEMMs as row-scaled 2-way fp16 split x 3 MFMA products, fp32-grade error)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"ViT-{args.config} N={N} g={args.groups}x{args.group_size} batch={B}/GPU 1 point prompt multimask",
-                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None,
+                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None, "batches_in_flight": (pipe.depth if pipe is not None else 1),
                        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3), "gemm_precision": args.precision, "weights": "seeded random init (no checkpoint offline)"},
             "roofline": roofline,
         }

@@ -429,17 +429,28 @@ class PointCloudSAM:
 
 
 class BatchPipeline:
-    """Two-stage software pipeline over a stream of independent batches: the coordinate-only tokenizer stage (FPS, kNN,
-    3-NN; a few latency-bound workgroups) of batch i+1 runs on its own high-priority HIP stream while the dense stage
-    (mini-PointNet, ViT, decoder; every CU) of batch i runs on the caller's stream.  ``submit`` enqueues stage 1,
-    ``next`` enqueues stage 2 of the oldest submitted batch and returns its (masks, iou).  Results are identical to
-    ``predict_masks`` (same kernels, same order per batch); only the interleaving on the device changes."""
+    """Software pipeline over a stream of independent batches.
 
-    def __init__(self, model: PointCloudSAM):
+    Stage 1, the coordinate-only tokenizer (FPS, kNN, 3-NN; a few latency-bound workgroups), of batch i+1 runs on its own
+    high-priority HIP stream while stage 2, the dense work (mini-PointNet, ViT, decoder; every CU), of batch i runs.
+    ``dense_streams = 1``: ``submit`` enqueues stage 1, ``next`` enqueues stage 2 of the oldest submitted batch on the caller's
+    stream.  ``dense_streams = S > 1``: ``submit`` enqueues BOTH stages, stage 2 on dense stream ``i % S``, so that S batches are
+    in flight and one batch's kernel tails (a 768-tile GEMM on 512 workgroup slots, single-workgroup epilogues, the small decoder
+    kernels) are filled by the other's kernels; ``next`` only makes the caller's stream wait for the batch.  Results are identical
+    to ``predict_masks`` (same kernels, same order per batch); only the interleaving on the device changes."""
+
+    def __init__(self, model: PointCloudSAM, dense_streams: int = 1):
         from collections import deque
         self.model = model
         self.tok_stream = torch.cuda.Stream(device=model.device, priority=-1)
+        self.dense = [torch.cuda.Stream(device=model.device) for _ in range(dense_streams)] if dense_streams > 1 else []
+        self.count = 0
         self.queue = deque()
+
+    @property
+    def depth(self) -> int:
+        """How many batches to keep submitted ahead of ``next``."""
+        return max(1, len(self.dense))
 
     @torch.no_grad()
     def submit(self, coords, features, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True):
@@ -451,12 +462,32 @@ class BatchPipeline:
             tok = m.tokenize(coords, with_interp=True)
             ready = torch.cuda.Event()
             ready.record(self.tok_stream)
+        if not self.dense:
+            for t in tok.tensors():
+                t.record_stream(main)  # allocated on tok_stream, consumed on the caller's stream
+            self.queue.append((tok, ready, coords, features, prompt_coords, prompt_labels, prompt_masks, multimask_output))
+            return
+        ds = self.dense[self.count % len(self.dense)]
+        self.count += 1
         for t in tok.tensors():
-            t.record_stream(main)  # allocated on tok_stream, consumed on the caller's stream
-        self.queue.append((tok, ready, coords, features, prompt_coords, prompt_labels, prompt_masks, multimask_output))
+            t.record_stream(ds)
+        ds.wait_stream(main)
+        ds.wait_event(ready)
+        with torch.cuda.stream(ds):
+            st = m.encode(coords, features, tok)
+            out = m.decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output)
+            done = torch.cuda.Event()
+            done.record(ds)
+        for t in out:
+            t.record_stream(main)
+        self.queue.append((out, done))
 
     @torch.no_grad()
     def next(self):
+        if self.dense:
+            out, done = self.queue.popleft()
+            torch.cuda.current_stream(self.model.device).wait_event(done)
+            return out
         tok, ready, coords, features, pc, pl, pm, mm = self.queue.popleft()
         torch.cuda.current_stream(self.model.device).wait_event(ready)
         st = self.model.encode(coords, features, tok)

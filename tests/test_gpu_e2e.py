@@ -192,22 +192,25 @@ def test_out_of_range_coordinates_raise(gpu):
     assert torch.isfinite(m).all()
 
 
-def test_batch_pipeline_matches_predict_masks(gpu):
-    """The 2-stream pipeline (tokenizer one batch ahead) returns bit-identical results to the inline path."""
+@pytest.mark.parametrize("dense_streams,precision", [(1, "f32"), (2, "f16x3"), (3, "f16x3")])
+def test_batch_pipeline_matches_predict_masks(gpu, dense_streams, precision):
+    """The pipeline (tokenizer one batch ahead; optionally several batches in flight on their own dense streams) returns
+    bit-identical results to the inline path."""
     from point_sam_amd.model import BatchPipeline
     cfg = get_config("tiny", 64, 16)
-    model = gpu(cfg, random_state_dict(cfg, 4))
+    model = gpu(cfg, random_state_dict(cfg, 4), precision=precision)
     batches = []
-    for i in range(4):
+    for i in range(6):
         xyz, rgb, prompt, labels = O.synthetic_batch(2, 3000 + 500 * i, seed=20 + i)
         batches.append(tuple(t.cuda() for t in (xyz, rgb, prompt, labels)))
     want = [model.predict_masks(*b) for b in batches]
-    pipe = BatchPipeline(model)
+    pipe = BatchPipeline(model, dense_streams=dense_streams)
     got = []
-    pipe.submit(*batches[0])
+    for k in range(min(pipe.depth, len(batches))):
+        pipe.submit(*batches[k])
     for k in range(len(batches)):
-        if k + 1 < len(batches):
-            pipe.submit(*batches[k + 1])
+        if k + pipe.depth < len(batches):
+            pipe.submit(*batches[k + pipe.depth])
         got.append(pipe.next())
     torch.cuda.synchronize()
     for (m1, i1), (m2, i2) in zip(want, got):
