@@ -164,7 +164,7 @@ def main():
                 note = ("fp32-equivalent peak of the scheme = bf16 dense MFMA peak 2500 TFLOP/s / 6 executed products; "
                         f"executed matrix-pipe rate = {ach * 6:.0f} TFLOP/s = {ach * 6 / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak")
             traffic = None
-            tfile = "r01_v9_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
+            tfile = "r01_v10_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
             try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
                 tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
                 key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<true, true>"}.get(kind)
