@@ -167,7 +167,7 @@ def main():
             tfile = "r01_v10_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
             try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
                 tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
-                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<true, true>"}.get(kind)
+                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<true, true, 2>"}.get(kind)
                 if key and key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
             except (OSError, ValueError, KeyError):
