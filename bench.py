@@ -87,20 +87,34 @@ def main():
             iou = psdist.gather_results(iou, total)
         return masks, iou
 
-    def run_steps(n):
-        """n full passes (every batch is tokenized, encoded and decoded inside this call).  With the pipeline the
-        tokenizer stage of step k+1 is enqueued on its own stream before the dense stage of step k."""
+    def run_steps(n, prof=None):
+        """n full passes (every batch is tokenized, encoded and decoded inside this call).  With the pipeline the tokenizer stage of a
+        step runs on its own stream ahead of the dense stage, and `pipe.depth` batches are in flight.  prof: sample the GEMM launches
+        of the LAST step (every 3rd one, HIP events on the launch stream, the other dense stream held off during a sampled launch)."""
+        def dense_call(k, fn):   # fn enqueues the dense stage of step k
+            if prof is None or k != n - 1:
+                return fn()
+            others = [s for i, s in enumerate(pipe.dense) if i != pipe.count % len(pipe.dense)] if (pipe is not None and pipe.dense) else []
+            # sampling starts in the second half of the step (the ~150 GEMM launches of a step: the encoder's 96 large ones come in
+            # block order): by then the previous batch has drained, so holding the other stream off costs no overlap
+            ops._gemm_counter = 0
+            ops.GEMM_PROFILE, ops.GEMM_PROFILE_EVERY, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER = prof, 3, tuple(others), 70 if others else 0
+            try:
+                return fn()
+            finally:
+                ops.GEMM_PROFILE, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER, ops.GEMM_PROFILE_EVERY = None, (), 0, 29
         out = None
         if pipe is None:
-            for _ in range(n):
-                out = finish(*model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False))
+            for k in range(n):
+                out = finish(*dense_call(k, lambda: model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False)))
             return out
+        sub = lambda: pipe.submit(xyz, rgb, prompt, labels, None, True)
         for k in range(min(pipe.depth, n)):
-            pipe.submit(xyz, rgb, prompt, labels, None, True)
+            dense_call(k, sub) if pipe.dense else sub()
         for k in range(n):
             if k + pipe.depth < n:
-                pipe.submit(xyz, rgb, prompt, labels, None, True)
-            out = finish(*pipe.next())
+                dense_call(k + pipe.depth, sub) if pipe.dense else sub()
+            out = finish(*(pipe.next() if pipe.dense else dense_call(k, pipe.next)))
         return out
 
     def fence():
@@ -111,30 +125,12 @@ def main():
     if args.warmup:
         run_steps(args.warmup)
     prof = None if args.no_gemm_profile else []
-    ops.GEMM_PROFILE = prof
     fence()
     t0 = time.perf_counter()
-    out = run_steps(args.steps)
+    out = run_steps(args.steps, prof)
     t_enqueued = time.perf_counter() - t0      # host time to issue every launch of the timed region (no sync inside)
     fence()
     elapsed = time.perf_counter() - t0
-    ops.GEMM_PROFILE = None
-    prof_excl = None
-    if prof is not None and pipe is not None and pipe.depth > 1:
-        # OUTSIDE the timed region: two more steps with ONE batch in flight, to show the dominant kernel's launch duration when it has
-        # the GPU to itself (with two batches in flight the kernels of the two dense streams time-share the CUs, so the per-launch
-        # duration measured in the timed region is longer although the machine does more work per second)
-        pipe1, every = BatchPipeline(model, dense_streams=1), ops.GEMM_PROFILE_EVERY
-        prof_excl, ops.GEMM_PROFILE_EVERY = [], 5
-        pipe1.submit(xyz, rgb, prompt, labels, None, True)
-        pipe1.next()
-        fence()
-        ops.GEMM_PROFILE = prof_excl
-        for _ in range(2):
-            pipe1.submit(xyz, rgb, prompt, labels, None, True)
-            pipe1.next()
-        fence()
-        ops.GEMM_PROFILE, ops.GEMM_PROFILE_EVERY = None, every
     model.check_coordinate_range()
     assert torch.isfinite(out[0]).all()
     if world > 1:
@@ -175,19 +171,12 @@ def main():
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "traffic_note": f"bytes/launch of the 128x128-tile kernel, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
                         "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
-                        "sampling": f"every {ops.GEMM_PROFILE_EVERY}th GEMM launch of the timed region, HIP events on the launch stream",
+                        "sampling": ("every 3rd GEMM launch of the last step of the timed region, HIP events on the launch stream" +
+                                     ("; second half of that step only, when the previous batch has drained, and the other dense stream is held off during a sampled launch: the duration is the kernel's own" if (pipe is not None and pipe.depth > 1) else "")),
                         "avg_launch_ms": round(tot_ms / len(sel), 4), "avg_launch_gflop": round(tot_fl / len(sel) / 1e9, 3)}
             # whole-path figure of SURVEY.md 8(d): algorithmic flops of the path (3.72e11 per cloud at this workload) / step time
             if args.config == "large" and N == 32768 and args.groups == 512 and args.group_size == 64:
                 roofline["whole_path_achieved"] = round(3.72e11 * total / world / (elapsed / args.steps) / 1e12, 2)
-            if prof_excl:
-                sel2 = [(s.elapsed_time(e), f) for s, e, f, _, _, _, k in prof_excl if k == kind and f >= 1e9]
-                if sel2:
-                    a2 = sum(f for _, f in sel2) / (sum(m for m, _ in sel2) * 1e-3) / 1e12
-                    roofline["one_batch_in_flight"] = {"achieved": round(a2, 2), "frac": round(a2 / peak, 4), "sampled_launches": len(sel2),
-                                                       "note": "same kernel, 2 extra steps AFTER the timed region with one batch in flight (no time-sharing between dense streams)"}
-                    roofline["note"] = (f"{pipe.depth} batches in flight on {pipe.depth} dense HIP streams: their kernels time-share the CUs, so the per-launch duration "
-                                        "(achieved, frac) is longer than the same launch alone (one_batch_in_flight) while the throughput (value) is higher")
 
     if rank == 0:
         res = {

@@ -14,10 +14,32 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU = 0, 1, 2, 3
 # Measurement hook (bench.py): when GEMM_PROFILE is a list, every GEMM_PROFILE_EVERY-th GEMM launch is bracketed by two
 # HIP events on the launch stream and (start, end, flops, M, N, K) is appended.  Sampling keeps the perturbation of the
 # timed region small (an event pair costs ~20 us of host time and the host issues ~400 launches per 14 ms step: bracketing every
-# launch cost 17 %, every 7th still 7 %; every 29th is below the run-to-run noise).
+# launch cost 17 %, every 7th still 7 %); bench.py samples every 3rd launch of the LAST step of the timed region only.
 GEMM_PROFILE = None
 GEMM_PROFILE_EVERY = 29
+# Streams whose kernels must not overlap a sampled launch (BatchPipeline with several batches in flight): the sampled launch
+# waits for what they have enqueued so far and they wait for its end, so the events bracket the kernel running ALONE.
+GEMM_PROFILE_OTHERS = ()
+GEMM_PROFILE_AFTER = 0     # launches (since the counter was reset) to skip before sampling starts
 _gemm_counter = 0
+
+
+def _sample_now():
+    return GEMM_PROFILE is not None and _gemm_counter > GEMM_PROFILE_AFTER and _gemm_counter % GEMM_PROFILE_EVERY == 0
+
+
+def _sampled_launch(launch, record):
+    """Brackets one launch with HIP events on the launch stream (exclusive of GEMM_PROFILE_OTHERS) and records them."""
+    cur = torch.cuda.current_stream()
+    for o in GEMM_PROFILE_OTHERS:
+        cur.wait_stream(o)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    launch()
+    e.record()
+    for o in GEMM_PROFILE_OTHERS:
+        o.wait_event(e)
+    record(s, e)
 
 
 # GEMM arithmetic: "f32" = v_mfma_f32_32x32x2_f32 everywhere (exact fp32 products); "bf16x6" = large GEMMs on the bf16
@@ -52,28 +74,20 @@ def _gemm_call(fn_args, flops, M, N, K, what):
     split = GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K
     fn = L.psam_gemm_bf16x6 if split else L.psam_gemm_f32
     _gemm_counter += 1
-    if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
+    if not _sample_now():
         check(fn(*fn_args), what)
         return
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    check(fn(*fn_args), what)
-    e.record()
-    GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6" if split else "f32"))
+    _sampled_launch(lambda: check(fn(*fn_args), what), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6" if split else "f32")))
 
 
 def _packed_gemm_call(fn_args, flops, M, N, K):
     global _gemm_counter
     L = _lib.load()
     _gemm_counter += 1
-    if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
+    if not _sample_now():
         check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw")
         return
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw")
-    e.record()
-    GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6"))
+    _sampled_launch(lambda: check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6")))
 
 
 def _stream():
@@ -269,14 +283,10 @@ def _f16x3_call(fn_args, flops, M, N, K, device):
         fn_args = fn_args[:-1] + (ws.data_ptr(), ws.numel(), epoch, fn_args[-1])
     else:
         fn_args = fn_args[:-1] + (0, 0, 0, fn_args[-1])
-    if GEMM_PROFILE is None or _gemm_counter % GEMM_PROFILE_EVERY:
+    if not _sample_now():
         check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3")
         return
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3")
-    e.record()
-    GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3"))
+    _sampled_launch(lambda: check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3")))
 
 
 def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False):
