@@ -227,6 +227,7 @@ def weight_scale_f16(W, K):
     hit = _WEIGHT_SCALES.get(key)
     if hit is None:
         hit = _WEIGHT_SCALES[key] = (row_scale_f16(W, K), W)
+        torch.cuda.current_stream().synchronize()   # one-time: the cached tensor may be consumed from ANY stream afterwards
     return hit[0]
 
 
@@ -252,6 +253,7 @@ def weight_packed_f16(W, K):
     if hit is None:
         sw = weight_scale_f16(W, K)
         hit = _WEIGHT_PACKED[key] = (pack_rows_f16x2(W, sw, K), sw, W)
+        torch.cuda.current_stream().synchronize()   # one-time: the cached tensor may be consumed from ANY stream afterwards
     return hit[0], hit[1]
 
 
