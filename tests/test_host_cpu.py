@@ -60,3 +60,26 @@ def test_weight_abi_names():
     sd["bogus.weight"] = torch.zeros(1)
     with pytest.raises(KeyError):
         check_state_dict(cfg, sd)
+
+
+def test_checkpoint_round_trip_through_safetensors(tmp_path):
+    """evaluation/inference.py:46 loads `model.safetensors` by name: a file with the reference's names (+ the timm leftovers a real
+    checkpoint carries, in fp16 like some published ones) loads into the name->fp32 dict the model consumes; a missing or mis-shaped
+    tensor is an error."""
+    from safetensors.torch import save_file
+    from point_sam_amd.weights import load_safetensors
+    cfg = get_config("tiny")
+    sd = random_state_dict(cfg, seed=5)
+    extra = {"pc_encoder.transformer.cls_token": torch.zeros(1, 1, 64), "pc_encoder.transformer.pos_embed": torch.zeros(1, 5, 64)}
+    path = str(tmp_path / "model.safetensors")
+    save_file({k: v.half().contiguous() for k, v in {**sd, **extra}.items()}, path)
+    got = load_safetensors(cfg, path)
+    assert all(got[k].dtype == torch.float32 and torch.equal(got[k], sd[k].half().float()) for k in sd)
+    bad = dict(sd); bad.pop("pc_encoder.out_proj.weight")
+    save_file({k: v.contiguous() for k, v in bad.items()}, path)
+    with pytest.raises(KeyError):
+        load_safetensors(cfg, path)
+    bad = dict(sd); bad["pc_encoder.out_proj.weight"] = torch.zeros(3, 3)
+    save_file({k: v.contiguous() for k, v in bad.items()}, path)
+    with pytest.raises((ValueError, KeyError)):
+        load_safetensors(cfg, path)
