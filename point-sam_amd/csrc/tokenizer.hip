@@ -180,7 +180,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
 // local (max min-distance, lowest index) candidate as one 64-bit key, all workgroups of the cloud meet at a counter barrier,
 // and each reduces the W keys itself (same winner everywhere: no second broadcast).  Keys, counter and flags are agent-scope
 // relaxed atomics (device-coherent, no bulk cache maintenance); a workgroup-scope release (plain waitcnt) orders the key store
-// before the arrival.  All B*W workgroups must be resident at once (checked on the host against the CU count).
+// before the arrival.  All B*W workgroups must be resident at once: the host only takes this path when B*W <= number of CUs, i.e.
+// half of the 2-per-CU capacity for 1024-thread workgroups, so two such launches may overlap (BatchPipeline issues all tokenizer
+// work on ONE stream, so they never do); more than two concurrent cooperative launches from different streams are not supported.
 // Same arithmetic and tie-break as fps_kernel -> bit-identical indices.
 // ------------------------------------------------------------------------------------------------
 template <int PPT4>
