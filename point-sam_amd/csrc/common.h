@@ -41,13 +41,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-// Power-of-two row scale of the f16x3 GEMM: 2^(14 - e), e = floor(log2(row maximum)) clamped to [-100, 100]; 1 for an
+// Power-of-two row scale of the f16x3 GEMM: 2^(14 - e), e = floor(log2(row maximum)) clamped below at -112 (scale and its inverse stay
+// normal fp32 numbers over the whole finite range: 2^-113 .. 2^126 and 2^-126 .. 2^113); 1 for an
 // all-zero / non-finite row (gemm_f16x3.hip).
 __device__ __forceinline__ float f16_row_scale(float amax) {
     const unsigned bits = __builtin_bit_cast(unsigned, amax);
     int e = (int)((bits >> 23) & 0xff) - 127;
     if (bits == 0 || e == 128) return 1.f;
-    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    e = e < -112 ? -112 : e;
     return __builtin_bit_cast(float, (unsigned)(127 + 14 - e) << 23);
 }
 

@@ -19,7 +19,7 @@ typedef float ep_f32x4 __attribute__((ext_vector_type(4)));
 template <int TN>
 constexpr int gemm_epilogue_lds_floats_per_wave() { return 32 * (TN * 32 + 4); }
 
-// 1/s for a power-of-two scale s in [2^-125, 2^126] (exact): exponent field 254 - E
+// 1/s for a power-of-two scale s in [2^-126, 2^126] (exact): exponent field 254 - E
 __device__ __forceinline__ float inv_pow2(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
 __device__ __forceinline__ ep_f32x4 ep_load4(const float* q) { return *reinterpret_cast<const ep_f32x4*>(q); }
 __device__ __forceinline__ float ep_act(float v, int act) { return act == 1 ? gelu_erf(v) : (act == 2 ? fmaxf(v, 0.f) : v); }

@@ -54,7 +54,7 @@ __device__ __forceinline__ void split2(const f32x2 x, const float s, unsigned& h
 }
 
 // ---------------------------------------------------------------------------------------------- row scales
-// scale[r] = 2^(14 - e), e = floor(log2(max_k |X[r,k]|)) clamped to [-100, 100]; 1 for an all-zero / non-finite row.
+// scale[r] = 2^(14 - e), e = floor(log2(max_k |X[r,k]|)) clamped below at -112; 1 for an all-zero / non-finite row.
 __global__ __launch_bounds__(256) void row_scale_f16_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols, float* __restrict__ scale) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
