@@ -65,7 +65,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from oracle import pointsam_oracle as O  # synthetic input generator + cpu_baseline only
+    from point_sam_amd.synthetic import synthetic_batch   # (oracle/ is only imported by the cpu_baseline leg below)
     from point_sam_amd import get_config, ops
     from point_sam_amd.model import PointCloudSAM
     from point_sam_amd.weights import random_state_dict
@@ -74,7 +74,7 @@ def main():
     sd = random_state_dict(cfg, seed=42)
     model = PointCloudSAM(cfg, sd, dev, precision=args.precision)
     B, N = args.batch, args.points
-    xyz, rgb, prompt, labels = O.synthetic_batch(B, N, seed=42 + rank)
+    xyz, rgb, prompt, labels = synthetic_batch(B, N, seed=42 + rank)
     xyz, rgb, prompt, labels = xyz.to(dev), rgb.to(dev), prompt.to(dev), labels.to(dev)
     total = B * world
 

@@ -7,8 +7,7 @@ from point_sam_amd import ops
 from point_sam_amd.config import get_config
 from point_sam_amd.model import PointCloudSAM
 from point_sam_amd.weights import random_state_dict
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-import pointsam_oracle as O
+from point_sam_amd.synthetic import synthetic_batch
 
 
 class Timer:
@@ -37,7 +36,7 @@ def run(tag, cfg_name, G, K, B, N, clicks, precision="f16x3"):
     T.wrap(model, "_two_way", "two_way_decoder")
     T.wrap(model, "_encode", "encode_total")
     T.wrap(model, "_decode", "decode_total")
-    xyz, rgb, prompt, labels = O.synthetic_batch(B, N, seed=42)
+    xyz, rgb, prompt, labels = synthetic_batch(B, N, seed=42)
     xyz, rgb, prompt, labels = xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda()
     g = torch.Generator().manual_seed(1)
     extra = xyz[:, torch.randint(0, N, (max(clicks - 1, 0),), generator=g)]

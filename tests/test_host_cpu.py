@@ -83,3 +83,13 @@ def test_checkpoint_round_trip_through_safetensors(tmp_path):
     save_file({k: v.contiguous() for k, v in bad.items()}, path)
     with pytest.raises((ValueError, KeyError)):
         load_safetensors(cfg, path)
+
+
+def test_synthetic_inputs_match_the_oracles_generator():
+    """bench.py draws its inputs from the package (it may touch oracle/ only for the cpu_baseline leg): same generator as the oracle's."""
+    from oracle import pointsam_oracle as O
+    from point_sam_amd.synthetic import synthetic_batch
+    for a, b in zip(synthetic_batch(2, 500, seed=7, num_prompts=2), O.synthetic_batch(2, 500, seed=7, num_prompts=2)):
+        assert torch.equal(a, b)
+    xyz = synthetic_batch(3, 1000)[0]
+    assert torch.allclose(xyz.norm(dim=2).max(dim=1).values, torch.ones(3))
