@@ -43,8 +43,8 @@ def cpu_baseline(cfg, sd, N, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="large")
     ap.add_argument("--points", type=int, default=32768)
     ap.add_argument("--groups", type=int, default=512)

@@ -20,7 +20,7 @@ for t in $FUNCS_E; do
   timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -s --tb=short -p no:cacheprovider -k "$t" 2>&1 | tail -40 >> $LOG
 done
 echo "== bench" >> $LOG
-timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> $LOG
+timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?" >> $LOG
 cat gpurun_out/bench.json >> $LOG; tail -5 gpurun_out/bench.err >> $LOG
-for p in bf16x6 f32; do timeout 900 python bench.py --steps 10 --warmup 2 --precision $p --no-cpu-baseline > gpurun_out/bench_$p.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_$p.json >> $LOG; done
+for p in bf16x6 f32; do timeout 900 python bench.py --precision $p --no-cpu-baseline > gpurun_out/bench_$p.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_$p.json >> $LOG; done
 grep -E "passed|failed|error|exit" $LOG | tail -40
