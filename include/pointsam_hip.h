@@ -4,7 +4,7 @@
  *
  * The reference (zyc00/Point-SAM) has no FFI of its own: its "operator API" for this path is the set of Python
  * call sites into third-party native code and ATen.  Each entry point below names the reference interface it
- * replaces (file:line under the reference checkout).  The Python host (point-sam_amd/ops.py) binds these with
+ * replaces (file:line under the reference checkout).  The Python host (point_sam_amd/ops.py) binds these with
  * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
  *
  * Conventions

@@ -4,7 +4,7 @@ ORACLE -- TEST INFRASTRUCTURE ONLY.
 CPU (PyTorch fp32 + a small C library) restatement of the Point-SAM inference hot path
 (encode + prompt decode), written functionally over a state dict keyed by the reference's parameter
 names.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-this module; the product path (``point-sam_amd/``) never does and fails loudly without its HIP library.
+this module; the product path (``point_sam_amd/``) never does and fails loudly without its HIP library.
 
 What pins it:
   * every pure-PyTorch module of the reference (pc_sam/model/{common,pc_encoder,prompt_encoder,

@@ -1,9 +1,8 @@
-"""Import shim: the package sources live in ``point-sam_amd/`` (a directory name Python cannot
-import directly because of the hyphen); this shim makes them importable as ``point_sam_amd``."""
-import os as _os
+"""point_sam_amd: MI355X-native (gfx950) inference hot path for Point-SAM.
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "point-sam_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _os, _f, _real
+The product path is HIP-only: importing ``point_sam_amd.ops`` (or anything built on it) raises if the
+compiled library ``csrc/libpointsam_hip.so`` is missing.
+"""
+from .config import CONFIGS, ModelConfig, ViTConfig, get_config  # noqa: F401
+
+__version__ = "0.1.0"

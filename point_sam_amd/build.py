@@ -33,12 +33,12 @@ def _stale(out, deps):
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]   # every header: an edit to any rebuilds all objects
     jobs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        if force or _stale(o, [s, hdr, os.path.abspath(__file__)]):
+        if force or _stale(o, [s, os.path.abspath(__file__)] + hdrs):
             jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
     def run(cmd):
         if verbose:

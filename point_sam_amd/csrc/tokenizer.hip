@@ -179,8 +179,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
 // each keeping its 4096 PPT4 points and their running min-distances in registers.  Per iteration every workgroup publishes its
 // local (max min-distance, lowest index) candidate as one 64-bit key, all workgroups of the cloud meet at a counter barrier,
 // and each reduces the W keys itself (same winner everywhere: no second broadcast).  Keys, counter and flags are agent-scope
-// relaxed atomics (device-coherent, no bulk cache maintenance); a workgroup-scope release (plain waitcnt) orders the key store
-// before the arrival.  All B*W workgroups must be resident at once: the host only takes this path when B*W <= number of CUs, i.e.
+// relaxed atomics (device-coherent sc1 accesses on both sides, no bulk cache maintenance); an explicit `s_waitcnt vmcnt(0)` between
+// the key store and the counter increment orders the key before the arrival.  All B*W workgroups must be resident at once: the host only takes this path when B*W <= number of CUs, i.e.
 // half of the 2-per-CU capacity for 1024-thread workgroups, so two such launches may overlap (BatchPipeline issues all tokenizer
 // work on ONE stream, so they never do); more than two concurrent cooperative launches from different streams are not supported.
 // Same arithmetic and tie-break as fps_kernel -> bit-identical indices.
@@ -254,7 +254,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float* __re
                 // key: larger min-distance wins, then the LOWER index; a workgroup of pure padding (v < 0) publishes 0
                 const unsigned long long key = v < 0.f ? 0ull : (((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (0xffffffffu - (unsigned)vi));
                 __hip_atomic_store(cand_b + slot * 64 + w, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the key is acknowledged before the arrival
+                // The key store is a write-through (sc1) store; it must be ACKNOWLEDGED before the arrival is counted.  A workgroup-scope
+                // release fence compiles to lgkmcnt(0) only on gfx950 (the store could still be in flight when another workgroup sees the
+                // counter reach its target), so drain the vector-memory counter explicitly (CDNA4 counts stores in vmcnt); inline asm so
+                // that the compiler cannot drop or move it.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_fetch_add(bar_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = (unsigned)j * (unsigned)W;
                 while (__hip_atomic_load(bar_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);

@@ -58,7 +58,7 @@ class EncoderState:
 class PointCloudSAM:
     """HIP implementation behind the reference's ``PointCloudSAM`` inference interface."""
 
-    def __init__(self, cfg: ModelConfig, state_dict, device="cuda", precision: str = "f32"):
+    def __init__(self, cfg: ModelConfig, state_dict, device="cuda", precision: str = "f16x3"):
         """precision: arithmetic of the large GEMMs (and, for "f16x3", of the encoder attention) --
         "f32": v_mfma_f32_32x32x2_f32, exact fp32 products;
         "bf16x6": exact 3-way bf16 split of both operands, 6 partial products on the bf16 matrix pipe (csrc/gemm_split.hip);
@@ -480,13 +480,21 @@ class BatchPipeline:
             done.record(ds)
         for t in out:
             t.record_stream(main)
-        self.queue.append((out, done))
+        # The inputs were allocated on the caller's stream but are read on tok_stream and ds: hold references until next() has made
+        # the caller's stream wait for `done`, so the caching allocator cannot hand their memory to a later allocation on the
+        # caller's stream while these kernels still read it (and mark them, for callers that drop them right after submit()).
+        keep = tuple(t for t in (coords, features, prompt_coords, prompt_labels, prompt_masks) if isinstance(t, torch.Tensor) and t.is_cuda)
+        for t in keep:
+            t.record_stream(self.tok_stream)
+            t.record_stream(ds)
+        self.queue.append((out, done, keep))
 
     @torch.no_grad()
     def next(self):
         if self.dense:
-            out, done = self.queue.popleft()
+            out, done, keep = self.queue.popleft()
             torch.cuda.current_stream(self.model.device).wait_event(done)
+            del keep
             return out
         tok, ready, coords, features, pc, pl, pm, mm = self.queue.popleft()
         torch.cuda.current_stream(self.model.device).wait_event(ready)

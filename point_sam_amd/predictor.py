@@ -27,7 +27,7 @@ class PointSAMPredictor:
 
     @classmethod
     def from_config(cls, name: str, ckpt_path: str = None, num_groups: int = None, group_size: int = None, seed: int = 42,
-                    device="cuda", precision: str = "f32") -> "PointSAMPredictor":
+                    device="cuda", precision: str = "f16x3") -> "PointSAMPredictor":
         cfg: ModelConfig = get_config(name, num_groups, group_size)
         sd = load_safetensors(cfg, ckpt_path) if ckpt_path else random_state_dict(cfg, seed)
         return cls(PointCloudSAM(cfg, sd, device, precision=precision))

@@ -1,7 +1,7 @@
 """Ablation builds of the pipelined f16x3 kernel (timing only; results are wrong by construction)."""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
-src = open(os.path.join(here, "../../point-sam_amd/csrc/gemm_f16x3.hip")).read()
+src = open(os.path.join(here, "../../point_sam_amd/csrc/gemm_f16x3.hip")).read()
 MFMA = "        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PA[term]], wf[j][PW[term]], acc[i][j], 0, 0, 0);\n    };"
 RELOAD_W = "            if (isw) w[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? offW[i] : OOB, knext * 4, 0));\n"
 RELOAD_A = "            else a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kok ? offA[i] : OOB, knext * 4, 0));\n"
@@ -27,7 +27,7 @@ def variant(n):
 for n in range(9):
     f = os.path.join(here, f"gemm_f16x3_abl{n}.hip")
     open(f, "w").write(variant(n))
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(here, "../../point-sam_amd/csrc"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(here, "../../point_sam_amd/csrc"),
                            "-I" + os.path.join(here, "../../include"), f, "-o", os.path.join(here, f"libgemm_f16x3_abl{n}.so")], stderr=subprocess.DEVNULL)
     os.remove(f)
 print("ok")

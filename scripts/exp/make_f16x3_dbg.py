@@ -1,7 +1,7 @@
 """Generates scripts/exp/gemm_f16x3_dbg.hip from csrc/gemm_f16x3.hip: same kernels + per-workgroup timestamps."""
 import os, re
 here = os.path.dirname(os.path.abspath(__file__))
-s = open(os.path.join(here, "../../point-sam_amd/csrc/gemm_f16x3.hip")).read()
+s = open(os.path.join(here, "../../point_sam_amd/csrc/gemm_f16x3.hip")).read()
 assert "void gemm_f16x3_kernel(const F16x3Args p) {" in s
 s = s.replace("void gemm_f16x3_kernel(const F16x3Args p) {",
               "void gemm_f16x3_kernel(const F16x3Args p, unsigned long long* dbg) {\n"

@@ -232,9 +232,64 @@ def make_forward_case(name, cfg_name, B, N, seed, iters):
     print(name, os.path.getsize(path) // 1024, "KiB", [arrays[f"prompt_labels_{i}"][:, -1].tolist() for i in range(iters)])
 
 
+PLY_DIR = os.path.join(REF, "demo", "static", "models")
+PLY_FILES = ["rhino.ply", "scene.ply", "sixaxis_10000_points.ply", "sixaxis_50000_points.ply", "tiko_10000_points.ply", "tiko_50000_points.ply"]
+
+
+def make_ply_cases(name, cfg_name, G, K, seed):
+    """The reference's only real inputs: demo/static/models/*.ply (ASCII x y z r g b; exact duplicate points inside).  Loaded with the
+    reference's own loader (demo/utils.py:4-29), normalised as its demo does (demo/app.py:116-126: rgb/255, centre at the mean, scale
+    by the max norm, all in float64, then .float()), then through the reference's own modules: KNNGrouper (torch.cdist+topk),
+    PointCloudSAM.predict_masks with one click.  sixaxis_50000_points.ply is byte-identical to sixaxis_10000_points.ply (stored once)."""
+    sys.path.insert(0, os.path.join(REF, "demo"))
+    import importlib
+    load_ply = importlib.import_module("utils").load_ply
+    cfg = get_config(cfg_name, G, K)
+    sd = random_state_dict(cfg, seed=seed)
+    model = build_reference_model(cfg, sd)
+    arrays, seen = {}, {}
+    import hashlib
+    for fi, fname in enumerate(PLY_FILES):
+        raw = open(os.path.join(PLY_DIR, fname), "rb").read()
+        digest = hashlib.md5(raw).hexdigest()
+        key = fname.replace(".ply", "")
+        if digest in seen:
+            arrays[f"{key}__same_as"] = np.array(seen[digest])
+            continue
+        seen[digest] = key
+        pts = load_ply(os.path.join(PLY_DIR, fname))
+        xyz64, rgb_u8 = pts[:, :3], pts[:, 3:6].astype(np.uint8)
+        assert (rgb_u8 == pts[:, 3:6]).all()
+        shift = xyz64.mean(0)
+        scale = np.linalg.norm(xyz64 - shift, axis=-1).max()
+        xyz = torch.from_numpy((xyz64 - shift) / scale).float()[None]
+        rgb = torch.from_numpy(rgb_u8.astype(np.float64) / 255).float()[None]
+        N = xyz.shape[1]
+        uniq = np.unique(xyz[0].numpy(), axis=0).shape[0]
+        g = torch.Generator().manual_seed(seed + fi)
+        pidx = torch.randint(0, N, (1, 1), generator=g)
+        prompt_coords = xyz[0][pidx[0]][None]
+        prompt_labels = torch.ones(1, 1, dtype=torch.int64)
+        with torch.no_grad():
+            emb, patches = model.pc_encoder(xyz, rgb)
+            masks, iou = model.predict_masks(xyz, rgb, prompt_coords, prompt_labels, None, True)
+        arrays.update({f"{key}__xyz": xyz[0].numpy(), f"{key}__rgb_u8": rgb_u8, f"{key}__fps_idx": patches["fps_idx"][0].numpy().astype(np.int32),
+                       f"{key}__knn_idx": patches["knn_idx"][0].numpy().astype(np.int32), f"{key}__pc_embeddings": emb[0].numpy(),
+                       f"{key}__prompt_idx": pidx.numpy(), f"{key}__masks": masks[0].numpy(), f"{key}__iou": iou[0].numpy()})
+        print(fname, "N", N, "distinct points", uniq, "duplicates", N - uniq)
+    meta = dict(cfg=cfg_name, G=G, K=K, seed=seed, files=PLY_FILES, weights_checksum=state_dict_checksum(sd), torch=torch.__version__)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{name}.npz")
+    np.savez_compressed(path, meta=np.array(repr(meta)), **arrays)
+    print(name, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "ply":      # only the demo-PLY fixture
+        make_ply_cases("ref_demo_ply", "tiny", G=128, K=32, seed=13)
+        sys.exit(0)
     make_case("ref_tiny_swiglu", "tiny", B=2, N=1024, M=2, P=2, seed=7)
     make_case("ref_tiny_gelu", "tiny_gelu", B=1, N=777, M=1, P=1, seed=11)
     make_case("ref_tiny_radius", "tiny_radius", B=2, N=900, M=1, P=2, seed=5)
     make_forward_case("ref_tiny_forward_eval", "tiny", B=2, N=1024, seed=7, iters=4)
+    make_ply_cases("ref_demo_ply", "tiny", G=128, K=32, seed=13)

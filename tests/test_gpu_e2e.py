@@ -242,29 +242,113 @@ def test_cfg3_large_scene_tokenizer_and_run(gpu):
     assert m1.shape == (1, 3, N) and torch.isfinite(m1).all() and torch.equal(m1, m2)
 
 
-def test_cfg5_giant_five_click_loop(gpu):
-    """BASELINE config #5 (ViT-giant, N=32768, 512x64, 5 clicks, encoder cached) against the oracle's click loop."""
+_CFG5 = {}
+
+
+def _cfg5_oracle():
+    if not _CFG5:
+        cfg = get_config("giant", 512, 64)
+        sd = random_state_dict(cfg, seed=42)
+        N = 32768
+        xyz, rgb, _, _ = O.synthetic_batch(1, N, seed=42)
+        g = torch.Generator().manual_seed(1)
+        clicks = xyz[:, torch.randint(0, N, (5,), generator=g)]
+        labels = torch.tensor([[1, 1, 0, 1, 0]])
+        _CFG5.update(cfg=cfg, sd=sd, N=N, xyz=xyz, rgb=rgb, clicks=clicks, labels=labels, want=O.click_loop(sd, cfg, xyz, rgb, clicks, labels))
+    return _CFG5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
+def test_cfg5_giant_five_click_loop(gpu, precision):
+    """BASELINE config #5 (ViT-giant, N=32768, 512x64, 5 clicks, encoder cached) against the oracle's click loop, at the shipped
+    default precision ("f16x3": head dim 88 attention included) and at "bf16x6"."""
     from point_sam_amd.predictor import PointSAMPredictor
-    cfg = get_config("giant", 512, 64)
-    sd = random_state_dict(cfg, seed=42)
-    N = 32768
-    xyz, rgb, _, _ = O.synthetic_batch(1, N, seed=42)
-    g = torch.Generator().manual_seed(1)
-    clicks = xyz[:, torch.randint(0, N, (5,), generator=g)]
-    labels = torch.tensor([[1, 1, 0, 1, 0]])
-    want = O.click_loop(sd, cfg, xyz, rgb, clicks, labels)
-    pred = PointSAMPredictor(gpu(cfg, sd, precision="bf16x6"))
+    c = _cfg5_oracle()
+    cfg, sd, N, xyz, rgb, clicks, labels, want = (c[k] for k in ("cfg", "sd", "N", "xyz", "rgb", "clicks", "labels", "want"))
+    pred = PointSAMPredictor(gpu(cfg, sd, precision=precision))
     xyz_d, rgb_d = xyz.cuda(), rgb.cuda()
     prompt_mask = None
     for t in range(5):
         pred.set_pointcloud(xyz_d, rgb_d)
         mask, scores, logits = pred.predict_masks(clicks[:, : t + 1].cuda(), labels[:, : t + 1].cuda(), prompt_mask, prompt_mask is None)
         e = _maxerr(logits, want[t][0])
-        print(f"\n[giant click {t + 1}] max|err| {e:.2e}")
+        print(f"\n[giant {precision} click {t + 1}] max|err| {e:.2e}")
         assert e < TOL and _maxerr(scores, want[t][1]) < TOL
         # the oracle feeds ITS best mask forward; do the same so both loops see identical prompts
         wm, wi = want[t]
         prompt_mask = (torch.gather(wm, 1, wi.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0] if t == 0 else wm[:, 0]).cuda()
+
+
+def test_cfg3_large_full_model_vs_oracle(gpu):
+    """BASELINE config #3 with the REAL ViT-L (configs/large.yaml geometry of evaluation/eval_kitti.py:352-354: 2048 groups of 256,
+    N = 131072, batch 1) at the shipped precision: encoder embeddings (attention over L = 2048 tokens), logits and IoU against the
+    oracle; tokenizer indices bit-exact over the whole cloud."""
+    cfg = get_config("large", 2048, 256)
+    sd = random_state_dict(cfg, seed=42)
+    N = 131072
+    xyz, rgb, prompt, labels = O.synthetic_batch(1, N, seed=3)
+    want_masks, want_iou, mid = O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="exact", return_intermediates=True)
+    model = gpu(cfg, sd, precision="f16x3")
+    st = model.encode(xyz.cuda(), rgb.cuda())
+    assert torch.equal(st.fps_idx.cpu(), mid["patches"]["fps_idx"]), "FPS indices not bit-exact"
+    assert torch.equal(st.knn_idx.cpu(), mid["patches"]["knn_idx"]), "kNN indices not bit-exact"
+    masks, iou = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+    model.check_coordinate_range()
+    assert torch.equal(st.interp_index.cpu(), mid["aux"].interp_index), "3-NN indices not bit-exact"
+    e_emb, e_m, e_i = _maxerr(st.pc_embeddings, mid["pc_embeddings"]), _maxerr(masks, want_masks), _maxerr(iou, want_iou)
+    print(f"\n[cfg3 large 131072 2048x256 f16x3] max|err| embeddings {e_emb:.2e} masks {e_m:.2e} iou {e_i:.2e} (|logit| max {want_masks.abs().max():.2f})")
+    assert e_emb < TOL and e_m < TOL and e_i < TOL
+
+
+def test_cfg2_gap_to_reference_cdist_mode(gpu):
+    """north_star states the tolerance against the REFERENCE CPU path, whose kNN / 3-NN go through torch.cdist + topk
+    (pc_sam/model/common.py:51-55, 238-255) while the HIP kernels use direct fp32 differences.  At BASELINE config #2's full
+    single-cloud size: fraction of groups with the identical neighbour set, fraction of points with the identical 3-NN set, and
+    the logit gap HIP (shipped precision) vs oracle mode="reference" -- asserted below 1e-3."""
+    cfg = get_config("large", 512, 64)
+    sd = random_state_dict(cfg, seed=42)
+    N = 32768
+    xyz, rgb, prompt, labels = O.synthetic_batch(1, N, seed=42)
+    ref_masks, ref_iou, mid = O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="reference", return_intermediates=True)
+    model = gpu(cfg, sd, precision="f16x3")
+    st = model.encode(xyz.cuda(), rgb.cuda())
+    masks, iou = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+    assert torch.equal(st.fps_idx.cpu(), mid["patches"]["fps_idx"])
+    knn_same = (st.knn_idx.cpu().sort(-1).values == mid["patches"]["knn_idx"].sort(-1).values).all(-1).float().mean().item()
+    nn3_same = (st.interp_index.cpu().sort(-1).values == mid["aux"].interp_index.sort(-1).values).all(-1).float().mean().item()
+    gap_m, gap_i = _maxerr(masks, ref_masks), _maxerr(iou, ref_iou)
+    print(f"\n[cfg2 vs reference cdist mode] groups with identical kNN set {knn_same:.4f}, points with identical 3-NN set {nn3_same:.5f}, "
+          f"logit gap {gap_m:.2e}, iou gap {gap_i:.2e}")
+    assert knn_same > 0.98 and nn3_same > 0.995
+    assert gap_m < TOL and gap_i < TOL, (gap_m, gap_i)
+
+
+def test_against_reference_demo_plys(gpu, golden_ply):
+    """The reference's only real inputs (demo/static/models/*.ply; up to 7276 exact duplicate points) run through the reference's
+    own modules (tests/golden/make_golden.py::make_ply_cases): FPS indices bit-identical on all six, neighbour sets equal up to
+    exact ties (duplicate points), encoder embeddings and logits within tolerance."""
+    from conftest import ply_cases
+    meta, _ = golden_ply
+    cfg = get_config(meta["cfg"], meta["G"], meta["K"])
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    assert state_dict_checksum(sd) == pytest.approx(meta["weights_checksum"], rel=1e-12)
+    model = gpu(cfg, sd, precision="f16x3")
+    for key, xyz, rgb, a in ply_cases(golden_ply):
+        st = model.encode(xyz.cuda(), rgb.cuda())
+        assert torch.equal(st.fps_idx.cpu()[0].to(torch.int32), a["fps_idx"]), f"{key}: FPS indices differ"
+        got, want = st.knn_idx.cpu()[0].sort(-1).values, a["knn_idx"].long().sort(-1).values
+        diff = (got != want).any(-1)
+        if bool(diff.any()):   # neighbour sets may differ only by points at EXACTLY the same distance (duplicates) or within cdist's rounding
+            c = st.centers.cpu()[0].double()
+            def d2(idx):
+                return ((xyz[0].double()[idx] - c[:, None, :]) ** 2).sum(-1).sort(-1).values
+            assert (d2(got)[diff] - d2(want)[diff]).abs().max() < 1e-6, f"{key}: kNN sets differ beyond ties"
+        prompt = xyz[0][a["prompt_idx"][0].long()][None].cuda()
+        masks, iou = model.decode(st, prompt, torch.ones(1, 1, dtype=torch.int64, device="cuda"), None, True)
+        e_emb, e_m, e_i = _maxerr(st.pc_embeddings[0], a["pc_embeddings"]), _maxerr(masks[0], a["masks"]), _maxerr(iou[0], a["iou"])
+        print(f"\n[{key}] N={xyz.shape[1]} groups with a different (tied) neighbour set {int(diff.sum())}/{len(diff)}; max|err| emb {e_emb:.2e} masks {e_m:.2e} iou {e_i:.2e}")
+        assert e_m < TOL and e_i < TOL and e_emb < TOL, key
+    model.check_coordinate_range()
 
 
 def test_forward_eval_protocol(gpu, golden_forward):

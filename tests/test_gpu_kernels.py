@@ -75,6 +75,31 @@ def test_fps_cooperative_bit_exact(ops, B, N, G, dup):
     assert torch.equal(idx1, idx)
 
 
+def test_fps_cooperative_under_memory_load(ops):
+    """The cooperative FPS exchanges keys between workgroups through device memory; run it several times while another stream
+    saturates HBM / the fabric with large copies and GEMMs (uneven load is what exposes an unordered key store vs barrier arrival)
+    -- every run must still give the oracle's indices bit for bit."""
+    B, N, G = 2, 131072, 600
+    xyz, _ = _cloud(B, N, seed=77)
+    want = O.fps(xyz, G)
+    x = cu(xyz)
+    big = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    a = torch.randn(4096, 1024, device="cuda")
+    w = torch.randn(3072, 1024, device="cuda")
+    side = torch.cuda.Stream()
+    stop = torch.cuda.Event()
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big[: 256 << 20].copy_(big[256 << 20:], non_blocking=True)
+                with ops.gemm_mode("f16x3"):
+                    ops.linear(a, w)
+        idx, _ = ops.fps(x, G)
+        stop.record()
+        assert torch.equal(idx.cpu(), want), f"run {rep}: cooperative FPS under load differs from the oracle"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("B,N,G,K,dup", [(2, 1024, 32, 16, 0), (1, 777, 32, 16, 0), (2, 4096, 128, 32, 0), (1, 32768, 96, 64, 0),
                                          (1, 5000, 64, 64, 2500), (1, 3000, 16, 256, 0), (1, 100, 8, 100, 40), (1, 20000, 32, 1000, 0)])
 def test_knn_bit_exact(ops, B, N, G, K, dup):
@@ -484,7 +509,8 @@ def _sdpa(q, k, v, H, scale):
 
 
 @pytest.mark.parametrize("hd,H,Lq,Lk", [(64, 2, 128, 128), (64, 3, 512, 512), (32, 2, 32, 32), (24, 4, 100, 100), (88, 2, 200, 200),
-                                        (16, 2, 70, 333), (64, 1, 5, 64), (48, 1, 129, 65), (128, 1, 64, 96), (96, 1, 33, 31)])
+                                        (16, 2, 70, 333), (64, 1, 5, 64), (48, 1, 129, 65), (128, 1, 64, 96), (96, 1, 33, 31),
+                                        (64, 2, 2048, 2048), (88, 1, 2048, 2048)])
 def test_flash_attention(ops, hd, H, Lq, Lk):
     g = torch.Generator().manual_seed(hd + Lq)
     B, D = 2, H * hd
@@ -498,7 +524,8 @@ def test_flash_attention(ops, hd, H, Lq, Lk):
     _close(out.view(B, Lq, D), want, 2e-5, what=f"flash hd={hd}")
 
 
-@pytest.mark.parametrize("hd,H,Lq,Lk", [(64, 4, 512, 512), (64, 2, 130, 70), (64, 3, 33, 200), (128, 2, 200, 129), (64, 1, 5, 64)])
+@pytest.mark.parametrize("hd,H,Lq,Lk", [(64, 4, 512, 512), (64, 2, 130, 70), (64, 3, 33, 200), (128, 2, 200, 129), (64, 1, 5, 64),
+                                        (64, 2, 2048, 2048), (64, 1, 1000, 2048)])
 def test_flash_attention_f16x3(ops, hd, H, Lq, Lk):
     """fp16-split flash attention: same tolerance as the f32-MFMA kernel against an fp64 SDPA; q/k/v with very different
     magnitudes per tensor and per row (the scales are per query row / per 64-key tile)."""
