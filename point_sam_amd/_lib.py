@@ -48,6 +48,9 @@ SIGNATURES = {
     "psam_gemm_f16x3_workspace_bytes": (size_t, []),
     "psam_gemm_f16x3_ws": (i32, [ptr, i64, ptr, i32, ptr, i64, ptr, i32, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, size_t,
                                  ctypes.c_uint32, ptr]),
+    "psam_pack_rows_f16x2_g8": (i32, [ptr, i64, ptr, i32, i32, ptr, i64, ptr]),
+    "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
+    "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3_force_config": (None, [i32]),
     "psam_gemm_f16x3_force_deep": (None, [i32]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),

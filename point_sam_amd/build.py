@@ -22,6 +22,7 @@ SOURCES = [
     ("gemm_split.hip", []),
     ("gemm_packw.hip", []),
     ("gemm_f16x3.hip", []),
+    ("gemm_f16x3p.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("error.cpp", ["-x", "hip"]),

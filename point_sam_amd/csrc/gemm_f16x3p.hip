@@ -1,0 +1,312 @@
+// fp32-GRADE GEMM on the fp16 matrix pipe, both operands PRE-PACKED ("f16x3p"): the production kernel of the large GEMMs.
+//
+//   C = act(alpha * A @ W^T + bias + rowbias[row / rowgroup]) + residual          (contract and epilogues of gemm.hip, 2-D form)
+//
+// Arithmetic = gemm_f16x3.hip: every operand row is scaled by a power of two (row maximum in [2^14, 2^15)) and every element split
+// into hi + lo fp16; a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation, un-scaled in the epilogue.
+// What is new is the data path.  Both operands arrive in the "g8" packed form (psam_pack_rows_f16x2_g8, the LayerNorm / attention /
+// GEMM-epilogue producers): the container is still one 32-bit word per element, and every group of 8 consecutive k holds
+//      [hi k0..k7 : 8 x fp16 = 16 B][lo k0..k7 : 16 B]
+// so one 16-byte chunk IS one matrix-instruction operand (8 k of one row).  With nothing left to compute while staging, a K slab
+// moves global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write, no VALU in the main loop.
+//
+//   * slab = 32 k = 128 B per row; LDS stage = [BM rows of A | BN rows of W] x 128 B; chunk c of row r is stored at position
+//     c ^ ((r >> 1) & 7)  -> every ds_read_b128 lane group touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+//     The DMA writes LDS linearly (wave base + lane * 16), so the swizzle is applied to the per-lane SOURCE address; each wave
+//     instruction fetches 8 whole 128-byte lines.
+//   * ring of S stages, ONE raw s_barrier per slab, counted vmcnt: at slab t every wave waits for its own pieces of slab t (+LA),
+//     the barrier publishes them and retires every read of slab t-1, then the pieces of slab t+S-1 are issued into the stage slab
+//     t-1 occupied -- S-1 slab times for the data to land.  LA = 1: the barrier of slab t also guarantees slab t+1, so the first
+//     fragments of slab t+1 are read under the last MFMAs of slab t (no fragment latency exposed after the barrier).
+//   * fragments double-buffered over the two k16 steps of a slab; one MFMA per issue slot with one ds_read / one DMA issue behind it.
+//   * epilogue: gemm_epilogue.h (LDS transposition, float4 rows).
+// Tile shapes (waves WM x WN, each TM x TN accumulator tiles of 32x32) and S are template parameters; the host picks per shape.
+#include <type_traits>
+#include "common.h"
+#include "gemm_epilogue.h"
+
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+
+struct F16PArgs {
+    const unsigned char* A; const unsigned char* W; float* C;
+    const float* bias; const float* residual; const float* rowbias;
+    const float* scaleA; const float* scaleW;
+    int64_t lda, ldw, ldc, ldr, ldrb;     // lda / ldw in 32-bit containers
+    int M, N, K, rowgroup, act;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+#define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+// LDS-DMA of 16 bytes per lane: LDS[dst + lane * 16] = buffer[voff(lane) + soff].  The builtin exists only in the device compilation
+// (the host pass of this translation unit must still parse the kernel template to emit its launch stub).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P_DMA16(rsrc, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, P_LDS(dst), 16, voff, soff, 0, 0)
+#else
+#define P_DMA16(rsrc, dst, voff, soff) ((void)(rsrc), (void)(dst), (void)(voff), (void)(soff))
+#endif
+
+template <int WM, int WN, int TM, int TN, int S, int LA>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArgs p) {
+    constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int ROWB = 128;                                   // bytes per row per slab (32 k x 4 B)
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int NBLK = STAGE / 1024, A_BLK = A_BYTES / 1024;  // 1 KiB DMA pieces (8 rows) per slab
+    static_assert(NBLK % NW == 0, "pieces divide among the waves");
+    constexpr int NL = NBLK / NW;                               // DMA instructions per wave per slab
+    static_assert(S >= 2 && LA >= 0 && LA <= 1 && S - 2 - LA >= 0, "ring depth");
+    constexpr int NFR = 2 * (TM + TN);                          // fragment reads per k16 step
+    constexpr int NMF = 3 * TM * TN;                            // MFMAs per k16 step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- tile of this workgroup: XCD-contiguous ranges of the row-major tile order (consecutive workgroup ids go to different XCDs)
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int tile = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, x = tile & 7, y = tile >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // ---- DMA source offsets: piece b = wave + i NW covers rows 8b..8b+7 of the stage; lane -> (row b*8 + lane/8, slot lane%8),
+    // which must receive chunk slot ^ swz(row) of that row.  Rows past M / N are clamped (their products are never stored).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda * 4), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw * 4), 0, 0x7fffffff, 0x00020000);
+    int voff[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int b = wave + i * NW;
+        const bool isw = b >= A_BLK;
+        const int row = (isw ? b - A_BLK : b) * 8 + (lane >> 3);            // row inside its operand's region
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int lim = isw ? p.N - n0 : p.M - m0;
+        const int rc = row < lim ? row : lim - 1;
+        voff[i] = (int)((int64_t)rc * (isw ? p.ldw : p.lda) * 4) + chunk * 16;
+    }
+    auto issue = [&](int slab, int stage) {     // DMA the wave's NL pieces of `slab` into ring stage `stage`
+        const int koff = slab * ROWB;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int b = wave + i * NW;
+            unsigned char* dst = smem + stage * STAGE + b * 1024;
+            if (b >= A_BLK) P_DMA16(rsW, dst, voff[i], koff);
+            else P_DMA16(rsA, dst, voff[i], koff);
+        }
+    };
+    auto issue_one = [&](int i, int slab, int stage) {
+        const int b = wave + i * NW;
+        unsigned char* dst = smem + stage * STAGE + b * 1024;
+        if (b >= A_BLK) P_DMA16(rsW, dst, voff[i], slab * ROWB);
+        else P_DMA16(rsA, dst, voff[i], slab * ROWB);
+    };
+
+    // ---- fragment offsets inside a stage: row r32 of a 32-row tile, chunk 4 s + 2 h + q (s = k16 step, q = hi / lo plane)
+    int fa_off[2][2], fw_off[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = r32 * ROWB + (((4 * s + 2 * h + q) ^ ((r32 >> 1) & 7)) << 4);
+            fa_off[s][q] = wm * TM * 32 * ROWB + f;
+            fw_off[s][q] = A_BYTES + wn * TN * 32 * ROWB + f;
+        }
+
+    pf32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    pf16x8 f0a[TM][2], f0w[TN][2], f1a[TM][2], f1w[TN][2];
+    // fragment read n in [0, NFR) of step s from `stage`: n -> (operand, tile, plane)
+    auto read_frag = [&](int n, int s, int stage, pf16x8 (&fa)[TM][2], pf16x8 (&fw)[TN][2]) {
+        const unsigned char* base = smem + stage * STAGE;
+        if (n < 2 * TM) { const int i = n >> 1, q = n & 1; fa[i][q] = *reinterpret_cast<const pf16x8*>(base + fa_off[s][q] + i * 32 * ROWB); }
+        else { const int m = n - 2 * TM, j = m >> 1, q = m & 1; fw[j][q] = *reinterpret_cast<const pf16x8*>(base + fw_off[s][q] + j * 32 * ROWB); }
+    };
+    auto mfma = [&](int m, const pf16x8 (&fa)[TM][2], const pf16x8 (&fw)[TN][2]) {     // m in [0, NMF): term-major (hi*lo, lo*hi, hi*hi)
+        constexpr int PA[3] = {0, 1, 0}, PW[3] = {1, 0, 0};
+        const int term = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[term]], fw[j][PW[term]], acc[i][j], 0, 0, 0);
+    };
+
+    const int nslabs = p.K / 32;
+    // ---- prologue: S-1 slabs in flight
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u) issue(u, u);
+    if (LA) {   // slab 0 visible, its first fragments in registers
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (S - 2)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int n = 0; n < NFR; ++n) read_frag(n, 0, 0, f0a, f0w);
+    }
+    int st = 0;                    // ring stage of the current slab
+    // One slab.  WAITN: DMA instructions of later slabs that may stay in flight at the wait; DO_ISSUE: a slab t+S-1 exists.
+    auto body = [&](int t, auto waitn_c, auto issue_c, auto next_c) {
+        constexpr int WAITN = decltype(waitn_c)::value;
+        constexpr bool DO_ISSUE = decltype(issue_c)::value, HAS_NEXT = decltype(next_c)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        const int st_issue = st == 0 ? S - 1 : st - 1;          // stage of slab t-1 = stage of slab t+S-1
+        const int st_next = st == S - 1 ? 0 : st + 1;
+        if (!LA) {
+#pragma unroll
+            for (int n = 0; n < NFR; ++n) read_frag(n, 0, st, f0a, f0w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // step 0: NMF MFMAs; behind them the NFR fragment reads of step 1 (all of them: step 1 needs them), then DMA issues
+        constexpr int P0 = (NFR + NMF - 1) / NMF;                               // extra operations per MFMA slot in step 0
+        constexpr int D0 = NMF * P0 - NFR < NL ? NMF * P0 - NFR : NL;            // DMA issues placed in step 0
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            mfma(m, f0a, f0w);
+#pragma unroll
+            for (int k = m * P0; k < (m + 1) * P0; ++k) {
+                if (k < NFR) read_frag(k, 1, st, f1a, f1w);
+                else if (DO_ISSUE && k - NFR < NL) issue_one(k - NFR, t + S - 1, st_issue);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // step 1: NMF MFMAs; behind them the rest of the DMA issues and (LA) the first fragments of the next slab
+        constexpr int REST = NL - D0, N1 = REST + (LA ? NFR : 0), P1 = N1 > 0 ? (N1 + NMF - 1) / NMF : 1;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            mfma(m, f1a, f1w);
+#pragma unroll
+            for (int k = m * P1; k < (m + 1) * P1; ++k) {
+                if (k < REST) { if (DO_ISSUE) issue_one(D0 + k, t + S - 1, st_issue); }
+                else if (LA && HAS_NEXT && k - REST < NFR) read_frag(k - REST, 0, st_next, f0a, f0w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st = st_next;
+    };
+    using std::integral_constant;
+    int t = 0;
+    for (; t + (S - 1) < nslabs; ++t) body(t, integral_constant<int, NL*(S - 2 - LA)>{}, integral_constant<bool, true>{}, integral_constant<bool, true>{});
+    // tail: the last S-1 slabs issue nothing; the number of DMAs that may remain in flight shrinks step by step
+    if constexpr (S >= 2) {
+        // slabs nslabs-(S-1) .. nslabs-1; at tail position j (0-based) the slabs still in flight after the needed one(s): S-2-j-LA
+        auto tail = [&](auto j_c) {
+            constexpr int j = decltype(j_c)::value;
+            constexpr int left = S - 2 - j - LA;
+            body(t, integral_constant<int, (left > 0 ? left : 0) * NL>{}, integral_constant<bool, false>{}, integral_constant<bool, (j < S - 2)>{});
+            ++t;
+        };
+        if constexpr (S >= 2) tail(integral_constant<int, 0>{});
+        if constexpr (S >= 3) tail(integral_constant<int, 1>{});
+        if constexpr (S >= 4) tail(integral_constant<int, 2>{});
+        if constexpr (S >= 5) tail(integral_constant<int, 3>{});
+        static_assert(S <= 5, "tail unrolled for S <= 5");
+    }
+
+    // ---- epilogue (gemm_epilogue.h): every wave is done with the ring, no DMA in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+                                  n0 + wn * TN * 32, lane, p.C, p.residual);
+}
+
+// ---------------------------------------------------------------------------------------------- g8 packing of an fp32 matrix
+// P[r, 8g .. 8g+7] (32-bit containers) = [hi(8 x fp16) | lo(8 x fp16)] of scale[r] * X[r, 8g .. 8g+7]; columns K .. Kp-1 (Kp = K rounded
+// up to 32, the GEMM's slab) are written as zeros.  In place (P == X, ldp == ldx) is allowed when K % 8 == 0.
+__global__ __launch_bounds__(256) void pack_rows_g8_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ scale, int rows,
+                                                           int K, int g8n, unsigned* __restrict__ P, int64_t ldp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)rows * g8n) return;
+    const int r = (int)(t / g8n), g = (int)(t % g8n);
+    const float* x = X + (int64_t)r * ldx + g * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g * 8 + e < K ? x[e] : 0.f;
+    const float s = scale[r];
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) psam_split2_f16(v[2 * e], v[2 * e + 1], s, hi[e], lo[e]);
+    unsigned* o = P + (int64_t)r * ldp + g * 8;
+    *reinterpret_cast<pu32x4*>(o) = pu32x4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<pu32x4*>(o + 4) = pu32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+PSAM_API int32_t psam_pack_rows_f16x2_g8(const float* X, int64_t ldx, const float* scale, int32_t rows, int32_t K, void* P, int64_t ldp,
+                                         hipStream_t stream) {
+    PSAM_REQUIRE(X && scale && P, PSAM_EINVAL, "psam_pack_rows_f16x2_g8: null pointer");
+    const int Kp = (K + 31) / 32 * 32;
+    PSAM_REQUIRE(rows > 0 && K > 0 && ldx >= K && ldp >= Kp, PSAM_EINVAL, "psam_pack_rows_f16x2_g8: bad shape (ldp >= K rounded up to 32)");
+    PSAM_REQUIRE((ldp & 7) == 0 && ((uintptr_t)P & 31) == 0, PSAM_EALIGN, "psam_pack_rows_f16x2_g8: packed rows must be 32-byte aligned");
+    PSAM_REQUIRE((const void*)X != (const void*)P || (ldx == ldp && (K & 7) == 0), PSAM_EINVAL, "psam_pack_rows_f16x2_g8: in place needs ldp == ldx, K % 8 == 0");
+    const int64_t total = (int64_t)rows * (Kp / 8);
+    hipLaunchKernelGGL(pack_rows_g8_kernel, dim3((unsigned)psam_cdiv(total, 256)), dim3(256), 0, stream, X, ldx, scale, rows, K, Kp / 8, (unsigned*)P, ldp);
+    return psam_launch_status("psam_pack_rows_f16x2_g8: launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------- host
+static int g_f16x3p_cfg = -1;
+PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
+
+template <int WM, int WN, int TM, int TN, int S, int LA>
+static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
+    constexpr int ring = S * (BM + BN) * 128, epi = NW * gemm_epilogue_lds_floats_per_wave<TN>() * 4;
+    constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    p.tiles_m = (int)psam_cdiv(p.M, BM);
+    p.tiles_n = (int)psam_cdiv(p.N, BN);
+    static bool attr_done = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
+            return PSAM_EINVAL;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * NW), lds, stream, p);
+    return psam_launch_status("psam_gemm_f16x3p: launch failed");
+}
+
+// A [M, K] and W [N, K]: g8-packed, row-scaled (scaleA[M], scaleW[N] powers of two); K % 32 == 0 (pad with zeros), K >= 128.
+PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C,
+                                  int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
+                                  int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, hipStream_t stream) {
+    PSAM_REQUIRE(A && W && C && scaleA && scaleW, PSAM_EINVAL, "psam_gemm_f16x3p: null pointer");
+    PSAM_REQUIRE(M > 0 && N > 0 && K >= 128 && (K & 31) == 0, PSAM_EINVAL, "psam_gemm_f16x3p: bad shape (K % 32 == 0, K >= 128)");
+    PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_f16x3p: bad activation code");
+    PSAM_REQUIRE(!rowbias || rowgroup > 0, PSAM_EINVAL, "psam_gemm_f16x3p: rowbias needs rowgroup > 0");
+    PSAM_REQUIRE((lda & 7) == 0 && (ldw & 7) == 0 && ((uintptr_t)A & 31) == 0 && ((uintptr_t)W & 31) == 0, PSAM_EALIGN,
+                 "psam_gemm_f16x3p: packed rows must be 32-byte aligned (lda, ldw multiples of 8)");
+    PSAM_REQUIRE((int64_t)256 * lda * 4 + K * 4 < ((int64_t)1 << 31) && (int64_t)256 * ldw * 4 + K * 4 < ((int64_t)1 << 31), PSAM_EINVAL,
+                 "psam_gemm_f16x3p: leading dimension too large for 32-bit tile offsets");
+    PSAM_REQUIRE(act != 3 || ((N & 63) == 0 && !residual && !rowbias), PSAM_EINVAL, "psam_gemm_f16x3p: SwiGLU epilogue needs N % 64 == 0, no residual/rowbias");
+    F16PArgs p;
+    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias;
+    p.scaleA = scaleA; p.scaleW = scaleW; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
+    p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
+    int cfg = g_f16x3p_cfg;
+    if (cfg < 0) cfg = 0;
+    switch (cfg) {
+        case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);     // 128x128, 4 waves, 2 stages (64 KiB): 2 workgroups per CU
+        case 1: return launch_f16x3p<2, 2, 2, 2, 3, 0>(p, stream);     // 128x128, 3 stages (96 KiB)
+        case 2: return launch_f16x3p<2, 2, 2, 2, 3, 1>(p, stream);     // ... with look-ahead fragments
+        case 3: return launch_f16x3p<2, 2, 2, 2, 4, 1>(p, stream);     // 128x128, 4 stages (128 KiB)
+        case 4: return launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream);     // 256x128, 8 waves, 3 stages (144 KiB)
+        case 5: return launch_f16x3p<4, 2, 2, 2, 3, 1>(p, stream);
+        case 6: return launch_f16x3p<2, 4, 2, 2, 3, 1>(p, stream);     // 128x256, 8 waves
+        case 7: return launch_f16x3p<4, 2, 2, 2, 2, 0>(p, stream);     // 256x128, 2 stages (96 KiB)
+        case 8: return launch_f16x3p<4, 2, 1, 2, 2, 0>(p, stream);     // 128x128 with 8 waves of 32x64 (70 KiB): 2 workgroups = 16 waves per CU
+        case 9: return launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);     // ... 4 stages (128 KiB): 1 workgroup of 8 waves
+        case 10: return launch_f16x3p<2, 2, 2, 1, 2, 0>(p, stream);    // 128x64, 4 waves of 64x32, 2 stages (48 KiB): 3 workgroups per CU
+        case 11: return launch_f16x3p<2, 2, 2, 1, 3, 1>(p, stream);    // 128x64, 3 stages (72 KiB): 2 per CU
+        default: break;
+    }
+    psam_set_error("psam_gemm_f16x3p: unknown config");
+    return PSAM_EINVAL;
+}

@@ -1,0 +1,139 @@
+"""f16x3p GEMM (g8-packed operands, LDS-DMA ring): correctness vs fp64 and timing of every tile / ring configuration on the
+encoder shapes, next to the round-1 kernel (psam_gemm_f16x3_ex, both operands packed).  GPU box:  python scripts/gemm_p_bench.py [cfgs]"""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from point_sam_amd import ops
+L = ops._lib.load()
+st = lambda: torch.cuda.current_stream().cuda_stream
+CFGS = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(12))
+NAMES = {0: "128x128 4w S2", 1: "128x128 4w S3", 2: "128x128 4w S3 LA", 3: "128x128 4w S4 LA", 4: "256x128 8w S3", 5: "256x128 8w S3 LA",
+         6: "128x256 8w S3 LA", 7: "256x128 8w S2", 8: "128x128 8w(32x64) S2", 9: "128x128 8w(32x64) S4 LA", 10: "128x64 4w S2", 11: "128x64 4w S3 LA"}
+
+
+def pack_g8(x, s):
+    M, K = x.shape
+    Kp = (K + 31) // 32 * 32
+    out = torch.empty(M, Kp, device="cuda")
+    ops.check(L.psam_pack_rows_f16x2_g8(x.data_ptr(), x.stride(0), s.data_ptr(), M, K, out.data_ptr(), Kp, st()), "pack g8")
+    return out
+
+
+def run_p(cfg, xp, sa, wp, sw, y, M, N, K, bias=None, res=None, act=0, rowbias=None, rowgroup=0):
+    L.psam_gemm_f16x3p_force_config(cfg)
+    ops.check(L.psam_gemm_f16x3p(xp.data_ptr(), xp.stride(0), sa.data_ptr(), wp.data_ptr(), wp.stride(0), sw.data_ptr(), y.data_ptr(), y.stride(0),
+                                 ops._p(bias), ops._p(res), 0 if res is None else res.stride(0), ops._p(rowbias), 0 if rowbias is None else rowbias.stride(0),
+                                 rowgroup, M, N, K, 1.0, act, st()), "gemm p")
+
+
+def correctness():
+    g = torch.Generator(device="cuda").manual_seed(1)
+    bad = 0
+    for (M, N, K, act) in [(300, 200, 160, 1), (129, 257, 128, 0), (512, 384, 1024, 0), (256, 256, 128, 3), (1000, 640, 96 * 3, 3), (4096, 1024, 2752, 0)]:
+        x = torch.randn(M, K, device="cuda", generator=g) * torch.exp(2 * torch.randn(M, 1, device="cuda", generator=g))
+        W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        bias = torch.randn(N, device="cuda", generator=g)
+        res = None if act == 3 else torch.randn(M, N, device="cuda", generator=g)
+        sa, sw = ops.row_scale_f16(x), ops.row_scale_f16(W)
+        xp, wp = pack_g8(x, sa), pack_g8(W, sw)
+        Kp = xp.shape[1]
+        ref = x.double() @ W.double().T + bias.double()
+        if act == 3:   # weight rows alternate 32-row blocks of gate / value
+            r = ref.view(M, N // 64, 2, 32)
+            ref = (torch.nn.functional.silu(r[:, :, 0]) * r[:, :, 1]).reshape(M, N // 2)
+        else:
+            if act == 1:
+                ref = torch.nn.functional.gelu(ref)
+            ref = ref + res.double()
+        for cfg in CFGS:
+            if act == 3 and cfg in (10, 11):
+                continue
+            y = torch.full((M, N // 2 if act == 3 else N), float("nan"), device="cuda")
+            run_p(cfg, xp, sa, wp, sw, y, M, N, Kp, bias=bias, res=res, act=act)
+            err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+            ok = err < 3e-6
+            bad += not ok
+            print(f"check {M}x{N}x{K} act{act} cfg{cfg:2d}: rel err {err:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+    return bad
+
+
+def timeit(fns, rounds=5, iters=20):
+    """fns: dict name -> callable; interleaved rounds; returns name -> (min us, median us) per call"""
+    for f in fns.values():
+        for _ in range(3):
+            f()
+    res = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, f in fns.items():
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); s.record()
+            for _ in range(iters):
+                f()
+            e.record(); torch.cuda.synchronize()
+            res[k].append(s.elapsed_time(e) * 1000 / iters)
+    return {k: (min(v), statistics.median(v)) for k, v in res.items()}
+
+
+SHAPES = [("qkv", 4096, 3072, 1024, 0), ("proj", 4096, 1024, 1024, 0), ("fc1", 4096, 5504, 1024, 3), ("fc2", 4096, 1024, 2752, 0),
+          ("pe_conv2.3", 262144, 512, 512, 0), ("up.3", 262144, 256, 256, 1)]
+
+
+def main():
+    bad = correctness()
+    print("correctness failures:", bad, flush=True)
+    data = {}
+    for name, M, N, K, act in SHAPES:
+        x = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5
+        y = torch.empty(M, N // 2 if act == 3 else N, device="cuda")
+        bias = torch.randn(N, device="cuda")
+        res = torch.randn(M, N, device="cuda") if name in ("proj", "fc2") else None
+        sa, sw = ops.row_scale_f16(x), ops.row_scale_f16(W)
+        xp, wp = pack_g8(x, sa), pack_g8(W, sw)
+        xo, wo = ops.pack_rows_f16x2(x, sa), ops.pack_rows_f16x2(W, sw)
+        data[name] = (xp, sa, wp, sw, y, M, N, K, bias, res, act)
+        fns = {"old": (lambda: L.psam_gemm_f16x3_ex(xo.data_ptr(), K, sa.data_ptr(), 1, wo.data_ptr(), K, sw.data_ptr(), 1, y.data_ptr(), y.stride(0),
+                                                    bias.data_ptr(), ops._p(res), 0 if res is None else N, 0, 0, 0, M, N, K, 1.0, act, st()))}
+        for cfg in CFGS:
+            if act == 3 and cfg in (10, 11):
+                continue
+            fns[f"c{cfg}"] = (lambda cfg=cfg: run_p(cfg, xp, sa, wp, sw, y, M, N, K, bias=bias, res=res, act=act))
+        r = timeit(fns, rounds=4, iters=10 if M > 100000 else 20)
+        gf = 2.0 * M * N * K
+        line = f"{name:10s} {M}x{N}x{K}:"
+        for k, (mn, md) in r.items():
+            line += f" {k} {mn:6.1f}us {gf / mn / 1e6:4.0f}TF |"
+        print(line, flush=True)
+    # one encoder layer's four GEMMs back to back, on one stream and on two streams at once (the bench keeps two batches in flight)
+    layer = ["qkv", "proj", "fc1", "fc2"]
+    s2 = torch.cuda.Stream()
+    def layer_run(cfgmap):
+        for nm in layer:
+            xp, sa, wp, sw, y, M, N, K, bias, res, act = data[nm]
+            c = cfgmap[nm]
+            if c == "old":
+                raise RuntimeError
+            run_p(c, xp, sa, wp, sw, y, M, N, K, bias=bias, res=res, act=act)
+    print("layer (qkv+proj+fc1+fc2 = 103.7 GF) x 24, us per layer:", flush=True)
+    for cfg in CFGS:
+        if cfg in (10, 11):
+            continue
+        cm = {nm: cfg for nm in layer}
+        def one():
+            for _ in range(24):
+                layer_run(cm)
+        def two():
+            s2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s2):
+                for _ in range(24):
+                    layer_run(cm)
+            for _ in range(24):
+                layer_run(cm)
+            torch.cuda.current_stream().wait_stream(s2)
+        r = timeit({"one": one, "two": two}, rounds=3, iters=2)
+        print(f"  cfg{cfg:2d} {NAMES[cfg]:22s}: 1 stream {r['one'][0] / 24:7.1f} us/layer ({103.7e3 / (r['one'][0] / 24):4.0f} TF) | 2 streams {r['two'][0] / 48:7.1f} us/layer "
+              f"({103.7e3 / (r['two'][0] / 48):4.0f} TF)", flush=True)
+    L.psam_gemm_f16x3p_force_config(-1)
+
+
+if __name__ == "__main__":
+    main()
