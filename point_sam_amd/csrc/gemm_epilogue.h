@@ -45,20 +45,21 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     const bool interior = vec_ok && row_base + TM * 32 <= p.M && col_base + TN * 32 <= p.N;   // wave-uniform
 
     // ---- per-lane constants of the interior path: non-gated TN*8 float4 per row, gated TN*4 float4 of output per row
-    const int c4n = swiglu ? TN * 4 : TN * 8, rpp = 64 / c4n, np = 32 / rpp;      // np = 4 or 8 passes per stripe
+    const int c4n = swiglu ? TN * 4 : TN * 8, rpp = 64 / c4n, np = 32 / rpp;      // rows per pass (1, 2, 4 or 8), np = 4 .. 32 passes per stripe
     const int rl0 = lane / c4n, c4 = lane % c4n;
+    const bool lane_on = rl0 < rpp;                                               // TN = 3: 48 of the 64 lanes carry a float4
     const int scol = swiglu ? ((c4 * 4) >> 5) * 64 + ((c4 * 4) & 31) : c4 * 4;   // staged column of the lane's (first) float4
     const int pcol = col_base + scol;                                            // its column in N (packed, for the gate)
     const int ocol = swiglu ? (col_base >> 1) + c4 * 4 : pcol;                   // output column
     ep_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, m0 = {alpha, alpha, alpha, alpha}, m1 = m0;
-    if (interior) {
+    if (interior && lane_on) {
         if (p.bias) { b0 = ep_load4(p.bias + pcol); if (swiglu) b1 = ep_load4(p.bias + pcol + 32); }
         if constexpr (SCALED) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { m0[e] *= inv_pow2(p.scaleW[pcol + e]); if (swiglu) m1[e] *= inv_pow2(p.scaleW[pcol + 32 + e]); }
         }
     }
-    constexpr int NPMAX = 8, NB = 2;   // NB = 4 doubles the epilogue register footprint (190 VGPRs) and costs a wave of occupancy
+    constexpr int NPMAX = TN * 8 > 32 ? 32 : (TN * 8 > 16 ? 16 : 8), NB = 2;   // NB = 4 doubles the epilogue register footprint (190 VGPRs) and costs a wave of occupancy
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -71,7 +72,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
         if (interior) {
 #pragma unroll
             for (int q0 = 0; q0 < NPMAX; q0 += NB) {     // batches of NB passes: loads first, then arithmetic and stores
-                if (q0 < np) {
+                if (q0 < np && lane_on) {
                     ep_f32x4 res[NB], rb[NB];
                     float rs[NB];
 #pragma unroll

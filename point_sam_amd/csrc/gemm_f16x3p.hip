@@ -48,7 +48,12 @@ struct F16PArgs {
 #define P_DMA16(rsrc, dst, voff, soff) ((void)(rsrc), (void)(dst), (void)(voff), (void)(soff))
 #endif
 
-template <int WM, int WN, int TM, int TN, int S, int LA>
+// ABL (measurement builds only, -DPSAM_GEMM_ABLATE): 1 = no epilogue, 2 = no DMA after the prologue, 4 = no MFMA, 8 = every tile loads the
+// operand panels of tile (0, 0) (perfect L2 sharing), 16 = no fragment reads after the first slab.
+// PF (where the DMA of a slab is issued): 0 = behind the fragment reads of the slab S-1 earlier, one per MFMA slot; 1 = all of it right
+// after that slab's barrier; 2 (S = 2 only) = a second barrier per slab once every wave holds its step-1 fragments frees the stage half
+// a slab early: the DMA of slab t+2 is issued in the middle of slab t (1.5 slab times ahead instead of 1).
+template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArgs p) {
     constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int ROWB = 128;                                   // bytes per row per slab (32 k x 4 B)
@@ -57,6 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     static_assert(NBLK % NW == 0, "pieces divide among the waves");
     constexpr int NL = NBLK / NW;                               // DMA instructions per wave per slab
     static_assert(S >= 2 && LA >= 0 && LA <= 1 && S - 2 - LA >= 0, "ring depth");
+    static_assert(PF != 2 || (S == 2 && LA == 0), "mid-slab release is written for the two-stage ring");
     constexpr int NFR = 2 * (TM + TN);                          // fragment reads per k16 step
     constexpr int NMF = 3 * TM * TN;                            // MFMAs per k16 step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,8 +83,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
 
     // ---- DMA source offsets: piece b = wave + i NW covers rows 8b..8b+7 of the stage; lane -> (row b*8 + lane/8, slot lane%8),
     // which must receive chunk slot ^ swz(row) of that row.  Rows past M / N are clamped (their products are never stored).
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda * 4), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw * 4), 0, 0x7fffffff, 0x00020000);
+    const int m0l = (ABL & 8) ? 0 : m0, n0l = (ABL & 8) ? 0 : n0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0l * p.lda * 4), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0l * p.ldw * 4), 0, 0x7fffffff, 0x00020000);
     int voff[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         const bool isw = b >= A_BLK;
         const int row = (isw ? b - A_BLK : b) * 8 + (lane >> 3);            // row inside its operand's region
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int lim = isw ? p.N - n0 : p.M - m0;
+        const int lim = isw ? p.N - n0l : p.M - m0l;
         const int rc = row < lim ? row : lim - 1;
         voff[i] = (int)((int64_t)rc * (isw ? p.ldw : p.lda) * 4) + chunk * 16;
     }
@@ -101,6 +108,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         }
     };
     auto issue_one = [&](int i, int slab, int stage) {
+        if (ABL & 2) return;
         const int b = wave + i * NW;
         unsigned char* dst = smem + stage * STAGE + b * 1024;
         if (b >= A_BLK) P_DMA16(rsW, dst, voff[i], slab * ROWB);
@@ -128,7 +136,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
 
     pf16x8 f0a[TM][2], f0w[TN][2], f1a[TM][2], f1w[TN][2];
     // fragment read n in [0, NFR) of step s from `stage`: n -> (operand, tile, plane)
+    bool first_slab = true;
     auto read_frag = [&](int n, int s, int stage, pf16x8 (&fa)[TM][2], pf16x8 (&fw)[TN][2]) {
+        if ((ABL & 16) && !first_slab) return;
         const unsigned char* base = smem + stage * STAGE;
         if (n < 2 * TM) { const int i = n >> 1, q = n & 1; fa[i][q] = *reinterpret_cast<const pf16x8*>(base + fa_off[s][q] + i * 32 * ROWB); }
         else { const int m = n - 2 * TM, j = m >> 1, q = m & 1; fw[j][q] = *reinterpret_cast<const pf16x8*>(base + fw_off[s][q] + j * 32 * ROWB); }
@@ -136,13 +146,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     auto mfma = [&](int m, const pf16x8 (&fa)[TM][2], const pf16x8 (&fw)[TN][2]) {     // m in [0, NMF): term-major (hi*lo, lo*hi, hi*hi)
         constexpr int PA[3] = {0, 1, 0}, PW[3] = {1, 0, 0};
         const int term = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[term]], fw[j][PW[term]], acc[i][j], 0, 0, 0);
+        if (ABL & 4) asm volatile("" ::"v"(fa[i][PA[term]]), "v"(fw[j][PW[term]]));
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[term]], fw[j][PW[term]], acc[i][j], 0, 0, 0);
     };
 
     const int nslabs = p.K / 32;
     // ---- prologue: S-1 slabs in flight
 #pragma unroll
-    for (int u = 0; u < S - 1; ++u) issue(u, u);
+    for (int u = 0; u < S - 1 + (PF == 2 ? 1 : 0); ++u) issue(u, u);
     if (LA) {   // slab 0 visible, its first fragments in registers
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (S - 2)) : "memory");
         asm volatile("s_barrier" ::: "memory");
@@ -158,6 +169,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         asm volatile("s_barrier" ::: "memory");
         const int st_issue = st == 0 ? S - 1 : st - 1;          // stage of slab t-1 = stage of slab t+S-1
         const int st_next = st == S - 1 ? 0 : st + 1;
+        if (PF == 1 && DO_ISSUE) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) issue_one(i, t + S - 1, st_issue);
+        }
         if (!LA) {
 #pragma unroll
             for (int n = 0; n < NFR; ++n) read_frag(n, 0, st, f0a, f0w);
@@ -165,14 +180,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         __builtin_amdgcn_sched_barrier(0);
         // step 0: NMF MFMAs; behind them the NFR fragment reads of step 1 (all of them: step 1 needs them), then DMA issues
         constexpr int P0 = (NFR + NMF - 1) / NMF;                               // extra operations per MFMA slot in step 0
-        constexpr int D0 = NMF * P0 - NFR < NL ? NMF * P0 - NFR : NL;            // DMA issues placed in step 0
+        constexpr int D0 = PF == 1 ? NL : (NMF * P0 - NFR < NL ? NMF * P0 - NFR : NL);   // DMA issues placed in (or before) step 0
 #pragma unroll
         for (int m = 0; m < NMF; ++m) {
             mfma(m, f0a, f0w);
 #pragma unroll
             for (int k = m * P0; k < (m + 1) * P0; ++k) {
                 if (k < NFR) read_frag(k, 1, st, f1a, f1w);
-                else if (DO_ISSUE && k - NFR < NL) issue_one(k - NFR, t + S - 1, st_issue);
+                else if (PF == 0 && DO_ISSUE && k - NFR < NL) issue_one(k - NFR, t + S - 1, st_issue);
+                else if (PF == 2 && DO_ISSUE && k - NFR < NL) issue_one(k - NFR, t + 2, st);
+            }
+            if (PF == 2 && (m + 1) * P0 >= NFR && m * P0 < NFR) {   // every step-1 fragment read is issued: wait for them, release the stage
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -183,19 +203,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
             mfma(m, f1a, f1w);
 #pragma unroll
             for (int k = m * P1; k < (m + 1) * P1; ++k) {
-                if (k < REST) { if (DO_ISSUE) issue_one(D0 + k, t + S - 1, st_issue); }
+                if (k < REST) { if (DO_ISSUE) issue_one(D0 + k, PF == 2 ? t + 2 : t + S - 1, PF == 2 ? st : st_issue); }
                 else if (LA && HAS_NEXT && k - REST < NFR) read_frag(k - REST, 0, st_next, f0a, f0w);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         st = st_next;
+        first_slab = false;
     };
     using std::integral_constant;
     int t = 0;
-    for (; t + (S - 1) < nslabs; ++t) body(t, integral_constant<int, NL*(S - 2 - LA)>{}, integral_constant<bool, true>{}, integral_constant<bool, true>{});
-    // tail: the last S-1 slabs issue nothing; the number of DMAs that may remain in flight shrinks step by step
-    if constexpr (S >= 2) {
-        // slabs nslabs-(S-1) .. nslabs-1; at tail position j (0-based) the slabs still in flight after the needed one(s): S-2-j-LA
+    if constexpr (PF == 2) {
+        // slabs t and t+1 are in flight at the top of slab t; slab t+2 is issued mid-slab
+        for (; t + 2 < nslabs; ++t) body(t, integral_constant<int, NL>{}, integral_constant<bool, true>{}, integral_constant<bool, true>{});
+        body(t, integral_constant<int, NL>{}, integral_constant<bool, false>{}, integral_constant<bool, true>{});
+        ++t;
+        body(t, integral_constant<int, 0>{}, integral_constant<bool, false>{}, integral_constant<bool, false>{});
+    } else {
+        for (; t + (S - 1) < nslabs; ++t) body(t, integral_constant<int, NL*(S - 2 - LA)>{}, integral_constant<bool, true>{}, integral_constant<bool, true>{});
+        // tail: the last S-1 slabs issue nothing; at tail position j the slabs still in flight after the needed one(s): S-2-j-LA
         auto tail = [&](auto j_c) {
             constexpr int j = decltype(j_c)::value;
             constexpr int left = S - 2 - j - LA;
@@ -212,6 +238,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     // ---- epilogue (gemm_epilogue.h): every wave is done with the ring, no DMA in flight
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (ABL & 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 123.456f) p.C[0] = sum;
+        return;
+    }
     gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
                                   n0 + wn * TN * 32, lane, p.C, p.residual);
 }
@@ -253,23 +290,27 @@ PSAM_API int32_t psam_pack_rows_f16x2_g8(const float* X, int64_t ldx, const floa
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
 
-template <int WM, int WN, int TM, int TN, int S, int LA>
+template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
 static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
     constexpr int ring = S * (BM + BN) * 128, epi = NW * gemm_epilogue_lds_floats_per_wave<TN>() * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
+    if (TN % 2 != 0 && p.act == 3) {      // the SwiGLU gate pairs accumulator tiles (2q, 2q+1)
+        psam_set_error("psam_gemm_f16x3p: this tile configuration cannot apply the SwiGLU epilogue");
+        return PSAM_EINVAL;
+    }
     p.tiles_m = (int)psam_cdiv(p.M, BM);
     p.tiles_n = (int)psam_cdiv(p.N, BN);
     static bool attr_done = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
             return PSAM_EINVAL;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * NW), lds, stream, p);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
@@ -292,6 +333,19 @@ PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scale
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = 0;
+#ifdef PSAM_GEMM_ABLATE
+    if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2
+        const int which = (cfg - 100) / 32, abl = (cfg - 100) % 32;
+#define ABL_CASE(B)                                                                      \
+    case B:                                                                              \
+        if (which == 0) return launch_f16x3p<2, 2, 2, 2, 2, 0, B>(p, stream);            \
+        if (which == 1) return launch_f16x3p<4, 2, 2, 2, 3, 0, B>(p, stream);            \
+        if (which == 2) return launch_f16x3p<4, 2, 2, 3, 2, 0, B>(p, stream);            \
+        return launch_f16x3p<4, 2, 2, 4, 2, 0, B>(p, stream);
+        switch (abl) { ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(16) ABL_CASE(19) ABL_CASE(23) default: break; }
+#undef ABL_CASE
+    }
+#endif
     switch (cfg) {
         case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);     // 128x128, 4 waves, 2 stages (64 KiB): 2 workgroups per CU
         case 1: return launch_f16x3p<2, 2, 2, 2, 3, 0>(p, stream);     // 128x128, 3 stages (96 KiB)
@@ -305,6 +359,22 @@ PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scale
         case 9: return launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);     // ... 4 stages (128 KiB): 1 workgroup of 8 waves
         case 10: return launch_f16x3p<2, 2, 2, 1, 2, 0>(p, stream);    // 128x64, 4 waves of 64x32, 2 stages (48 KiB): 3 workgroups per CU
         case 11: return launch_f16x3p<2, 2, 2, 1, 3, 1>(p, stream);    // 128x64, 3 stages (72 KiB): 2 per CU
+        case 12: return launch_f16x3p<4, 2, 2, 3, 2, 0>(p, stream);    // 256x192, 8 waves of 64x96, 2 stages (112 KiB)
+        case 13: return launch_f16x3p<2, 2, 2, 3, 2, 0>(p, stream);    // 128x192, 4 waves of 64x96, 2 stages (80 KiB): 2 per CU
+        case 14: return launch_f16x3p<4, 2, 2, 4, 2, 0>(p, stream);    // 256x256, 8 waves of 64x128, 2 stages (128 KiB)
+        case 15: return launch_f16x3p<2, 4, 4, 2, 2, 0>(p, stream);    // 256x256, 8 waves of 128x64
+        case 16: return launch_f16x3p<2, 2, 4, 2, 2, 0>(p, stream);    // 256x128, 4 waves of 128x64, 2 stages (96 KiB)
+        // DMA issue placement variants (PF = 1: first after the barrier, PF = 2: mid-slab stage release)
+        case 20: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 1>(p, stream);   // 128x128 4 waves
+        case 21: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);
+        case 22: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 1>(p, stream);   // 256x192
+        case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);
+        case 24: return launch_f16x3p<4, 2, 2, 4, 2, 0, 0, 1>(p, stream);   // 256x256
+        case 25: return launch_f16x3p<4, 2, 2, 4, 2, 0, 0, 2>(p, stream);
+        case 26: return launch_f16x3p<4, 2, 2, 2, 3, 0, 0, 1>(p, stream);   // 256x128 S3
+        case 27: return launch_f16x3p<4, 2, 2, 2, 2, 0, 0, 2>(p, stream);   // 256x128 S2 mid-slab
+        case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);   // 128x128 8 waves of 32x64, S2 mid-slab (70 KiB: 2 per CU)
+        case 29: return launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 1>(p, stream);   // 128x128 8 waves S4 LA, DMA first
         default: break;
     }
     psam_set_error("psam_gemm_f16x3p: unknown config");

@@ -6,9 +6,39 @@ import torch
 from point_sam_amd import ops
 L = ops._lib.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
-CFGS = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(12))
+CFGS = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(17))
 NAMES = {0: "128x128 4w S2", 1: "128x128 4w S3", 2: "128x128 4w S3 LA", 3: "128x128 4w S4 LA", 4: "256x128 8w S3", 5: "256x128 8w S3 LA",
-         6: "128x256 8w S3 LA", 7: "256x128 8w S2", 8: "128x128 8w(32x64) S2", 9: "128x128 8w(32x64) S4 LA", 10: "128x64 4w S2", 11: "128x64 4w S3 LA"}
+         6: "128x256 8w S3 LA", 7: "256x128 8w S2", 8: "128x128 8w(32x64) S2", 9: "128x128 8w(32x64) S4 LA", 10: "128x64 4w S2", 11: "128x64 4w S3 LA",
+         12: "256x192 8w S2", 13: "128x192 4w S2", 14: "256x256 8w(64x128) S2", 15: "256x256 8w(128x64) S2", 16: "256x128 4w(128x64) S2",
+         20: "128x128 4w S2 PF1", 21: "128x128 4w S2 PF2", 22: "256x192 PF1", 23: "256x192 PF2", 24: "256x256 PF1", 25: "256x256 PF2", 26: "256x128 S3 PF1",
+         27: "256x128 S2 PF2", 28: "128x128 8w S2 PF2", 29: "128x128 8w S4 LA PF1"}
+ODD_TN = (10, 11, 12, 13, 22, 23)
+# per-shape configuration maps for the two-stream layer loop (qkv, proj, fc1, fc2)
+COMBOS = {"all c0": (0, 0, 0, 0), "all c4": (4, 4, 4, 4), "all c14": (14, 14, 14, 14), "c12 c4 c14 c4": (12, 4, 14, 4), "c12 c9 c14 c9": (12, 9, 14, 9),
+          "c14 c4 c14 c4": (14, 4, 14, 4), "c12 c4 c4 c4": (12, 4, 4, 4), "c13 c0 c13 c0": (13, 0, 13, 0), "c12 c16 c14 c16": (12, 16, 14, 16),
+          "c14 c14 c14 c14": (14, 14, 14, 14), "c15 c4 c15 c4": (15, 4, 15, 4), "c12 c9 c4 c9": (12, 9, 4, 9), "c12 c0 c14 c0": (12, 0, 14, 0),
+          "c23 c9 c25 c9": (23, 9, 25, 9), "c23 c28 c25 c28": (23, 28, 25, 28), "c23 c29 c27 c29": (23, 29, 27, 29), "c22 c29 c24 c29": (22, 29, 24, 29),
+          "c23 c9 c27 c9": (23, 9, 27, 9), "c23 c9 c4 c9": (23, 9, 4, 9)}
+
+
+def half_chip_streams():
+    """Two streams confined to complementary halves of every XCD (CU-mask bit i = XCC i % 8, SE (i / 8) % 4, CU i / 32)."""
+    import ctypes
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "libcumask.so")
+    if not os.path.exists(lib):
+        return []
+    C = ctypes.CDLL(lib)
+    out = []
+    for m in ((1 << 128) - 1, ((1 << 128) - 1) << 128):
+        words = (ctypes.c_uint32 * 8)(*[(m >> (32 * w)) & 0xffffffff for w in range(8)])
+        sp = ctypes.c_void_p()
+        assert C.cumask_stream_create(ctypes.byref(sp), words, 8) == 0
+        out.append(torch.cuda.ExternalStream(sp.value))
+    return out
+
+
+HALF = []
+BEST = {}
 
 
 def pack_g8(x, s):
@@ -46,7 +76,7 @@ def correctness():
                 ref = torch.nn.functional.gelu(ref)
             ref = ref + res.double()
         for cfg in CFGS:
-            if act == 3 and cfg in (10, 11):
+            if act == 3 and cfg in ODD_TN:  # odd TN: no SwiGLU pairing
                 continue
             y = torch.full((M, N // 2 if act == 3 else N), float("nan"), device="cuda")
             run_p(cfg, xp, sa, wp, sw, y, M, N, Kp, bias=bias, res=res, act=act)
@@ -79,8 +109,12 @@ SHAPES = [("qkv", 4096, 3072, 1024, 0), ("proj", 4096, 1024, 1024, 0), ("fc1", 4
 
 
 def main():
+    global HALF
+    HALF = half_chip_streams() if os.environ.get("HALF_CHIP") else []
     bad = correctness()
     print("correctness failures:", bad, flush=True)
+    if os.environ.get("ONLY_CHECK"):
+        return
     data = {}
     for name, M, N, K, act in SHAPES:
         x = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5
@@ -94,7 +128,7 @@ def main():
         fns = {"old": (lambda: L.psam_gemm_f16x3_ex(xo.data_ptr(), K, sa.data_ptr(), 1, wo.data_ptr(), K, sw.data_ptr(), 1, y.data_ptr(), y.stride(0),
                                                     bias.data_ptr(), ops._p(res), 0 if res is None else N, 0, 0, 0, M, N, K, 1.0, act, st()))}
         for cfg in CFGS:
-            if act == 3 and cfg in (10, 11):
+            if act == 3 and cfg in ODD_TN:  # odd TN: no SwiGLU pairing
                 continue
             fns[f"c{cfg}"] = (lambda cfg=cfg: run_p(cfg, xp, sa, wp, sw, y, M, N, K, bias=bias, res=res, act=act))
         r = timeit(fns, rounds=4, iters=10 if M > 100000 else 20)
@@ -103,6 +137,7 @@ def main():
         for k, (mn, md) in r.items():
             line += f" {k} {mn:6.1f}us {gf / mn / 1e6:4.0f}TF |"
         print(line, flush=True)
+        BEST[name] = int(min((k for k in r if k != "old"), key=lambda k: r[k][0])[1:])
     # one encoder layer's four GEMMs back to back, on one stream and on two streams at once (the bench keeps two batches in flight)
     layer = ["qkv", "proj", "fc1", "fc2"]
     s2 = torch.cuda.Stream()
@@ -114,10 +149,11 @@ def main():
                 raise RuntimeError
             run_p(c, xp, sa, wp, sw, y, M, N, K, bias=bias, res=res, act=act)
     print("layer (qkv+proj+fc1+fc2 = 103.7 GF) x 24, us per layer:", flush=True)
-    for cfg in CFGS:
-        if cfg in (10, 11):
+    COMBOS["best single"] = tuple(BEST[nm] for nm in layer)
+    for cname, cm4 in COMBOS.items():
+        if any(c not in CFGS for c in cm4):
             continue
-        cm = {nm: cfg for nm in layer}
+        cm = dict(zip(layer, cm4))
         def one():
             for _ in range(24):
                 layer_run(cm)
@@ -129,9 +165,24 @@ def main():
             for _ in range(24):
                 layer_run(cm)
             torch.cuda.current_stream().wait_stream(s2)
-        r = timeit({"one": one, "two": two}, rounds=3, iters=2)
-        print(f"  cfg{cfg:2d} {NAMES[cfg]:22s}: 1 stream {r['one'][0] / 24:7.1f} us/layer ({103.7e3 / (r['one'][0] / 24):4.0f} TF) | 2 streams {r['two'][0] / 48:7.1f} us/layer "
-              f"({103.7e3 / (r['two'][0] / 48):4.0f} TF)", flush=True)
+        def halves():   # two streams, each confined to 16 CUs of every XCD (hipExtStreamCreateWithCUMask)
+            cur = torch.cuda.current_stream()
+            for hs in HALF:
+                hs.wait_stream(cur)
+                with torch.cuda.stream(hs):
+                    for _ in range(24):
+                        layer_run(cm)
+            for hs in HALF:
+                cur.wait_stream(hs)
+        fns = {"one": one, "two": two}
+        if HALF:
+            fns["halves"] = halves
+        r = timeit(fns, rounds=3, iters=2)
+        line = (f"  {cname:18s}: 1 stream {r['one'][0] / 24:7.1f} us/layer ({103.7e3 / (r['one'][0] / 24):4.0f} TF) | 2 streams {r['two'][0] / 48:7.1f} us/layer "
+                f"({103.7e3 / (r['two'][0] / 48):4.0f} TF)")
+        if HALF:
+            line += f" | 2 half-chip streams {r['halves'][0] / 48:7.1f} us/layer ({103.7e3 / (r['halves'][0] / 48):4.0f} TF)"
+        print(line, flush=True)
     L.psam_gemm_f16x3p_force_config(-1)
 
 
