@@ -151,7 +151,7 @@ def main():
                 peak, kernel, note = F32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "f32-input MFMA dense peak"
             elif kind == "f16x3":
                 peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-                kernel = "gemm_f16x3_pipe_kernel (v_mfma_f32_32x32x16_f16, row-scaled 2-way fp16 split, 3 partial products per fp32-grade product)"
+                kernel = "gemm_f16x3p_kernel (v_mfma_f32_32x32x16_f16; operands pre-packed as row-scaled hi|lo fp16, LDS-DMA ring; 3 partial products per fp32-grade product)"
                 note = ("fp32-equivalent peak of the scheme = fp16 dense MFMA peak 2500 TFLOP/s / 3 executed products; "
                         f"executed matrix-pipe rate = {ach * 3:.0f} TFLOP/s = {ach * 3 / BF16_MFMA_PEAK_TFLOPS:.3f} of the fp16 peak")
             else:
@@ -160,16 +160,16 @@ def main():
                 note = ("fp32-equivalent peak of the scheme = bf16 dense MFMA peak 2500 TFLOP/s / 6 executed products; "
                         f"executed matrix-pipe rate = {ach * 6:.0f} TFLOP/s = {ach * 6 / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak")
             traffic = None
-            tfile = "r01_v10_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
+            tfile = "r02_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
             try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
                 tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
-                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "void gemm_f16x3_pipe_kernel<true, true, 2>"}.get(kind)
+                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "gemm_f16x3p_kernel"}.get(kind)
                 if key and key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
             except (OSError, ValueError, KeyError):
                 traffic = None
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "traffic_note": f"bytes/launch of the 128x128-tile kernel, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
+                        "traffic": traffic, "traffic_note": f"bytes/launch (launch-weighted mean over the kernel's tile configurations), rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
                         "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
                         "sampling": ("every 3rd GEMM launch of the last step of the timed region, HIP events on the launch stream" +
                                      ("; second half of that step only, when the previous batch has drained, and the other dense stream is held off during a sampled launch: the duration is the kernel's own" if (pipe is not None and pipe.depth > 1) else "")),

@@ -114,33 +114,11 @@ int32_t psam_gemm_bf16x6(const float* A, int64_t lda, int64_t sA1, int64_t sA2, 
                          int64_t ldc, int64_t sC1, int64_t sC2, const float* bias, const float* residual, int64_t ldr, int64_t sR1, int64_t sR2,
                          const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, int32_t batch1, int32_t batch2,
                          float alpha, int32_t act, psam_stream_t stream);
-/* bf16x6 GEMM against a PRE-PACKED static weight: psam_pack_weight_bf16x3 splits W[N,K] once (at model load) into the
- * three bf16 planes stored in MFMA-fragment order; the GEMM then streams W fragments straight into registers (no LDS, no
- * split arithmetic for the weight) and double-buffers only the activation operand in LDS.  Same result contract as
- * psam_gemm_bf16x6. */
-size_t psam_packed_weight_bytes(int32_t N, int32_t K);
-int32_t psam_pack_weight_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* out, psam_stream_t stream);
-int32_t psam_gemm_bf16x6_pw(const float* A, int64_t lda, const void* Wpk, float* C, int64_t ldc, const float* bias, const float* residual,
-                            int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha,
-                            int32_t act, psam_stream_t stream);
-void psam_gemm_bf16x6_pw_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
-/* fp32-grade GEMM on the fp16 matrix pipe ("f16x3", 2-D form of the psam_gemm_f32 contract; same reference call sites).
- * Each operand row is scaled by a power of two (scaleA[M], scaleW[N] from psam_row_scale_f16: row maximum into
- * [2^14, 2^15); a static weight's scales are computed once) and split into hi + lo fp16 while its K slab is staged;
- * hi*hi + hi*lo + lo*hi are accumulated in fp32 (dropped lo*lo and split residual <= 3*2^-22 relative per product) and
- * the epilogue multiplies by 1/(scaleA[row] scaleW[col]) exactly. */
+/* fp32-grade GEMM on the fp16 matrix pipe ("f16x3"; 2-D form of the psam_gemm_f32 contract, same reference call sites).
+ * Each operand row is scaled by a power of two (row maximum into [2^14, 2^15): psam_row_scale_f16; a static weight's scales are
+ * computed once at load) and split into hi + lo fp16; hi*hi + hi*lo + lo*hi are accumulated in fp32 (dropped lo*lo and split
+ * residual <= 3*2^-22 relative per product) and the epilogue multiplies by 1/(scaleA[row] scaleW[col]) exactly. */
 int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* scale, psam_stream_t stream);
-int32_t psam_gemm_f16x3(const float* A, int64_t lda, const float* scaleA, const float* W, int64_t ldw, const float* scaleW, float* C,
-                        int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
-                        int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
-/* f16x2-packed operands: same [R, K] container of 32-bit words (leading dimension ld), every group of four consecutive k holding
- * [hi0..hi3 | lo0..lo3] fp16 of the row-scaled values -- the two 8-byte LDS slots the GEMM stages, so a packed operand needs no
- * split arithmetic in the GEMM.  Static weights are packed once at load; producers (LayerNorm) can emit the form directly.
- * P == X (in place) is allowed.  psam_gemm_f16x3_ex: a_packed / w_packed say which operand is in that form. */
-int32_t psam_pack_rows_f16x2(const float* X, int64_t ldx, const float* scale, int32_t rows, int32_t K, void* P, int64_t ldp, psam_stream_t stream);
-int32_t psam_gemm_f16x3_ex(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw, const float* scaleW,
-                           int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias,
-                           int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
 /* Production form of the large GEMMs ("f16x3p", csrc/gemm_f16x3p.hip): BOTH operands pre-packed in the "g8" form -- per group of 8
  * consecutive k: [hi k0..k7 (8 x fp16) | lo k0..k7] in the same 32-bit-per-element container -- so that one 16-byte chunk is one
  * matrix-instruction operand and a K slab moves global -> LDS by LDS-DMA with no staging registers or arithmetic.  K % 32 == 0 (pack
@@ -151,16 +129,8 @@ int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const 
                          const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,
                          int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
 void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring configuration index, -1 = auto */
-/* Same with a split-K workspace: tiles of an under-filled launch are computed by two workgroups over half of K each, the partner's
- * accumulators handed to the owner through `ws` and added in a fixed order (bit-reproducible).  ws: psam_gemm_f16x3_workspace_bytes()
- * bytes, zeroed ONCE; epoch: non-zero and unique per call on that workspace; one workspace per concurrently used stream. */
-size_t psam_gemm_f16x3_workspace_bytes(void);
-int32_t psam_gemm_f16x3_ws(const void* A, int64_t lda, const float* scaleA, int32_t a_packed, const void* W, int64_t ldw, const float* scaleW,
-                           int32_t w_packed, float* C, int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias,
-                           int64_t ldrb, int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, void* ws, size_t ws_bytes,
-                           uint32_t epoch, psam_stream_t stream);
-void psam_gemm_f16x3_force_config(int32_t cfg);
-void psam_gemm_f16x3_force_deep(int32_t sets); /* tuning hook: 2/3/4 operand register sets (prefetch distance) in the pipelined kernel, -1 = auto */ /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
+/* Row scales and g8 packing of fp32 rows in ONE pass (an activation no LayerNorm produced, e.g. the attention output). */
+int32_t psam_scale_pack_rows_g8(const float* X, int64_t ldx, int32_t rows, int32_t K, void* P, int64_t ldp, float* scale, psam_stream_t stream);
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,
                     int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 void psam_gemm_bf16x6_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64 tiles, -1=auto */
@@ -171,7 +141,8 @@ void psam_gemm_force_config(int32_t cfg); /* tuning hook: 0=128x128, 1=128x64, 2
 int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                        int64_t rows, int32_t cols, float eps, int32_t act, psam_stream_t stream);
 /* Same, plus row_scale[rows] (optional): the power-of-two f16x3 scale of every OUTPUT row (psam_row_scale_f16 fused in). */
-/* psam_layernorm_ex: pack != 0 writes y as the f16x2-packed form of the row-scaled output (needs row_scale; 256 <= cols <= 4096). */
+/* psam_layernorm_ex: pack != 0 writes y as the g8-packed form of the row-scaled output, zero-padded to cols rounded up to 32 when ldy has
+ * room (needs row_scale; 256 <= cols <= 4096; 32-byte aligned output rows): the A operand of psam_gemm_f16x3p. */
 int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                           int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack, psam_stream_t stream);
 int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,

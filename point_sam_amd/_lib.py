@@ -34,25 +34,14 @@ SIGNATURES = {
                             i32, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_bf16x6": (i32, [ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, i64, i64, i64, ptr, ptr, i64, i64, i64, ptr, i64, i32,
                                i32, i32, i32, i32, i32, f32, i32, ptr]),
-    "psam_packed_weight_bytes": (size_t, [i32, i32]),
-    "psam_pack_weight_bf16x3": (i32, [ptr, i64, i32, i32, ptr, ptr]),
-    "psam_gemm_bf16x6_pw": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
-    "psam_gemm_bf16x6_pw_force_config": (None, [i32]),
     "psam_linear": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
     "psam_gemm_force_config": (None, [i32]),
     "psam_gemm_bf16x6_force_config": (None, [i32]),
     "psam_row_scale_f16": (i32, [ptr, i64, i32, i32, ptr, ptr]),
-    "psam_gemm_f16x3": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
-    "psam_pack_rows_f16x2": (i32, [ptr, i64, ptr, i32, i32, ptr, i64, ptr]),
-    "psam_gemm_f16x3_ex": (i32, [ptr, i64, ptr, i32, ptr, i64, ptr, i32, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
-    "psam_gemm_f16x3_workspace_bytes": (size_t, []),
-    "psam_gemm_f16x3_ws": (i32, [ptr, i64, ptr, i32, ptr, i64, ptr, i32, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, size_t,
-                                 ctypes.c_uint32, ptr]),
     "psam_pack_rows_f16x2_g8": (i32, [ptr, i64, ptr, i32, i32, ptr, i64, ptr]),
     "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3p_force_config": (None, [i32]),
-    "psam_gemm_f16x3_force_config": (None, [i32]),
-    "psam_gemm_f16x3_force_deep": (None, [i32]),
+    "psam_scale_pack_rows_g8": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, ptr]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
     "psam_layernorm_rs": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, ptr]),
     "psam_layernorm_ex": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, i32, ptr]),

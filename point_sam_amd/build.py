@@ -20,8 +20,6 @@ SOURCES = [
     ("tokenizer.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
     ("gemm_split.hip", []),
-    ("gemm_packw.hip", []),
-    ("gemm_f16x3.hip", []),
     ("gemm_f16x3p.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),

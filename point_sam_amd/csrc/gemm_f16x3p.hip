@@ -2,7 +2,7 @@
 //
 //   C = act(alpha * A @ W^T + bias + rowbias[row / rowgroup]) + residual          (contract and epilogues of gemm.hip, 2-D form)
 //
-// Arithmetic = gemm_f16x3.hip: every operand row is scaled by a power of two (row maximum in [2^14, 2^15)) and every element split
+// Arithmetic: every operand row is scaled by a power of two (row maximum in [2^14, 2^15)) and every element split
 // into hi + lo fp16; a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation, un-scaled in the epilogue.
 // What is new is the data path.  Both operands arrive in the "g8" packed form (psam_pack_rows_f16x2_g8, the LayerNorm / attention /
 // GEMM-epilogue producers): the container is still one 32-bit word per element, and every group of 8 consecutive k holds
@@ -253,6 +253,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
                                   n0 + wn * TN * 32, lane, p.C, p.residual);
 }
 
+// ---------------------------------------------------------------------------------------------- row scales
+// scale[r] = 2^(14 - e), e = floor(log2(max_k |X[r,k]|)) clamped below at -112; 1 for an all-zero / non-finite row (common.h).
+__global__ __launch_bounds__(256) void row_scale_f16_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols, float* __restrict__ scale) {
+    typedef float rs_f32x4 __attribute__((ext_vector_type(4)));
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = X + (int64_t)row * ldx;
+    float m = 0.f;
+    if (((ldx & 3) == 0) && (((uintptr_t)X & 15) == 0)) {
+        const int c4 = cols >> 2;
+        for (int c = lane; c < c4; c += 64) {
+            const rs_f32x4 v = *reinterpret_cast<const rs_f32x4*>(x + c * 4);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        for (int c = (c4 << 2) + lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[c]));
+    } else {
+        for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[c]));
+    }
+    m = wave_max(m);
+    if (lane == 0) scale[row] = f16_row_scale(m);
+}
+
+PSAM_API int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* scale, hipStream_t stream) {
+    PSAM_REQUIRE(X && scale, PSAM_EINVAL, "psam_row_scale_f16: null pointer");
+    PSAM_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, PSAM_EINVAL, "psam_row_scale_f16: bad shape");
+    hipLaunchKernelGGL(row_scale_f16_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, scale);
+    return psam_launch_status("psam_row_scale_f16: launch failed");
+}
+
 // ---------------------------------------------------------------------------------------------- g8 packing of an fp32 matrix
 // P[r, 8g .. 8g+7] (32-bit containers) = [hi(8 x fp16) | lo(8 x fp16)] of scale[r] * X[r, 8g .. 8g+7]; columns K .. Kp-1 (Kp = K rounded
 // up to 32, the GEMM's slab) are written as zeros.  In place (P == X, ldp == ldx) is allowed when K % 8 == 0.
@@ -286,9 +315,90 @@ PSAM_API int32_t psam_pack_rows_f16x2_g8(const float* X, int64_t ldx, const floa
     return psam_launch_status("psam_pack_rows_f16x2_g8: launch failed");
 }
 
+// Row scale + g8 packing in one pass (an fp32 activation that no LayerNorm produced, e.g. the attention output): one wave per row, the
+// row stays in registers between the maximum and the split.  K <= NV4 * 256, K % 4 == 0, rows 16-byte aligned.
+template <int NV4>
+__global__ __launch_bounds__(256) void scale_pack_rows_g8_kernel(const float* __restrict__ X, int64_t ldx, int rows, int K, unsigned* __restrict__ P,
+                                                                 int64_t ldp, float* __restrict__ scale) {
+    typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int row = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6);
+    if (row >= rows) return;
+    const sp_f32x4* xr = reinterpret_cast<const sp_f32x4*>(X + (int64_t)row * ldx);
+    const int c4n = K >> 2;
+    sp_f32x4 v[NV4];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = xr[c < c4n ? c : c4n - 1];                       // unconditional (clamped) loads
+        if (c >= c4n) v[i] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+    }
+    amax = wave_max(amax);
+    const float sc = f16_row_scale(amax);
+    if (lane == 0) scale[row] = sc;
+    const int klim = (K + 31) & ~31;
+    const bool odd = lane & 1;
+    unsigned* prow = P + (int64_t)row * ldp;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 64 + lane;
+        unsigned h0, l0, h1, l1;
+        psam_split2_f16(v[i][0], v[i][1], sc, h0, l0);
+        psam_split2_f16(v[i][2], v[i][3], sc, h1, l1);
+        const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+        if (c * 4 < klim) *reinterpret_cast<pu32x4*>(prow + c * 4) = odd ? pu32x4{r0, r1, l0, l1} : pu32x4{h0, h1, r0, r1};
+    }
+}
+
+// scale[r] = f16 row scale of X[r, :K]; P[r, :] = g8-packed scale[r] * X[r, :K], zero-padded to K rounded up to 32 (ldp >= that).
+PSAM_API int32_t psam_scale_pack_rows_g8(const float* X, int64_t ldx, int32_t rows, int32_t K, void* P, int64_t ldp, float* scale, hipStream_t stream) {
+    PSAM_REQUIRE(X && P && scale, PSAM_EINVAL, "psam_scale_pack_rows_g8: null pointer");
+    const int Kp = (K + 31) / 32 * 32;
+    PSAM_REQUIRE(rows > 0 && K > 0 && K <= 6144 && (K & 3) == 0 && ldx >= K && ldp >= Kp, PSAM_EINVAL,
+                 "psam_scale_pack_rows_g8: bad shape (K % 4 == 0, K <= 6144, ldp >= K rounded up to 32)");
+    PSAM_REQUIRE((ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 && (ldp & 7) == 0 && ((uintptr_t)P & 31) == 0, PSAM_EALIGN,
+                 "psam_scale_pack_rows_g8: rows of X 16-byte, of P 32-byte aligned");
+    const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
+#define SP_LAUNCH(R) hipLaunchKernelGGL(scale_pack_rows_g8_kernel<R>, grid, block, 0, stream, X, ldx, rows, K, (unsigned*)P, ldp, scale)
+    if (Kp <= 256) SP_LAUNCH(1);
+    else if (Kp <= 512) SP_LAUNCH(2);
+    else if (Kp <= 1024) SP_LAUNCH(4);
+    else if (Kp <= 2048) SP_LAUNCH(8);
+    else if (Kp <= 4096) SP_LAUNCH(16);
+    else SP_LAUNCH(24);
+#undef SP_LAUNCH
+    return psam_launch_status("psam_scale_pack_rows_g8: launch failed");
+}
+
 // ---------------------------------------------------------------------------------------------- host
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
+
+// Tile configuration for a shape.  Measured per-CU rates of the configurations are within ~15 % of each other once a CU is busy
+// (profiles/r02_gemm_p_sweep_*.log); what differs is how many rounds of workgroups a launch needs and how much of the last round is
+// empty.  cost = rounds x tile area x (K + 300) x penalty: the 300 stands for the epilogue of a tile (12-14 us of the 77 us, K = 1024
+// qkv GEMM), the penalty for the operand bytes per flop of the smaller tiles (LDS-DMA path ~32 B/clk/CU).
+static int f16x3p_pick(int M, int N, int K, int act) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    struct Cand { int cfg, bm, bn; bool swiglu; double pen; };
+    static const Cand cands[] = {{14, 256, 256, true, 1.0}, {23, 256, 192, false, 1.0}, {4, 256, 128, true, 1.05}, {9, 128, 128, true, 1.15}};
+    int best = 9;
+    double best_cost = 1e300;
+    for (const Cand& c : cands) {
+        if (act == 3 && !c.swiglu) continue;
+        const double tiles = (double)psam_cdiv(M, c.bm) * (double)psam_cdiv(N, c.bn);
+        const double rounds = (double)psam_cdiv((int64_t)tiles, ncu);
+        const double cost = rounds * c.bm * c.bn * (K + 300.0) * c.pen;
+        if (cost < best_cost) { best_cost = cost; best = c.cfg; }
+    }
+    return best;
+}
 
 template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
 static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
@@ -332,7 +442,7 @@ PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scale
     p.scaleA = scaleA; p.scaleW = scaleW; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     int cfg = g_f16x3p_cfg;
-    if (cfg < 0) cfg = 0;
+    if (cfg < 0) cfg = f16x3p_pick(M, N, K, act);
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2
         const int which = (cfg - 100) / 32, abl = (cfg - 100) % 32;
@@ -346,35 +456,15 @@ PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scale
 #undef ABL_CASE
     }
 #endif
-    switch (cfg) {
-        case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);     // 128x128, 4 waves, 2 stages (64 KiB): 2 workgroups per CU
-        case 1: return launch_f16x3p<2, 2, 2, 2, 3, 0>(p, stream);     // 128x128, 3 stages (96 KiB)
-        case 2: return launch_f16x3p<2, 2, 2, 2, 3, 1>(p, stream);     // ... with look-ahead fragments
-        case 3: return launch_f16x3p<2, 2, 2, 2, 4, 1>(p, stream);     // 128x128, 4 stages (128 KiB)
-        case 4: return launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream);     // 256x128, 8 waves, 3 stages (144 KiB)
-        case 5: return launch_f16x3p<4, 2, 2, 2, 3, 1>(p, stream);
-        case 6: return launch_f16x3p<2, 4, 2, 2, 3, 1>(p, stream);     // 128x256, 8 waves
-        case 7: return launch_f16x3p<4, 2, 2, 2, 2, 0>(p, stream);     // 256x128, 2 stages (96 KiB)
-        case 8: return launch_f16x3p<4, 2, 1, 2, 2, 0>(p, stream);     // 128x128 with 8 waves of 32x64 (70 KiB): 2 workgroups = 16 waves per CU
-        case 9: return launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);     // ... 4 stages (128 KiB): 1 workgroup of 8 waves
-        case 10: return launch_f16x3p<2, 2, 2, 1, 2, 0>(p, stream);    // 128x64, 4 waves of 64x32, 2 stages (48 KiB): 3 workgroups per CU
-        case 11: return launch_f16x3p<2, 2, 2, 1, 3, 1>(p, stream);    // 128x64, 3 stages (72 KiB): 2 per CU
-        case 12: return launch_f16x3p<4, 2, 2, 3, 2, 0>(p, stream);    // 256x192, 8 waves of 64x96, 2 stages (112 KiB)
-        case 13: return launch_f16x3p<2, 2, 2, 3, 2, 0>(p, stream);    // 128x192, 4 waves of 64x96, 2 stages (80 KiB): 2 per CU
-        case 14: return launch_f16x3p<4, 2, 2, 4, 2, 0>(p, stream);    // 256x256, 8 waves of 64x128, 2 stages (128 KiB)
-        case 15: return launch_f16x3p<2, 4, 4, 2, 2, 0>(p, stream);    // 256x256, 8 waves of 128x64
-        case 16: return launch_f16x3p<2, 2, 4, 2, 2, 0>(p, stream);    // 256x128, 4 waves of 128x64, 2 stages (96 KiB)
-        // DMA issue placement variants (PF = 1: first after the barrier, PF = 2: mid-slab stage release)
-        case 20: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 1>(p, stream);   // 128x128 4 waves
-        case 21: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);
-        case 22: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 1>(p, stream);   // 256x192
-        case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);
-        case 24: return launch_f16x3p<4, 2, 2, 4, 2, 0, 0, 1>(p, stream);   // 256x256
-        case 25: return launch_f16x3p<4, 2, 2, 4, 2, 0, 0, 2>(p, stream);
-        case 26: return launch_f16x3p<4, 2, 2, 2, 3, 0, 0, 1>(p, stream);   // 256x128 S3
-        case 27: return launch_f16x3p<4, 2, 2, 2, 2, 0, 0, 2>(p, stream);   // 256x128 S2 mid-slab
-        case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);   // 128x128 8 waves of 32x64, S2 mid-slab (70 KiB: 2 per CU)
-        case 29: return launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 1>(p, stream);   // 128x128 8 waves S4 LA, DMA first
+    switch (cfg) {   // the configurations that won somewhere in the sweeps (profiles/r02_gemm_p_sweep_*.log); numbering kept from the sweeps
+        case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);            // 128x128, 4 waves of 64x64, 2 stages (64 KiB): 2 workgroups per CU
+        case 4: return launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream);            // 256x128, 8 waves, 3 stages (144 KiB)
+        case 9: return launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);            // 128x128, 8 waves of 32x64, 4 stages + look-ahead fragments (128 KiB)
+        case 12: return launch_f16x3p<4, 2, 2, 3, 2, 0>(p, stream);           // 256x192, 8 waves of 64x96, 2 stages (112 KiB); no SwiGLU epilogue
+        case 14: return launch_f16x3p<4, 2, 2, 4, 2, 0>(p, stream);           // 256x256, 8 waves of 64x128, 2 stages (128 KiB)
+        case 21: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 4 waves, mid-slab stage release
+        case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);     // 256x192, mid-slab stage release
+        case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 8 waves of 32x64, 2 stages, mid-slab release (70 KiB): 2 per CU
         default: break;
     }
     psam_set_error("psam_gemm_f16x3p: unknown config");

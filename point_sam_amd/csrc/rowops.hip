@@ -133,8 +133,11 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
     const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
     const int cfull = cols >> 2;    // float4 groups entirely inside the row (cols >= 256 on this path, so cfull >= 64)
     if (pack) {
-        // f16x2-packed output for the f16x3 GEMM (gemm_f16x3.hip): the outputs stay in registers until the row maximum (hence
-        // the row scale) is known, then every float4 group is written as [hi x4 | lo x4]; columns >= cols of the last group are 0.
+        // g8-packed output for the f16x3p GEMM (gemm_f16x3p.hip): the outputs stay in registers until the row maximum (hence the row
+        // scale) is known; then every group of 8 columns is written as [hi x8 | lo x8] fp16.  A lane holds 4 columns (hi: 8 B, lo: 8 B),
+        // its neighbour lane ^ 1 the other 4 of the group: the even lane collects the 16-byte hi chunk, the odd lane the lo chunk (one
+        // exchange), so consecutive lanes still write consecutive 16-byte chunks.  Columns cols .. round_up(cols, 32) - 1 (the GEMM's
+        // K padding) are written as zeros when the row stride has room for them.
 #pragma unroll
         for (int i = 0; i < NV4; ++i) {
             const int c = i * 64 + lane;
@@ -155,15 +158,18 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
         const float sc = f16_row_scale(amax);
         if (lane == 0) rscale[row] = sc;
         typedef unsigned ln_u32x4 __attribute__((ext_vector_type(4)));
+        const int kp = (cols + 31) & ~31;
+        const int klim = kp <= ldy ? kp : (cols + 7) & ~7;      // columns to write (multiple of 8)
+        const bool odd = lane & 1;
 #pragma unroll
         for (int i = 0; i < NV4; ++i) {
             const int c = i * 64 + lane;
-            if (c * 4 < cols) {
-                unsigned h0, l0, h1, l1;
-                psam_split2_f16(v[i][0], v[i][1], sc, h0, l0);
-                psam_split2_f16(v[i][2], v[i][3], sc, h1, l1);
-                *reinterpret_cast<ln_u32x4*>(yrow + c * 4) = ln_u32x4{h0, h1, l0, l1};
-            }
+            unsigned h0, l0, h1, l1;
+            psam_split2_f16(v[i][0], v[i][1], sc, h0, l0);
+            psam_split2_f16(v[i][2], v[i][3], sc, h1, l1);
+            // even lane keeps its hi and receives the neighbour's hi; odd lane keeps its lo and receives the neighbour's lo
+            const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+            if (c * 4 < klim) *reinterpret_cast<ln_u32x4*>(yrow + c * 4) = odd ? ln_u32x4{r0, r1, l0, l1} : ln_u32x4{h0, h1, r0, r1};
         }
         return;
     }
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
 }
 
 // row_scale (optional, [rows]): the f16x3 GEMM's power-of-two row scale of the OUTPUT rows (psam_row_scale_f16 fused in).
-// pack != 0: y receives the f16x2-packed form of the row-scaled output (psam_pack_rows_f16x2 fused in; needs row_scale and the
-// float4 path: 256 <= cols <= 4096, 16-byte aligned rows) -- the A operand of psam_gemm_f16x3_ex with a_packed = 1.
+// pack != 0: y receives the g8-packed form of the row-scaled output (psam_pack_rows_f16x2_g8 fused in; needs row_scale and the
+// float4 path: 256 <= cols <= 4096, 32-byte aligned output rows) -- the A operand of psam_gemm_f16x3p.
 PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
                                    int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack,
                                    hipStream_t stream) {
@@ -205,13 +211,15 @@ PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res
     const int64_t c4 = ((int64_t)cols + 3) & ~(int64_t)3;
     const bool vec = cols >= 256 && cols <= 4096 && ((ldx | ldy | (res ? ldr : 0)) & 3) == 0 && ldx >= c4 && ldy >= c4 && (!res || ldr >= c4) &&
                      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)w | (uintptr_t)b) & 15) == 0;
-    PSAM_REQUIRE(!pack || (vec && row_scale), PSAM_EINVAL, "psam_layernorm: packed output needs row_scale and the float4 path (256 <= cols <= 4096, aligned)");
+    PSAM_REQUIRE(!pack || (vec && row_scale && (ldy & 7) == 0 && ((uintptr_t)y & 31) == 0 && ldy >= ((cols + 7) & ~7)), PSAM_EINVAL,
+                 "psam_layernorm: packed output needs row_scale, the float4 path (256 <= cols <= 4096, aligned) and 32-byte aligned output rows");
     if (vec) {
 #define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale, pack)
-        if (cols <= 256) LNV_LAUNCH(1);
-        else if (cols <= 512) LNV_LAUNCH(2);
-        else if (cols <= 1024) LNV_LAUNCH(4);
-        else if (cols <= 2048) LNV_LAUNCH(8);
+        const int span = pack ? ((cols + 31) & ~31) : cols;     // the packed form also writes the zero padding up to the 32-k slab
+        if (span <= 256) LNV_LAUNCH(1);
+        else if (span <= 512) LNV_LAUNCH(2);
+        else if (span <= 1024) LNV_LAUNCH(4);
+        else if (span <= 2048) LNV_LAUNCH(8);
         else LNV_LAUNCH(16);
 #undef LNV_LAUNCH
         return psam_launch_status("psam_layernorm: launch failed");

@@ -114,10 +114,32 @@ class PointCloudSAM:
             blk.p = p
             self.blocks.append(blk)
         self.out_tokens = torch.cat([w["mask_decoder.iou_token.weight"], w["mask_decoder.mask_tokens.weight"]], 0).contiguous()
+        # "f16x3": every static weight that can feed the packed-operand GEMM (csrc/gemm_f16x3p.hip) is scaled, split and packed ONCE,
+        # here, and owned by this model (fw: name -> ops.F16Weight; launches below the split thresholds use its fp32 original)
+        self.fw = {}
+        if self.precision == "f16x3":
+            h0 = cfg.patch_hidden[0]
+            for name, t in w.items():
+                if name.endswith(".weight") and t.dim() == 2 and ops.F16Weight.eligible(*t.shape) and not name.startswith("pc_encoder.transformer."):
+                    self.fw[name] = ops.F16Weight(t)
+            for prefix in ("pc_encoder.patch_embed.patch_encoder", "mask_encoder.patch_encoder"):   # cat([max, x]) @ W^T as two GEMMs
+                w2a = w[prefix + ".conv2.0.weight"]
+                for tag, sl in (("#max", w2a[:, :h0]), ("#x", w2a[:, h0:])):
+                    if ops.F16Weight.eligible(*sl.shape):
+                        self.fw[prefix + ".conv2.0.weight" + tag] = ops.F16Weight(sl)
+            for blk in self.blocks:
+                for attr in ("wqkv", "w1", "w2"):
+                    t = getattr(blk, attr)
+                    if ops.F16Weight.eligible(*t.shape):
+                        setattr(blk, attr, ops.F16Weight(t))
+                pw = w[blk.p + ".attn.proj.weight"]
+                if ops.F16Weight.eligible(*pw.shape):
+                    self.fw[blk.p + ".attn.proj.weight"] = ops.F16Weight(pw)
+            torch.cuda.current_stream(self.device).synchronize()   # the packed weights are consumed from several streams afterwards
 
     # ------------------------------------------------------------------------------------------ building blocks
     def _lin(self, name, x, **kw):
-        return ops.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"), **kw)
+        return ops.linear(x, self.fw.get(name + ".weight", self.w[name + ".weight"]), self.w.get(name + ".bias"), **kw)
 
     def _ln(self, name, x, eps, **kw):
         return ops.layernorm(x, self.w[name + ".weight"], self.w[name + ".bias"], eps, **kw)
@@ -125,10 +147,10 @@ class PointCloudSAM:
     def _ln_feeds_gemm(self, x, consumer):
         """(pack, row-scale buffer) for a LayerNorm whose only consumer is a large "f16x3" GEMM over all of its columns: the LN
         kernel then emits the GEMM's row scales and, on its float4 path, the packed hi|lo operand itself."""
-        if (self.precision != "f16x3" or x.shape[0] < ops.SPLIT_MIN_M or x.shape[1] < ops.SPLIT_MIN_K
-                or self.w[consumer + ".weight"].shape[0] < ops.SPLIT_MIN_N):
+        if self.precision != "f16x3" or x.shape[0] < ops.SPLIT_MIN_M or (consumer + ".weight") not in self.fw or not ops.layernorm_can_pack(x.shape[1]) \
+                or x.shape[1] % 32 != 0:
             return False, None
-        return ops.layernorm_can_pack(x.shape[1]), torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        return True, torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
 
     def _patch_encoder(self, prefix, coords, feats, centers, knn_idx):
         """PatchEncoder.forward on gathered groups (common.py:499-506) -> [B*rep*G, Cout]."""
@@ -142,8 +164,8 @@ class PointCloudSAM:
         y1 = ops.group_max(h2, K)
         w2a = w[prefix + ".conv2.0.weight"]
         # cat([max, x]) @ W^T = max @ W[:, :h0]^T (one row per group) + x @ W[:, h0:]^T
-        g1 = ops.linear(y1, w2a[:, :h0], w[prefix + ".conv2.0.bias"])
-        h3 = ops.linear(h2, w2a[:, h0:], None, rowbias=g1, rowgroup=K)
+        g1 = ops.linear(y1, self.fw.get(prefix + ".conv2.0.weight#max", w2a[:, :h0]), w[prefix + ".conv2.0.bias"])
+        h3 = ops.linear(h2, self.fw.get(prefix + ".conv2.0.weight#x", w2a[:, h0:]), None, rowbias=g1, rowgroup=K)
         del h2
         pk, rs = self._ln_feeds_gemm(h3, prefix + ".conv2.3")
         self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3, scale_out=rs, pack=pk)
@@ -158,9 +180,8 @@ class PointCloudSAM:
         # "f16x3" GEMMs need a power-of-two scale per operand row and stage hi/lo fp16 planes: the LayerNorms that feed them emit
         # the scale and (when the float4 LN path applies) the packed planes directly, so the GEMM does no split arithmetic for A
         f16 = self.precision == "f16x3"
-        rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if f16 else None
-        big = x.shape[0] >= ops.SPLIT_MIN_M and D >= ops.SPLIT_MIN_N
-        pk = f16 and big and ops.layernorm_can_pack(D)
+        pk = f16 and x.shape[0] >= ops.SPLIT_MIN_M and isinstance(blk.wqkv, ops.F16Weight) and ops.layernorm_can_pack(D)
+        rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if pk else None
         h = self._ln(p + ".norm1", x, vit.ln_eps, scale_out=rs, pack=pk)
         qkv = ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs, x_packed=pk)
         o = torch.empty_like(x)
@@ -172,9 +193,10 @@ class PointCloudSAM:
             # the first H columns in place, then fc2 over K = Hp (zero-padded weight columns)
             u = ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=pk)
             Hh = vit.mlp_hidden
-            pk2 = f16 and big and ops.layernorm_can_pack(Hh)
-            ops.layernorm(u[:, :Hh], self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, out=u[:, :Hh], scale_out=rs, pack=pk2)
-            ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=rs, x_packed=pk2)
+            pk2 = pk and isinstance(blk.w2, ops.F16Weight) and ops.layernorm_can_pack(Hh)
+            ops.layernorm(u[:, :Hh], self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, out=u[:, :Hh], scale_out=rs if pk2 else None,
+                          pack=pk2)
+            ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=rs if pk2 else None, x_packed=pk2)
         else:
             g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=pk)
             ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)

@@ -45,10 +45,11 @@ def _sampled_launch(launch, record):
 # GEMM arithmetic: "f32" = v_mfma_f32_32x32x2_f32 everywhere (exact fp32 products); "bf16x6" = large GEMMs on the bf16
 # matrix pipe with the exact 3-way operand split (fp32-accurate, see csrc/gemm_split.hip), small ones stay on "f32".
 GEMM_MODE = "f32"
-SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 64
+SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 128
 GEMM_MODES = ("f32", "bf16x6", "f16x3")
-# "f16x3" = large 2-D GEMMs on the fp16 matrix pipe: power-of-two row scales + 2-way fp16 split, 3 partial products
-# (fp32-grade: same measured error vs fp64 as the f32 kernel, csrc/gemm_f16x3.hip); batched and small ones stay on "f32".
+# "f16x3" = large 2-D GEMMs against a prepared static weight (F16Weight) on the fp16 matrix pipe: power-of-two row scales + 2-way
+# fp16 split, 3 partial products (fp32-grade: same measured error vs fp64 as the f32 kernel, csrc/gemm_f16x3p.hip); batched and
+# small ones stay on "f32".
 
 
 class gemm_mode:
@@ -78,16 +79,6 @@ def _gemm_call(fn_args, flops, M, N, K, what):
         check(fn(*fn_args), what)
         return
     _sampled_launch(lambda: check(fn(*fn_args), what), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6" if split else "f32")))
-
-
-def _packed_gemm_call(fn_args, flops, M, N, K):
-    global _gemm_counter
-    L = _lib.load()
-    _gemm_counter += 1
-    if not _sample_now():
-        check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw")
-        return
-    _sampled_launch(lambda: check(L.psam_gemm_bf16x6_pw(*fn_args), "psam_gemm_bf16x6_pw"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "bf16x6")))
 
 
 def _stream():
@@ -192,23 +183,6 @@ def _row_view(t, name):
     return t.data_ptr(), t.stride(0)
 
 
-class PackedWeight:
-    """A static nn.Linear weight pre-split into bf16x3 planes in MFMA fragment order (csrc/gemm_packw.hip), plus the fp32
-    original for the launches that do not use the packed kernel (small M, "f32" mode)."""
-
-    def __init__(self, W: torch.Tensor):
-        wp, ldw = _row_view(W, "W")
-        self.fp32 = W
-        self.N, self.K = W.shape
-        L = _lib.load()
-        self.data = torch.empty(L.psam_packed_weight_bytes(self.N, self.K), dtype=torch.uint8, device=W.device)
-        check(L.psam_pack_weight_bf16x3(wp, ldw, self.N, self.K, self.data.data_ptr(), _stream()), "psam_pack_weight_bf16x3")
-
-    @property
-    def shape(self):
-        return (self.N, self.K)
-
-
 def row_scale_f16(x, K=None, out=None):
     """Per-row power-of-two scales for the f16x3 GEMM (row maximum of x[:, :K] into [2^14, 2^15))."""
     xp, ldx = _row_view(x, "x")
@@ -219,115 +193,104 @@ def row_scale_f16(x, K=None, out=None):
     return out
 
 
-_WEIGHT_SCALES = {}   # static weights: (ptr, shape, ld, K, version) -> (scale tensor, weight kept alive)
+def _kpad(K: int) -> int:
+    return (K + 31) // 32 * 32
 
 
-def weight_scale_f16(W, K):
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), K, W._version)
-    hit = _WEIGHT_SCALES.get(key)
-    if hit is None:
-        hit = _WEIGHT_SCALES[key] = (row_scale_f16(W, K), W)
-        torch.cuda.current_stream().synchronize()   # one-time: the cached tensor may be consumed from ANY stream afterwards
-    return hit[0]
-
-
-def pack_rows_f16x2(x, scale, K=None, out=None):
-    """f16x2-packed form of the row-scaled x[:, :K] (csrc/gemm_f16x3.hip): same fp32-sized container, [hi x4 | lo x4] per 4 k."""
+def pack_rows_g8(x, scale, K=None, out=None):
+    """g8-packed form of the row-scaled x[:, :K] (csrc/gemm_f16x3p.hip): per 8 consecutive k [hi x8 | lo x8] fp16 in the 32-bit
+    containers; K is zero-padded to the next multiple of 32 (the GEMM's slab)."""
     xp, ldx = _row_view(x, "x")
     rows = x.shape[0]
     K = x.shape[1] if K is None else K
     if out is None:
-        out = torch.empty(rows, K, dtype=torch.float32, device=x.device)
+        out = torch.empty(rows, _kpad(K), dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
-    check(_lib.load().psam_pack_rows_f16x2(xp, ldx, scale.data_ptr(), rows, K, op, ldo, _stream()), "psam_pack_rows_f16x2")
+    check(_lib.load().psam_pack_rows_f16x2_g8(xp, ldx, scale.data_ptr(), rows, K, op, ldo, _stream()), "psam_pack_rows_f16x2_g8")
     return out
 
 
-_WEIGHT_PACKED = {}
+def scale_pack_rows_g8(x, K=None, out=None, scale=None):
+    """(packed, scale): row scales and the g8-packed form of fp32 rows in ONE pass (K <= 6144, K % 4 == 0)."""
+    xp, ldx = _row_view(x, "x")
+    rows = x.shape[0]
+    K = x.shape[1] if K is None else K
+    if out is None:
+        out = torch.empty(rows, _kpad(K), dtype=torch.float32, device=x.device)
+    if scale is None:
+        scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    op, ldo = _row_view(out, "out")
+    check(_lib.load().psam_scale_pack_rows_g8(xp, ldx, rows, K, op, ldo, scale.data_ptr(), _stream()), "psam_scale_pack_rows_g8")
+    return out, scale
 
 
-def weight_packed_f16(W, K):
-    """(packed weight, row scales) of a static weight, computed once."""
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), K, W._version)
-    hit = _WEIGHT_PACKED.get(key)
-    if hit is None:
-        sw = weight_scale_f16(W, K)
-        hit = _WEIGHT_PACKED[key] = (pack_rows_f16x2(W, sw, K), sw, W)
-        torch.cuda.current_stream().synchronize()   # one-time: the cached tensor may be consumed from ANY stream afterwards
-    return hit[0], hit[1]
+class F16Weight:
+    """A static nn.Linear weight [N, K] prepared ONCE for the "f16x3" GEMM (csrc/gemm_f16x3p.hip): per-row power-of-two scales and the
+    g8-packed, K-padded (multiple of 32) hi|lo fp16 form.  Owned by the model that built it (no process-global cache); the fp32
+    original stays available for launches below the split thresholds."""
+
+    def __init__(self, W: torch.Tensor):
+        _row_view(W, "W")
+        self.fp32 = W
+        self.N, self.K = W.shape
+        self.scale = row_scale_f16(W)
+        self.packed = pack_rows_g8(W, self.scale)
+        self.Kp = self.packed.shape[1]
+
+    @staticmethod
+    def eligible(N: int, K: int) -> bool:
+        return N >= SPLIT_MIN_N and K >= SPLIT_MIN_K
+
+    @property
+    def shape(self):
+        return (self.N, self.K)
 
 
-PACK_WEIGHTS = True   # "f16x3": stage pre-packed weights (no split arithmetic for W in the GEMM); False = split W on the fly
-
-
-# "f16x3": let under-filled launches split K over workgroup pairs (csrc/gemm_f16x3.hip).  Correct and bit-reproducible, but
-# measured SLOWER than the unsplit launches on this path (proj 41 -> 49 us, qkv 98 -> 112 us: the 64 KiB per-tile hand-over
-# through device-coherent accesses costs more than the better occupancy gains), so it is off.
-SPLIT_K = False
-_F16X3_WS = {}        # (device index, stream handle) -> [zeroed workspace tensor, launch counter]
-
-
-def _f16x3_workspace(device):
-    key = (device.index, _stream())
-    ent = _F16X3_WS.get(key)
-    if ent is None:
-        ent = _F16X3_WS[key] = [torch.zeros(_lib.load().psam_gemm_f16x3_workspace_bytes(), dtype=torch.uint8, device=device), 0]
-    ent[1] = ent[1] % 0xFFFFFFF0 + 1          # non-zero, unique per launch on this workspace
-    return ent[0], ent[1]
-
-
-def _f16x3_call(fn_args, flops, M, N, K, device):
+def _f16x3p_call(fn_args, flops, M, N, K):
     global _gemm_counter
     L = _lib.load()
     _gemm_counter += 1
-    if SPLIT_K:
-        ws, epoch = _f16x3_workspace(device)
-        fn_args = fn_args[:-1] + (ws.data_ptr(), ws.numel(), epoch, fn_args[-1])
-    else:
-        fn_args = fn_args[:-1] + (0, 0, 0, fn_args[-1])
     if not _sample_now():
-        check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3")
+        check(L.psam_gemm_f16x3p(*fn_args), "psam_gemm_f16x3p")
         return
-    _sampled_launch(lambda: check(L.psam_gemm_f16x3_ws(*fn_args), "psam_gemm_f16x3"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3")))
+    _sampled_launch(lambda: check(L.psam_gemm_f16x3p(*fn_args), "psam_gemm_f16x3p"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3")))
 
 
 def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False):
-    """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views.
-    x_scale: optional precomputed row_scale_f16(x, K) ("f16x3" mode; computed here otherwise); x_packed: x is already the
-    f16x2-packed form of the row-scaled activations (x_scale required; "f16x3" mode only)."""
-    packed = None
-    if isinstance(W, PackedWeight):
-        packed, W = W, W.fp32
+    """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views, or W an F16Weight
+    (prepared static weight).
+    "f16x3" mode with an F16Weight and M above the threshold runs the packed-operand GEMM (csrc/gemm_f16x3p.hip): x is either already
+    g8-packed by its producer (x_packed=True with x_scale: LayerNorm / scale_pack_rows_g8 output, [M, >= K padded to 32]) or is
+    scaled and packed here in one extra pass."""
+    fw = None
+    if isinstance(W, F16Weight):
+        fw, W = W, W.fp32
     xp, ldx = _row_view(x, "x")
     wp, ldw = _row_view(W, "W")
     M = x.shape[0]
     N = W.shape[0]
     if K is None:
         K = W.shape[1]
-        assert x.shape[1] == K, (x.shape, W.shape)
-    elif packed is not None and K != packed.K:
-        packed = None
+        assert x_packed or x.shape[1] == K, (x.shape, W.shape)
+    elif fw is not None and K != fw.K:
+        fw = None
     if out is None:
         out = torch.empty(M, N // 2 if act == ACT_SWIGLU else N, dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
-    if GEMM_MODE == "f16x3" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
-        sa = row_scale_f16(x, K) if x_scale is None else x_scale
-        if PACK_WEIGHTS:
-            wpk, sw = weight_packed_f16(W, K)
-            wp, ldw, wflag = wpk.data_ptr(), wpk.stride(0), 1
+    if GEMM_MODE == "f16x3" and fw is not None and M >= SPLIT_MIN_M:
+        if x_packed:
+            if x_scale is None or x.shape[1] < fw.Kp or (ldx & 7) or (xp & 31):
+                raise ValueError("x_packed needs x_scale and g8-packed rows padded to a multiple of 32 columns, 32-byte aligned")
+            xa, sa = x, x_scale
         else:
-            sw, wflag = weight_scale_f16(W, K), 0
-        _f16x3_call((xp, ldx, sa.data_ptr(), 1 if x_packed else 0, wp, ldw, sw.data_ptr(), wflag, op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup,
-                     M, N, K, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K, x.device)
+            xa, sa = scale_pack_rows_g8(x, K)
+        _f16x3p_call((xa.data_ptr(), xa.stride(0), sa.data_ptr(), fw.packed.data_ptr(), fw.packed.stride(0), fw.scale.data_ptr(), op, ldo, _p(bias),
+                      rp, ldr, rbp, ldrb, rowgroup, M, N, fw.Kp, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K)
         return out
     if x_packed:
-        raise ValueError("x_packed activations can only feed an f16x3 GEMM (M, N, K above the split thresholds)")
-    if packed is not None and GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K:
-        _packed_gemm_call((xp, ldx, packed.data.data_ptr(), op, ldo, _p(bias), rp, ldr, rbp, ldrb, rowgroup, M, N, K, 1.0, act, _stream()),
-                          2.0 * M * N * K, M, N, K)
-        return out
+        raise ValueError("x_packed activations can only feed an f16x3 GEMM with a prepared F16Weight (M above the split threshold)")
     _gemm_call((xp, ldx, 0, 0, wp, ldw, 0, 0, op, ldo, 0, 0, _p(bias), rp, ldr, 0, 0, rbp, ldrb, rowgroup, M, N, K, 1, 1, 1.0, act, _stream()),
                2.0 * M * N * K, M, N, K, "psam_gemm_f32")
     return out
@@ -344,14 +307,20 @@ def layernorm_can_pack(cols: int) -> bool:
     return 256 <= cols <= 4096
 
 
+def packed_cols(cols: int) -> int:
+    """Columns of the buffer that receives a g8-packed row of `cols` values (zero-padded to the GEMM's 32-k slab)."""
+    return _kpad(cols)
+
+
 def layernorm(x, w, b, eps, act=ACT_NONE, residual=None, out=None, scale_out=None, pack=False):
     """y = act(LN(x + residual)) over the last dim of a 2-D row view.  scale_out ([rows] fp32, optional) receives the f16x3
-    row scales of y (what row_scale_f16(y) would compute), for the GEMM that consumes y.  pack=True: out receives the f16x2-packed
-    form of the scaled rows instead of fp32 (linear(..., x_scale=scale_out, x_packed=True))."""
+    row scales of y (what row_scale_f16(y) would compute), for the GEMM that consumes y.  pack=True: out receives the g8-packed
+    form of the scaled rows instead of fp32 (linear(..., x_scale=scale_out, x_packed=True)); out needs packed_cols(cols) columns
+    of room per row for the zero padding (or exactly cols when cols % 8 == 0 and the padding already holds zeros)."""
     xp, ldx = _row_view(x, "x")
     rows, cols = x.shape
     if out is None:
-        out = torch.empty(rows, cols, dtype=torch.float32, device=x.device)
+        out = torch.empty(rows, _kpad(cols) if pack else cols, dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     check(_lib.load().psam_layernorm_ex(xp, ldx, rp, ldr, w.data_ptr(), b.data_ptr(), op, ldo, rows, cols, eps, act, _p(scale_out), 1 if pack else 0,

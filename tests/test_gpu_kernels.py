@@ -85,7 +85,7 @@ def test_fps_cooperative_under_memory_load(ops):
     x = cu(xyz)
     big = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     a = torch.randn(4096, 1024, device="cuda")
-    w = torch.randn(3072, 1024, device="cuda")
+    w = ops.F16Weight(torch.randn(3072, 1024, device="cuda"))
     side = torch.cuda.Stream()
     stop = torch.cuda.Event()
     for rep in range(4):
@@ -223,11 +223,15 @@ def test_gemm_bf16x6_matches_fp64_like_f32(ops, M, N, K):
     assert errs["bf16x6"] < 4 * errs["f32"] + 1e-7, errs
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 36), (520, 640, 2752)])
+F16X3P_CFGS = [-1, 0, 4, 9, 12, 14, 21, 23, 28]   # tile / ring configurations of csrc/gemm_f16x3p.hip (-1 = the host's choice)
+
+
+@pytest.mark.parametrize("cfg", F16X3P_CFGS)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 160), (520, 640, 2752), (777, 3072, 256)])
 def test_gemm_f16x3_matches_fp64_like_f32(ops, cfg, M, N, K):
-    """The scaled 2-way fp16 split GEMM must be in the accuracy class of the f32-MFMA GEMM (both against fp64): operands with
-    a wide dynamic range across rows AND along k, ragged M/N, K tail, bias + GELU + residual epilogue."""
+    """The packed-operand, scaled 2-way fp16 split GEMM must be in the accuracy class of the f32-MFMA GEMM (both against fp64): operands
+    with a wide dynamic range across rows AND along k, ragged M/N, K not a multiple of the 32-k slab (zero padding), bias + GELU +
+    residual epilogue -- for every tile / ring configuration."""
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
     W = torch.randn(N, K, generator=g) * torch.exp(torch.randn(1, K, generator=g)) / K ** 0.5
@@ -235,15 +239,16 @@ def test_gemm_f16x3_matches_fp64_like_f32(ops, cfg, M, N, K):
     want = F.gelu(x.double() @ W.double().T + b.double()) + res.double()
     scale = (x.double().abs() @ W.double().abs().T + 1.0)
     L = ops._lib.load()
+    fw = ops.F16Weight(cu(W))
     errs = {}
-    L.psam_gemm_f16x3_force_config(cfg)
+    L.psam_gemm_f16x3p_force_config(cfg)
     try:
         for mode in ("f32", "f16x3"):
             with ops.gemm_mode(mode):
-                y = ops.linear(cu(x), cu(W), cu(b), act=ops.ACT_GELU, residual=cu(res))
+                y = ops.linear(cu(x), fw, cu(b), act=ops.ACT_GELU, residual=cu(res))
             errs[mode] = ((y.cpu().double() - want).abs() / scale).max().item()
     finally:
-        L.psam_gemm_f16x3_force_config(-1)
+        L.psam_gemm_f16x3p_force_config(-1)
     assert errs["f16x3"] < 3e-7 * math.sqrt(K) + 1e-7, errs
     assert errs["f16x3"] < 4 * errs["f32"] + 1e-7, errs
 
@@ -259,7 +264,7 @@ def test_gemm_f16x3_extreme_row_scales(ops):
     x[9] = torch.randn(K, generator=g) * (2.0 ** -torch.arange(K).remainder(19).float())
     W = torch.randn(N, K, generator=g) * (10.0 ** torch.linspace(-6, 6, N)).unsqueeze(1)
     with ops.gemm_mode("f16x3"):
-        y = ops.linear(cu(x), cu(W)).cpu().double()
+        y = ops.linear(cu(x), ops.F16Weight(cu(W))).cpu().double()
     want = x.double() @ W.double().T
     scale = x.double().abs() @ W.double().abs().T
     assert torch.isfinite(y).all()
@@ -287,92 +292,79 @@ def test_layernorm_emits_f16x3_row_scale(ops, cols):
         assert torch.equal(y, ops.layernorm(x, w, b, 1e-5, act=act))
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (520, 640, 2752)])
-def test_gemm_f16x3_packed_operands(ops, M, N, K):
-    """Pre-packed (hi|lo fp16) operands give bit-identical results to splitting on the fly, for every packed/unpacked pairing."""
+def _unpack_g8(p, scale, K):
+    """[rows, Kp] g8-packed containers -> (hi + lo) / scale as fp64 [rows, K] (test helper: the inverse of the packing)."""
+    rows, Kp = p.shape
+    h = p.contiguous().view(torch.float16).view(rows, Kp // 8, 2, 8).double()        # [rows, group, hi|lo, 8]
+    return ((h[:, :, 0] + h[:, :, 1]).reshape(rows, Kp) / scale.double()[:, None])[:, :K]
+
+
+@pytest.mark.parametrize("M,K", [(300, 128), (256, 516), (1000, 1024), (77, 2752), (130, 6144), (64, 36)])
+def test_g8_packing(ops, M, K):
+    """pack_rows_g8 (static weights) and scale_pack_rows_g8 (activations, one pass): identical bits; the decoded value is the input to
+    2^-21 relative (hi + lo = 22 significand bits); the K padding up to the 32-k slab is zero."""
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))).cuda()
+    s = ops.row_scale_f16(x)
+    p = ops.pack_rows_g8(x, s)
+    Kp = (K + 31) // 32 * 32
+    assert p.shape == (M, Kp)
+    dec = _unpack_g8(p, s, Kp)
+    assert (dec[:, K:] == 0).all()
+    rel = ((dec[:, :K] - x.double()).abs() / x.double().abs().amax(1, keepdim=True)).max().item()
+    assert rel < 2.0 ** -21, rel
+    if K % 4 == 0:
+        p2, s2 = ops.scale_pack_rows_g8(x)
+        assert torch.equal(s2, s) and torch.equal(p2.view(torch.int32), p.view(torch.int32))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 392, 516), (4096, 1024, 1024), (520, 640, 2752)])
+def test_gemm_f16x3_packed_activations(ops, M, N, K):
+    """An activation packed by its producer (x_packed=True) gives bit-identical results to packing inside linear()."""
     g = torch.Generator().manual_seed(M + N)
     x = (torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))).cuda()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     b, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
-    L = ops._lib.load()
-    sa, sw = ops.row_scale_f16(x), ops.row_scale_f16(W)
-    xp, wp = ops.pack_rows_f16x2(x, sa), ops.pack_rows_f16x2(W, sw)
-    st = torch.cuda.current_stream().cuda_stream
-    outs = {}
-    for ap in (0, 1):
-        for wpk in (0, 1):
-            y = torch.empty(M, N, device="cuda")
-            rc = L.psam_gemm_f16x3_ex((xp if ap else x).data_ptr(), K, sa.data_ptr(), ap, (wp if wpk else W).data_ptr(), K, sw.data_ptr(), wpk, y.data_ptr(), N,
-                                      b.data_ptr(), res.data_ptr(), N, 0, 0, 0, M, N, K, 1.0, 1, st)
-            assert rc == 0, L.psam_last_error_string()
-            outs[(ap, wpk)] = y
-    L.psam_gemm_f16x3_force_config(3)
-    try:
-        with ops.gemm_mode("f16x3"):
-            ref = ops.linear(x, W, b, act=ops.ACT_GELU, residual=res)
-    finally:
-        L.psam_gemm_f16x3_force_config(-1)
-    for k, y in outs.items():
-        assert torch.equal(y, ref), k
-    xin = x.clone()
-    assert torch.equal(ops.pack_rows_f16x2(xin, sa, out=xin), xp)          # in place
+    fw = ops.F16Weight(W)
+    xp, sa = ops.scale_pack_rows_g8(x)
+    with ops.gemm_mode("f16x3"):
+        ref = ops.linear(x, fw, b, act=ops.ACT_GELU, residual=res)
+        got = ops.linear(xp, fw, b, act=ops.ACT_GELU, residual=res, x_scale=sa, x_packed=True)
+    assert torch.equal(ref, got)
+    with pytest.raises(ValueError):
+        with ops.gemm_mode("f32"):
+            ops.linear(xp, fw, x_scale=sa, x_packed=True)
 
 
-@pytest.mark.parametrize("cols,ld", [(1024, 1024), (2730, 2752), (300, 304), (4096, 4096)])
+@pytest.mark.parametrize("cols,ld", [(1024, 1024), (2730, 2752), (300, 320), (4096, 4096)])
 def test_layernorm_packed_output(ops, cols, ld):
-    """LayerNorm with pack=True == LayerNorm followed by row_scale_f16 + pack_rows_f16x2 (bit for bit), also in place on a padded
-    buffer (the SwiGLU output of the EVA02 blocks: 2730 of 2752 columns, pad columns zero)."""
+    """LayerNorm with pack=True == LayerNorm followed by row_scale_f16 + pack_rows_g8 (bit for bit), also in place on a padded
+    buffer (the SwiGLU output of the EVA02 blocks: 2730 of 2752 columns); the K padding is written as zeros."""
     g = torch.Generator().manual_seed(cols)
-    buf = torch.zeros(300, ld)
+    buf = torch.full((300, ld), 7.0)      # non-zero padding: the kernel must overwrite it with zeros
     buf[:, :cols] = torch.randn(300, cols, generator=g) * torch.exp(torch.randn(300, 1, generator=g))
     w, b = torch.randn(cols, generator=g).cuda(), torch.randn(cols, generator=g).cuda()
     x = buf.cuda()
-    y = ops.layernorm(x[:, :cols], w, b, 1e-6, out=torch.zeros_like(x)[:, :cols])
-    ybuf = torch.zeros_like(x); ybuf[:, :cols] = y
-    sa = ops.row_scale_f16(ybuf)
-    want = ops.pack_rows_f16x2(ybuf, sa)
+    y = ops.layernorm(x[:, :cols], w, b, 1e-6)
+    sa = ops.row_scale_f16(y)
+    want = ops.pack_rows_g8(y, sa)                      # [300, Kp]
+    Kp = want.shape[1]
     rs = torch.empty(300, device="cuda")
     xin = x.clone()
     ops.layernorm(xin[:, :cols], w, b, 1e-6, out=xin[:, :cols], scale_out=rs, pack=True)      # in place, padded
     assert torch.equal(rs, sa)
+    got = xin[:, :Kp].contiguous().view(torch.int32)
     if cols % 4 == 0:
-        assert torch.equal(xin.view(torch.int32), want.view(torch.int32))
-    else:   # the ragged last group is evaluated element-wise in the unpacked kernel (FMA contraction may differ by an ulp)
-        full = (cols // 4) * 4
-        assert torch.equal(xin[:, :full].view(torch.int32), want[:, :full].view(torch.int32))
-        assert torch.equal(xin[:, full + 4:].view(torch.int32), want[:, full + 4:].view(torch.int32))
-        h = xin[:, full:full + 4].contiguous().view(torch.float16).float()          # [rows, 8]: hi x4 | lo x4
-        dec = (h[:, :4] + h[:, 4:]) / rs[:, None]
-        assert torch.allclose(dec[:, : cols - full], y[:, full:], rtol=2e-6, atol=1e-7) and (dec[:, cols - full:] == 0).all()
-
-
-@pytest.mark.parametrize("M,N,K,act", [(4096, 1024, 1024, 1), (4096, 1024, 2752, 0), (4096, 3072, 1024, 0), (2048, 1024, 512, 3), (1000, 392, 516, 1)])
-def test_gemm_f16x3_split_k(ops, M, N, K, act):
-    """Split-K over workgroup pairs (under-filled launches): accuracy class unchanged, bit-reproducible run to run (the owner
-    adds the partner's partial in a fixed order), and the workspace/epoch protocol survives many back-to-back launches."""
-    g = torch.Generator().manual_seed(M + N + K)
-    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
-    b = torch.randn(N, generator=g).cuda()
-    res = None if act == 3 else torch.randn(M, N, generator=g).cuda()
-    outs = {}
-    for split in (False, True):
-        ops.SPLIT_K = split
-        try:
-            with ops.gemm_mode("f16x3"):
-                ys = [ops.linear(x, W, b, act=act, residual=res) for _ in range(6)]
-        finally:
-            ops.SPLIT_K = False
-        assert all(torch.equal(ys[0], y) for y in ys[1:]), "not reproducible"
-        outs[split] = ys[0]
-    if act == 3:
-        return
-    want = x.double() @ W.double().T + b.double()
-    want = (F.gelu(want) if act == 1 else want) + res.double()
-    scale = x.double().abs() @ W.double().abs().T + 1.0
-    e0 = ((outs[False].double() - want).abs() / scale).max().item()
-    e1 = ((outs[True].double() - want).abs() / scale).max().item()
-    assert e1 < 2 * e0 + 1e-7, (e0, e1)
+        assert torch.equal(got, want.view(torch.int32))
+    else:   # the ragged last float4 is evaluated element-wise in the unpacked kernel (FMA contraction may differ by an ulp)
+        g8 = (cols // 8) * 8
+        assert torch.equal(got[:, :g8], want.view(torch.int32)[:, :g8])
+        assert torch.equal(got[:, g8 + 8:], want.view(torch.int32)[:, g8 + 8:])
+        dec = _unpack_g8(xin[:, :Kp], rs, Kp)
+        assert torch.allclose(dec[:, g8:cols].float(), y[:, g8:], rtol=2e-6, atol=1e-7) and (dec[:, cols:] == 0).all()
+    rs2 = torch.empty(300, device="cuda")
+    out = ops.layernorm(x[:, :cols], w, b, 1e-6, scale_out=rs2, pack=True)                      # out of place: a [rows, Kp] buffer
+    assert out.shape == (300, Kp) and torch.equal(out.view(torch.int32), got) and torch.equal(rs2, sa)
 
 
 def test_gemm_f16x3_epilogues(ops):
@@ -385,16 +377,24 @@ def test_gemm_f16x3_epilogues(ops):
     W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
     b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
     rb = torch.randn(M // grp, 2 * Hp, generator=g)
-    with ops.gemm_mode("f16x3"):
-        u = ops.linear(cu(x), cu(W1), cu(b1), act=ops.ACT_SWIGLU)
-        y = ops.linear(cu(x), cu(W1), None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
-        xs = ops.row_scale_f16(cu(x))
-        y2 = ops.linear(cu(x), cu(W1), None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp, x_scale=xs)
+    fw = ops.F16Weight(cu(W1))
+    L = ops._lib.load()
     want = F.silu(F.linear(x.double(), Wg.double(), bg.double())) * F.linear(x.double(), Wx.double(), bx.double())
-    _close(u[:, :H], want, 1e-4, what="f16x3 swiglu epilogue")
-    assert (u[:, H:] == 0).all()
-    _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what="f16x3 rowbias+relu")
-    assert torch.equal(y, y2)
+    for cfg in F16X3P_CFGS:
+        L.psam_gemm_f16x3p_force_config(cfg)
+        try:
+            with ops.gemm_mode("f16x3"):
+                if cfg in (12, 23):     # three-tile-wide wave tiles cannot pair gate / value tiles: rejected, not mis-computed
+                    with pytest.raises(ops._lib.PointSamHipError):
+                        ops.linear(cu(x), fw, cu(b1), act=ops.ACT_SWIGLU)
+                else:
+                    u = ops.linear(cu(x), fw, cu(b1), act=ops.ACT_SWIGLU)
+                    _close(u[:, :H], want, 1e-4, what=f"f16x3 swiglu epilogue cfg{cfg}")
+                    assert (u[:, H:] == 0).all()
+                y = ops.linear(cu(x), fw, None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
+        finally:
+            L.psam_gemm_f16x3p_force_config(-1)
+        _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what=f"f16x3 rowbias+relu cfg{cfg}")
 
 
 def test_gemm_bf16x6_epilogues(ops):
@@ -609,49 +609,3 @@ def test_border_farthest_and_error_regions(ops, N, B, rep):
         for z in range(Z):
             wi, wd = O.border_farthest(xyz[z // rep], reg[z])
             assert int(idx[z]) == wi and float(dist[z]) == wd, (name, z, int(idx[z]), wi, float(dist[z]), wd)
-
-
-@pytest.mark.parametrize("cfg", [0, 1, -1])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 392, 516), (4096, 1024, 1024), (300, 130, 36), (640, 2752, 96), (512, 160, 2752)])
-def test_gemm_bf16x6_packed_weight(ops, cfg, M, N, K):
-    """Pre-packed-weight bf16x6 GEMM: same accuracy class as the f32-MFMA GEMM against fp64, ragged M/N, K tails, epilogues."""
-    g = torch.Generator().manual_seed(M + N + K)
-    x = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, 1, generator=g))
-    W = torch.randn(N, K, generator=g) * torch.exp(torch.randn(1, K, generator=g)) / K ** 0.5
-    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    want = F.gelu(x.double() @ W.double().T + b.double()) + res.double()
-    scale = (x.double().abs() @ W.double().abs().T + 1.0)
-    Wd = cu(W)
-    pw = ops.PackedWeight(Wd)
-    L = ops._lib.load()
-    L.psam_gemm_bf16x6_pw_force_config(cfg)
-    try:
-        with ops.gemm_mode("bf16x6"):
-            y = ops.linear(cu(x), pw, cu(b), act=ops.ACT_GELU, residual=cu(res))
-        with ops.gemm_mode("f32"):
-            y32 = ops.linear(cu(x), pw, cu(b), act=ops.ACT_GELU, residual=cu(res))   # packed object falls back to its fp32 weight
-    finally:
-        L.psam_gemm_bf16x6_pw_force_config(-1)
-    e = ((y.cpu().double() - want).abs() / scale).max().item()
-    e32 = ((y32.cpu().double() - want).abs() / scale).max().item()
-    assert e < 3e-7 * math.sqrt(K) + 1e-7 and e < 4 * e32 + 1e-7, (e, e32)
-
-
-def test_gemm_bf16x6_packed_weight_swiglu_and_rowbias(ops):
-    g = torch.Generator().manual_seed(5)
-    M, D, H, Hp, grp = 384, 128, 170, 192, 64
-    x = torch.randn(M, D, generator=g)
-    Wg, Wx = torch.randn(H, D, generator=g) / D ** 0.5, torch.randn(H, D, generator=g) / D ** 0.5
-    bg, bx = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
-    pad = lambda t: torch.cat([t, torch.zeros((Hp - H,) + tuple(t.shape[1:]))], 0)
-    W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
-    b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
-    rb = torch.randn(M // grp, 2 * Hp, generator=g)
-    pw = ops.PackedWeight(cu(W1))
-    with ops.gemm_mode("bf16x6"):
-        u = ops.linear(cu(x), pw, cu(b1), act=ops.ACT_SWIGLU)
-        y = ops.linear(cu(x), pw, None, act=ops.ACT_RELU, rowbias=cu(rb), rowgroup=grp)
-    want = F.silu(F.linear(x.double(), Wg.double(), bg.double())) * F.linear(x.double(), Wx.double(), bx.double())
-    _close(u[:, :H], want, 1e-4, what="packed swiglu epilogue")
-    assert (u[:, H:] == 0).all()
-    _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what="packed rowbias+relu")
