@@ -129,6 +129,25 @@ int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const 
                          const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,
                          int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
 void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring configuration index, -1 = auto */
+/* The same GEMM with fused extras (all optional; M % 256 == 0 and N % 128 == 0 required when any is used) -- what lets the EVA02 MLP
+ * `fc2(LayerNorm(SiLU(fc1_g x) * fc1_x x))` (timm SwiGLU with scale_mlp) run as two GEMMs and nothing in between:
+ *   pack_out : C receives the g8-packed output rows (the next GEMM's A operand), scaled per row by out_scale[row] (written here) =
+ *              the power of two that puts the BOUND B = out_k1 / scaleA[row] + out_k2 (B^2 with the SwiGLU gate) of the row's magnitude
+ *              into [2^14, 2^15) -- out_k1 = 2^15 sqrt(K) max_n ||W[n]||_2, out_k2 = max |bias| (Cauchy-Schwarz);
+ *   stats    : [M, psam_gemm_f16x3p_stat_segs(N), 2] (mean, centred sum of squares) of every 32-column segment of the gated rows over
+ *              the columns < stat_cols; psam_ln_stats_finalize merges them (fixed order) into the LayerNorm's mean / rstd per row;
+ *   ln_*     : LayerNorm of the A rows folded into the GEMM: C = rstd[row] (A W'^T - mean[row] c[col]) + bias (+ residual), with the
+ *              caller's W' = W * gamma (per column), c = W' 1, bias = W beta + b. */
+typedef struct {
+    float* out_scale; float out_k1, out_k2; int32_t pack_out;
+    float* stats; int32_t stat_cols;
+    const float* ln_mean; const float* ln_rstd; const float* ln_c;
+} psam_gemm_fuse_t;
+int32_t psam_gemm_f16x3p_stat_segs(int32_t N);
+int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C, int64_t ldc,
+                            const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,
+                            int32_t N, int32_t K, float alpha, int32_t act, const psam_gemm_fuse_t* fuse, psam_stream_t stream);
+int32_t psam_ln_stats_finalize(const float* stats, int32_t rows, int32_t segs, int32_t cols, float eps, float* mean, float* rstd, psam_stream_t stream);
 /* Row scales and g8 packing of fp32 rows in ONE pass (an activation no LayerNorm produced, e.g. the attention output). */
 int32_t psam_scale_pack_rows_g8(const float* X, int64_t ldx, int32_t rows, int32_t K, void* P, int64_t ldp, float* scale, psam_stream_t stream);
 int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, float* y,

@@ -41,6 +41,9 @@ SIGNATURES = {
     "psam_pack_rows_f16x2_g8": (i32, [ptr, i64, ptr, i32, i32, ptr, i64, ptr]),
     "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3p_force_config": (None, [i32]),
+    "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
+    "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
+    "psam_ln_stats_finalize": (i32, [ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_scale_pack_rows_g8": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, ptr]),
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
     "psam_layernorm_rs": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, ptr]),
@@ -54,6 +57,14 @@ SIGNATURES = {
     "psam_add_bcast": (i32, [ptr, i64, i32, ptr, i64, i64, ptr, i64, i64, i64, i32, ptr]),
     "psam_interp3": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr]),
 }
+
+
+
+class GemmFuse(ctypes.Structure):
+    """psam_gemm_fuse_t (include/pointsam_hip.h)."""
+    _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
+                ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr)]
+
 
 _lib = None
 

@@ -33,7 +33,16 @@ __device__ __forceinline__ void ep_wave_sync() {
 // act == 3 (SwiGLU gate fused into fc1): accumulator tile j = 2q holds g and tile 2q+1 holds x of the same 32 hidden units
 // (the packed weight alternates 32-row blocks of fc1_g and fc1_x); the output has N/2 columns, no alpha/rowbias/residual.
 // SCALED (gemm_f16x3.hip): ArgsT also has scaleA[M], scaleW[N]; the accumulator is multiplied by 1/(scaleA[row] scaleW[col]).
-template <int TM, int TN, bool SCALED = false, typename ArgsT>
+// EXT (gemm_f16x3p.hip; ArgsT then also has the psam_gemm_fuse_t fields, interior tiles only -- the host guarantees it):
+//  * pack_out: C receives the g8-packed form ([hi x8 | lo x8] fp16 per 8 columns, gemm_f16x3p.hip) of the output row scaled by
+//    out_scale[row] = f16_row_scale(B^2), B = out_k1 / scaleA[row] + out_k2 -- an a-priori BOUND on the row's magnitude (Cauchy-Schwarz
+//    on the A row's maximum and the weight row norms) instead of its maximum, which no single tile knows; the bound costs a few of
+//    the 18 binades of full-precision range and cannot overflow.  The output can then feed the next GEMM with no pass in between.
+//  * stats (with the SwiGLU gate): per row and per wave-wide column segment (TN*16 gated outputs) the segment's mean and centred sum
+//    of squares over the columns < stat_cols -- the partials of a LayerNorm over the gated row (merged by psam_ln_stats_finalize).
+//  * ln_mean / ln_rstd / ln_c: the LayerNorm of the A rows folded into this GEMM -- C = rstd[row] * (A W'^T - mean[row] * c[col]) + bias
+//    with W' = W * gamma (columns), c = W' 1, bias = W beta + b.
+template <int TM, int TN, bool SCALED = false, bool EXT = false, typename ArgsT>
 __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], float* __restrict__ lw, int row_base, int col_base,
                                                 int lane, float* __restrict__ C, const float* __restrict__ R) {
     const int r32 = lane & 31, h = lane >> 5;
@@ -52,6 +61,8 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     const int pcol = col_base + scol;                                            // its column in N (packed, for the gate)
     const int ocol = swiglu ? (col_base >> 1) + c4 * 4 : pcol;                   // output column
     ep_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, m0 = {alpha, alpha, alpha, alpha}, m1 = m0;
+    ep_f32x4 lnc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EXT) { if (interior && lane_on && p.ln_c) lnc = ep_load4(p.ln_c + pcol); }
     if (interior && lane_on) {
         if (p.bias) { b0 = ep_load4(p.bias + pcol); if (swiglu) b1 = ep_load4(p.bias + pcol + 32); }
         if constexpr (SCALED) {
@@ -88,19 +99,57 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                         const int row = row_base + i * 32 + rl;
                         ep_f32x4 v = ep_load4(lw + rl * LD + scol);
                         if constexpr (SCALED) v *= rs[q];
-                        v = v * m0 + b0;
+                        if constexpr (EXT) {
+                            if (p.ln_c) { v = (v * m0 - lnc * p.ln_mean[row]) * p.ln_rstd[row] + b0; } else v = v * m0 + b0;
+                        } else v = v * m0 + b0;
                         if (swiglu) {
                             ep_f32x4 x = ep_load4(lw + rl * LD + scol + 32);
                             if constexpr (SCALED) x *= rs[q];
                             x = x * m1 + b1;
                             v = ep_f32x4{silu(v[0]) * x[0], silu(v[1]) * x[1], silu(v[2]) * x[2], silu(v[3]) * x[3]};
+                            if constexpr (EXT) {
+                                if (p.stats) {     // LayerNorm partials of this row over the wave's TN*16 gated columns (valid ones: < stat_cols)
+                                    const int seg0 = col_base >> 1, nv = p.stat_cols - seg0 < TN * 16 ? (p.stat_cols - seg0 > 0 ? p.stat_cols - seg0 : 0) : TN * 16;
+                                    float sm = 0.f;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) sm += (ocol + e < p.stat_cols) ? v[e] : 0.f;
+#pragma unroll
+                                    for (int o = 1; o < TN * 4; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                                    const float mean = nv > 0 ? sm / (float)nv : 0.f;
+                                    float m2 = 0.f;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { const float d = (ocol + e < p.stat_cols) ? v[e] - mean : 0.f; m2 += d * d; }
+#pragma unroll
+                                    for (int o = 1; o < TN * 4; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+                                    if (c4 == 0) {
+                                        float* st = p.stats + ((int64_t)row * p.stat_segs + seg0 / (TN * 16)) * 2;
+                                        st[0] = mean; st[1] = m2;
+                                    }
+                                }
+                            }
                         } else {
                             if (p.rowbias) v += rb[q];
                             if (p.act == 1) v = ep_f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
                             else if (p.act == 2) v = ep_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                             if (R) v += res[q];
                         }
-                        *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
+                        bool stored = false;
+                        if constexpr (EXT) {
+                            if (p.pack_out) {      // g8-packed output with the bound-derived row scale (see the header of this function)
+                                const float bnd = p.out_k1 * rs[q] + p.out_k2;          // rs = 1 / scaleA[row]
+                                const float so = f16_row_scale(p.act == 3 ? bnd * bnd : bnd);
+                                if (c4 == 0 && col_base == 0) p.out_scale[row] = so;
+                                unsigned h0, l0, h1, l1;
+                                psam_split2_f16(v[0], v[1], so, h0, l0);
+                                psam_split2_f16(v[2], v[3], so, h1, l1);
+                                const bool odd = lane & 1;
+                                const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+                                typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+                                *reinterpret_cast<ep_u32x4*>(C + (int64_t)row * p.ldc + ocol) = odd ? ep_u32x4{r0, r1, l0, l1} : ep_u32x4{h0, h1, r0, r1};
+                                stored = true;
+                            }
+                        }
+                        if (!stored) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
                     }
                 }
             }

@@ -37,6 +37,10 @@ struct F16PArgs {
     int M, N, K, rowgroup, act;
     float alpha;
     int tiles_m, tiles_n;
+    // fused extras (psam_gemm_fuse_t, see gemm_epilogue.h): all null / 0 for the plain GEMM
+    float* out_scale; float out_k1, out_k2; int pack_out;
+    float* stats; int stat_cols, stat_segs;
+    const float* ln_mean; const float* ln_rstd; const float* ln_c;
 };
 
 #define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         if (sum == 123.456f) p.C[0] = sum;
         return;
     }
-    gemm_store_tile<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+    gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
                                   n0 + wn * TN * 32, lane, p.C, p.residual);
 }
 
@@ -424,10 +428,21 @@ static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
+// Optional fused extras of psam_gemm_f16x3p_ex (include/pointsam_hip.h: psam_gemm_fuse_t).
+struct psam_gemm_fuse_t {
+    float* out_scale; float out_k1, out_k2; int32_t pack_out;       // g8-packed output rows with a bound-derived scale
+    float* stats; int32_t stat_cols;                                // LayerNorm partials of the SwiGLU-gated rows: [M, segs, 2]
+    const float* ln_mean; const float* ln_rstd; const float* ln_c;  // LayerNorm of the A rows folded into this GEMM
+};
+
+// segments (of 32 gated columns) per row of the stats buffer of a SwiGLU GEMM with N packed weight rows
+PSAM_API int32_t psam_gemm_f16x3p_stat_segs(int32_t N) { return (N / 2 + 31) / 32; }
+
 // A [M, K] and W [N, K]: g8-packed, row-scaled (scaleA[M], scaleW[N] powers of two); K % 32 == 0 (pad with zeros), K >= 128.
-PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C,
-                                  int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
-                                  int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, hipStream_t stream) {
+PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C,
+                                     int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
+                                     int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const psam_gemm_fuse_t* fuse,
+                                     hipStream_t stream) {
     PSAM_REQUIRE(A && W && C && scaleA && scaleW, PSAM_EINVAL, "psam_gemm_f16x3p: null pointer");
     PSAM_REQUIRE(M > 0 && N > 0 && K >= 128 && (K & 31) == 0, PSAM_EINVAL, "psam_gemm_f16x3p: bad shape (K % 32 == 0, K >= 128)");
     PSAM_REQUIRE(act >= 0 && act <= 3, PSAM_EINVAL, "psam_gemm_f16x3p: bad activation code");
@@ -441,8 +456,24 @@ PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scale
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias;
     p.scaleA = scaleA; p.scaleW = scaleW; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
+    p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
+    p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act);
+    if (fuse && (fuse->pack_out || fuse->stats || fuse->ln_c)) {
+        // The fused epilogue paths exist for interior tiles of the two-tile-wide wave tiles only: whole 256-row / 128-column tiles.
+        PSAM_REQUIRE((M & 255) == 0 && (N & 127) == 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: fused extras need M % 256 == 0 and N % 128 == 0");
+        PSAM_REQUIRE(!fuse->pack_out || (fuse->out_scale && (ldc & 7) == 0 && ((uintptr_t)C & 31) == 0), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: packed output needs out_scale and 32-byte aligned output rows");
+        PSAM_REQUIRE(!fuse->stats || (act == 3 && fuse->stat_cols > 0 && fuse->stat_cols <= N / 2), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: row statistics come with the SwiGLU epilogue (0 < stat_cols <= N / 2)");
+        PSAM_REQUIRE(!fuse->ln_c || (fuse->ln_mean && fuse->ln_rstd && act != 3), PSAM_EINVAL, "psam_gemm_f16x3p_ex: folded LayerNorm needs mean, rstd, c (no SwiGLU)");
+        PSAM_REQUIRE(((uintptr_t)fuse->ln_c & 15) == 0, PSAM_EALIGN, "psam_gemm_f16x3p_ex: ln_c must be 16-byte aligned");
+        p.out_scale = fuse->out_scale; p.out_k1 = fuse->out_k1; p.out_k2 = fuse->out_k2; p.pack_out = fuse->pack_out;
+        p.stats = fuse->stats; p.stat_cols = fuse->stat_cols; p.stat_segs = psam_gemm_f16x3p_stat_segs(N);
+        p.ln_mean = fuse->ln_mean; p.ln_rstd = fuse->ln_rstd; p.ln_c = fuse->ln_c;
+        if (cfg != 4 && cfg != 9) cfg = (N >= 2048) ? 4 : 9;      // 256x128 / 128x128 tiles: wave tiles two 32-column tiles wide
+    }
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2
         const int which = (cfg - 100) / 32, abl = (cfg - 100) % 32;
@@ -469,4 +500,58 @@ PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scale
     }
     psam_set_error("psam_gemm_f16x3p: unknown config");
     return PSAM_EINVAL;
+}
+
+PSAM_API int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C,
+                                  int64_t ldc, const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb,
+                                  int32_t rowgroup, int32_t M, int32_t N, int32_t K, float alpha, int32_t act, hipStream_t stream) {
+    return psam_gemm_f16x3p_ex(A, lda, scaleA, W, ldw, scaleW, C, ldc, bias, residual, ldr, rowbias, ldrb, rowgroup, M, N, K, alpha, act, nullptr, stream);
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm statistics from the partials
+// stats [rows, segs, 2] = (mean, centred sum of squares) of consecutive 32-column segments of a row (the last used one may hold fewer
+// columns); merged in a FIXED order (Chan et al.: exact in real arithmetic, no cancellation; bit-reproducible) -> mean[rows],
+// rstd[rows] = 1 / sqrt(M2 / cols + eps).
+// One wave per row: lane l merges segments l, l + 64, ... in order, then the 64 lane partials merge in a fixed butterfly.
+__device__ __forceinline__ void chan_merge(float& n, float& mu, float& m2, float nb, float mb, float qb) {
+    const float nn = n + nb;
+    if (nn > 0.f) {
+        const float d = mb - mu, f = nb / nn;
+        mu += d * f;
+        m2 += qb + d * d * (n * f);
+        n = nn;
+    }
+}
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ stats, int rows, int segs, int cols, float eps,
+                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+    typedef float st_f32x2 __attribute__((ext_vector_type(2)));
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const st_f32x2* st = reinterpret_cast<const st_f32x2*>(stats + (int64_t)row * segs * 2);
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    for (int t = lane; t * 32 < cols; t += 64) {
+        const st_f32x2 v = st[t];
+        chan_merge(n, mu, m2, (float)(cols - t * 32 < 32 ? cols - t * 32 : 32), v[0], v[1]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mu, o, 64), qb = __shfl_xor(m2, o, 64);
+        // both partners must compute the SAME merged triple: order the pair by lane (lower lane first)
+        const bool lo = (lane & o) == 0;
+        float n0 = lo ? n : nb, mu0 = lo ? mu : mb, m20 = lo ? m2 : qb;
+        chan_merge(n0, mu0, m20, lo ? nb : n, lo ? mb : mu, lo ? qb : m2);
+        n = n0; mu = mu0; m2 = m20;
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = 1.0f / sqrtf(m2 / (float)cols + eps);
+    }
+}
+
+PSAM_API int32_t psam_ln_stats_finalize(const float* stats, int32_t rows, int32_t segs, int32_t cols, float eps, float* mean, float* rstd,
+                                        hipStream_t stream) {
+    PSAM_REQUIRE(stats && mean && rstd, PSAM_EINVAL, "psam_ln_stats_finalize: null pointer");
+    PSAM_REQUIRE(rows > 0 && cols > 0 && segs * 32 >= cols, PSAM_EINVAL, "psam_ln_stats_finalize: bad shape");
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, stats, rows, segs, cols, eps, mean, rstd);
+    return psam_launch_status("psam_ln_stats_finalize: launch failed");
 }

@@ -69,6 +69,7 @@ class PointCloudSAM:
         if precision not in ops.GEMM_MODES:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
         self.precision = precision
+        self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -128,6 +129,19 @@ class PointCloudSAM:
                     if ops.F16Weight.eligible(*sl.shape):
                         self.fw[prefix + ".conv2.0.weight" + tag] = ops.F16Weight(sl)
             for blk in self.blocks:
+                if cfg.vit.swiglu and ops.F16Weight.eligible(*blk.w2.shape):
+                    # fused MLP (csrc/gemm_f16x3p.hip, psam_gemm_fuse_t): fc1 emits the gated rows already packed for fc2 (scale from the
+                    # bound B^2, B = 2^15 sqrt(D) max_n ||W1[n]|| / scale(h) + max|b1|) plus LayerNorm partials; the inner LayerNorm is
+                    # folded into fc2:  fc2(LN(u)) = rstd (u (W2 gamma)^T - mean c) + d,  c = (W2 gamma) 1,  d = W2 beta + b2.
+                    H, Hp = cfg.vit.mlp_hidden, blk.hp
+                    gam = torch.zeros(Hp, device=self.device, dtype=torch.float64)
+                    gam[:H] = w[blk.p + ".mlp.norm.weight"].double()
+                    w2g = blk.w2.double() * gam[None, :]
+                    blk.ln_c = w2g.sum(1).float().contiguous()
+                    blk.ln_d = (blk.w2.double()[:, :H] @ w[blk.p + ".mlp.norm.bias"].double() + w[blk.p + ".mlp.fc2.bias"].double()).float().contiguous()
+                    blk.w2g = ops.F16Weight(w2g.float().contiguous())
+                    blk.k1 = float(2.0 ** 15 * math.sqrt(D) * blk.w1.double().norm(dim=1).max().item())
+                    blk.k2 = float(blk.b1.abs().max().item())
                 for attr in ("wqkv", "w1", "w2"):
                     t = getattr(blk, attr)
                     if ops.F16Weight.eligible(*t.shape):
@@ -191,8 +205,19 @@ class PointCloudSAM:
         if vit.swiglu:
             # fc1 with the SiLU gate fused in the GEMM epilogue -> u [M, Hp] (pad columns exactly 0), inner LayerNorm over
             # the first H columns in place, then fc2 over K = Hp (zero-padded weight columns)
-            u = ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=pk)
             Hh = vit.mlp_hidden
+            M = x.shape[0]
+            if pk and self.fuse_mlp and hasattr(blk, "w2g") and ops.fuse_supported(M, 2 * blk.hp) and ops.fuse_supported(M, D):
+                # two GEMMs, nothing in between: fc1 writes the gated rows g8-packed (bound-derived scales su) and their LayerNorm
+                # partials; fc2 runs on them with the LayerNorm folded in (mean / rstd per row from the partials)
+                u = torch.empty(M, blk.hp, dtype=torch.float32, device=x.device)
+                su = torch.empty(M, dtype=torch.float32, device=x.device)
+                st = torch.empty(M, ops.stat_segs(2 * blk.hp), 2, dtype=torch.float32, device=x.device)
+                ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=True, out=u, pack_out=(su, blk.k1, blk.k2), stats=(st, Hh))
+                mean, rstd = ops.ln_stats_finalize(st, Hh, vit.ln_eps)
+                ops.linear(u, blk.w2g, blk.ln_d, residual=x, out=x, x_scale=su, x_packed=True, ln_fold=(mean, rstd, blk.ln_c))
+                return x
+            u = ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=pk)
             pk2 = pk and isinstance(blk.w2, ops.F16Weight) and ops.layernorm_can_pack(Hh)
             ops.layernorm(u[:, :Hh], self.w[p + ".mlp.norm.weight"], self.w[p + ".mlp.norm.bias"], vit.ln_eps, out=u[:, :Hh], scale_out=rs if pk2 else None,
                           pack=pk2)

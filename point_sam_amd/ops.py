@@ -246,22 +246,45 @@ class F16Weight:
         return (self.N, self.K)
 
 
-def _f16x3p_call(fn_args, flops, M, N, K):
+def _f16x3p_call(fn_args, flops, M, N, K, fuse=None):
     global _gemm_counter
+    import ctypes
     L = _lib.load()
     _gemm_counter += 1
+    fn_args = fn_args[:-1] + (ctypes.byref(fuse) if fuse is not None else None, fn_args[-1])
     if not _sample_now():
-        check(L.psam_gemm_f16x3p(*fn_args), "psam_gemm_f16x3p")
+        check(L.psam_gemm_f16x3p_ex(*fn_args), "psam_gemm_f16x3p")
         return
-    _sampled_launch(lambda: check(L.psam_gemm_f16x3p(*fn_args), "psam_gemm_f16x3p"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3")))
+    _sampled_launch(lambda: check(L.psam_gemm_f16x3p_ex(*fn_args), "psam_gemm_f16x3p"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3")))
 
 
-def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False):
+def fuse_supported(M: int, N: int) -> bool:
+    """Shapes for which the fused GEMM extras (packed output, LayerNorm partials, folded LayerNorm) exist."""
+    return M % 256 == 0 and N % 128 == 0
+
+
+def stat_segs(N: int) -> int:
+    return (N // 2 + 31) // 32
+
+
+def ln_stats_finalize(stats, cols, eps):
+    """[M, segs, 2] per-segment (mean, centred sum of squares) -> (mean [M], rstd [M]) of a LayerNorm over `cols` columns."""
+    M, segs, _ = stats.shape
+    mean = torch.empty(M, dtype=torch.float32, device=stats.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=stats.device)
+    check(_lib.load().psam_ln_stats_finalize(stats.data_ptr(), M, segs, cols, eps, mean.data_ptr(), rstd.data_ptr(), _stream()), "psam_ln_stats_finalize")
+    return mean, rstd
+
+
+def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False,
+           pack_out=None, stats=None, ln_fold=None):
     """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views, or W an F16Weight
     (prepared static weight).
     "f16x3" mode with an F16Weight and M above the threshold runs the packed-operand GEMM (csrc/gemm_f16x3p.hip): x is either already
     g8-packed by its producer (x_packed=True with x_scale: LayerNorm / scale_pack_rows_g8 output, [M, >= K padded to 32]) or is
-    scaled and packed here in one extra pass."""
+    scaled and packed here in one extra pass.  Fused extras of that GEMM (fuse_supported shapes; include/pointsam_hip.h psam_gemm_fuse_t):
+    pack_out=(scale_out [M], k1, k2): `out` receives g8-packed rows + their bound-derived scales; stats=(buf [M, stat_segs(N), 2], cols):
+    LayerNorm partials of the SwiGLU-gated rows; ln_fold=(mean [M], rstd [M], c [N]): LayerNorm of x folded into the GEMM."""
     fw = None
     if isinstance(W, F16Weight):
         fw, W = W, W.fp32
@@ -286,9 +309,20 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
             xa, sa = x, x_scale
         else:
             xa, sa = scale_pack_rows_g8(x, K)
+        fuse = None
+        if pack_out is not None or stats is not None or ln_fold is not None:
+            fuse = _lib.GemmFuse()
+            if pack_out is not None:
+                fuse.out_scale, fuse.out_k1, fuse.out_k2, fuse.pack_out = pack_out[0].data_ptr(), float(pack_out[1]), float(pack_out[2]), 1
+            if stats is not None:
+                fuse.stats, fuse.stat_cols = stats[0].data_ptr(), int(stats[1])
+            if ln_fold is not None:
+                fuse.ln_mean, fuse.ln_rstd, fuse.ln_c = ln_fold[0].data_ptr(), ln_fold[1].data_ptr(), ln_fold[2].data_ptr()
         _f16x3p_call((xa.data_ptr(), xa.stride(0), sa.data_ptr(), fw.packed.data_ptr(), fw.packed.stride(0), fw.scale.data_ptr(), op, ldo, _p(bias),
-                      rp, ldr, rbp, ldrb, rowgroup, M, N, fw.Kp, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K)
+                      rp, ldr, rbp, ldrb, rowgroup, M, N, fw.Kp, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K, fuse)
         return out
+    if pack_out is not None or stats is not None or ln_fold is not None:
+        raise ValueError("fused GEMM extras exist only on the f16x3 packed-operand path")
     if x_packed:
         raise ValueError("x_packed activations can only feed an f16x3 GEMM with a prepared F16Weight (M above the split threshold)")
     _gemm_call((xp, ldx, 0, 0, wp, ldw, 0, 0, op, ldo, 0, 0, _p(bias), rp, ldr, 0, 0, rbp, ldrb, rowgroup, M, N, K, 1, 1, 1.0, act, _stream()),

@@ -96,6 +96,23 @@ def test_against_oracle(gpu, name, precision):
     assert _maxerr(masks2, want2) < TOL and _maxerr(iou2, want_iou2) < TOL, (_maxerr(masks2, want2), _maxerr(iou2, want_iou2))
 
 
+def test_fused_mlp_matches_unfused_model(gpu):
+    """The two-GEMM MLP (inner LayerNorm folded into fc2, packed hand-over) vs the three-kernel sequence on a whole ViT-L stack."""
+    cfg = get_config("large", 256, 32)
+    sd = random_state_dict(cfg, seed=42)
+    xyz, rgb, prompt, labels = O.synthetic_batch(1, 8192, seed=6)
+    outs = []
+    for fuse in (True, False):
+        model = gpu(cfg, sd, precision="f16x3")
+        model.fuse_mlp = fuse
+        st = model.encode(xyz.cuda(), rgb.cuda())
+        masks, iou = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+        outs.append((st.pc_embeddings, masks, iou))
+    e_emb, e_m = _maxerr(outs[0][0], outs[1][0]), _maxerr(outs[0][1], outs[1][1])
+    print(f"\n[fused vs unfused MLP, ViT-L x24] max|diff| embeddings {e_emb:.2e} masks {e_m:.2e}")
+    assert e_emb < 1e-4 and e_m < 1e-4
+
+
 def test_properties_full_size(gpu):
     """BASELINE sizes without an oracle run: determinism and batch independence (clouds never interact)."""
     cfg = get_config("tiny", 512, 64)

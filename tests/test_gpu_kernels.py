@@ -397,6 +397,61 @@ def test_gemm_f16x3_epilogues(ops):
         _close(y, F.relu(x.double() @ W1.double().T + rb.double().repeat_interleave(grp, 0)), 1e-4, what=f"f16x3 rowbias+relu cfg{cfg}")
 
 
+@pytest.mark.parametrize("M,D,H", [(512, 256, 300), (256, 1024, 2730), (1024, 384, 650)])
+def test_fused_mlp_two_gemms(ops, M, D, H):
+    """EVA02 MLP as two GEMMs and nothing in between (psam_gemm_fuse_t): fc1 emits the SwiGLU-gated rows g8-packed with bound-derived
+    scales plus LayerNorm partials; fc2 runs with the inner LayerNorm folded in.  Against fp64 and against the unfused sequence
+    (fc1 -> LayerNorm kernel -> fc2); the bound-derived scale never overflows fp16 and keeps the decoded rows fp32-grade."""
+    g = torch.Generator().manual_seed(M + D + H)
+    Hp = (H + 63) // 64 * 64
+    h = torch.randn(M, D, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
+    Wg, Wx = torch.randn(H, D, generator=g) / D ** 0.5, torch.randn(H, D, generator=g) / D ** 0.5
+    bg, bx = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    gam, bet = 1 + 0.2 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    W2, b2 = torch.randn(D, H, generator=g) / H ** 0.5, torch.randn(D, generator=g) * 0.1
+    res = torch.randn(M, D, generator=g)
+    eps = 1e-6
+    u64 = F.silu(F.linear(h.double(), Wg.double(), bg.double())) * F.linear(h.double(), Wx.double(), bx.double())
+    want = F.linear(F.layer_norm(u64, (H,), gam.double(), bet.double(), eps), W2.double(), b2.double()) + res.double()
+    pad = lambda t: torch.cat([t, torch.zeros((Hp - H,) + tuple(t.shape[1:]))], 0)
+    W1 = torch.stack([pad(Wg).view(Hp // 32, 32, D), pad(Wx).view(Hp // 32, 32, D)], 1).reshape(2 * Hp, D)
+    b1 = torch.stack([pad(bg).view(Hp // 32, 32), pad(bx).view(Hp // 32, 32)], 1).reshape(2 * Hp)
+    W2p = torch.zeros(D, Hp); W2p[:, :H] = W2
+    gp = torch.zeros(Hp, dtype=torch.float64); gp[:H] = gam.double()
+    w2g = W2p.double() * gp[None, :]
+    ln_c = cu(w2g.sum(1).float())
+    ln_d = cu((W2.double() @ bet.double() + b2.double()).float())
+    k1 = float(2.0 ** 15 * math.sqrt(D) * W1.double().norm(dim=1).max())
+    k2 = float(b1.abs().max())
+    fw1, fw2, fw2g = ops.F16Weight(cu(W1)), ops.F16Weight(cu(W2p)), ops.F16Weight(cu(w2g.float()))
+    assert ops.fuse_supported(M, 2 * Hp) and ops.fuse_supported(M, D)
+    with ops.gemm_mode("f16x3"):
+        hp, sh = ops.scale_pack_rows_g8(cu(h))
+        # unfused: fc1 -> LayerNorm (packing) -> fc2
+        u = ops.linear(hp, fw1, cu(b1), act=ops.ACT_SWIGLU, x_scale=sh, x_packed=True)
+        rs = torch.empty(M, device="cuda")
+        ops.layernorm(u[:, :H], cu(gam), cu(bet), eps, out=u[:, :H], scale_out=rs, pack=True)
+        y0 = ops.linear(u, fw2, cu(b2), residual=cu(res), x_scale=rs, x_packed=True)
+        # fused
+        up = torch.empty(M, Hp, device="cuda"); su = torch.empty(M, device="cuda")
+        st = torch.empty(M, ops.stat_segs(2 * Hp), 2, device="cuda")
+        ops.linear(hp, fw1, cu(b1), act=ops.ACT_SWIGLU, x_scale=sh, x_packed=True, out=up, pack_out=(su, k1, k2), stats=(st, H))
+        mean, rstd = ops.ln_stats_finalize(st, H, eps)
+        y1 = ops.linear(up, fw2g, ln_d, residual=cu(res), x_scale=su, x_packed=True, ln_fold=(mean, rstd, ln_c))
+    # the packed gated rows decode to u (fp32-grade), with power-of-two scales that keep every element below 2^15
+    dec = _unpack_g8(up, su, Hp)
+    assert (dec[:, H:] == 0).all()
+    assert ((dec[:, :H].cpu() - u64).abs().max(1).values / u64.abs().max(1).values.clamp_min(1e-30)).max().item() < 1e-5
+    assert (torch.log2(su) == torch.log2(su).round()).all() and (u64.abs().max(1).values * su.cpu().double() < 2.0 ** 15).all()
+    want_rstd = 1.0 / torch.sqrt(u64.var(1, unbiased=False) + eps)
+    assert ((mean.cpu().double() - u64.mean(1)).abs() * want_rstd).max().item() < 1e-5          # in units of the row's standard deviation
+    assert ((rstd.cpu().double() - want_rstd).abs() / want_rstd).max().item() < 1e-5
+    e0 = ((y0.cpu().double() - want).abs().max() / want.abs().max()).item()
+    e1 = ((y1.cpu().double() - want).abs().max() / want.abs().max()).item()
+    print(f"\n[fused MLP M={M} D={D} H={H}] rel err vs fp64: unfused {e0:.2e}, fused {e1:.2e}")
+    assert e1 < 3e-6 and e1 < 4 * e0 + 5e-7, (e0, e1)
+
+
 def test_gemm_bf16x6_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
