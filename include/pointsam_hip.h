@@ -82,6 +82,13 @@ int32_t psam_group_gather_r(const float* xyz, const float* feats, const float* c
 int32_t psam_patch_l1_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W, const float* bias,
                         const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
                         float radius, float* out, psam_stream_t stream);
+/* The same with the remaining grouper options and a packed output:
+ *   center_idx [B,G] (the groups' FPS indices) != NULL: `centralize_features` (KNNGrouper / group_with_centers_and_knn,
+ *   common.py:116-118, 183-186): input = [rel xyz, features, features - centre features], W [128, 3 + 2C];
+ *   scale_out [rows] != NULL: out receives the g8-packed rows (A operand of psam_gemm_f16x3p for conv1.3) and scale_out their scales. */
+int32_t psam_patch_l1_ex(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const int64_t* center_idx,
+                         const float* W, const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
+                         int32_t G, int32_t K, int32_t C, float radius, float* out, float* scale_out, psam_stream_t stream);
 
 /* Click simulation of the evaluation protocol.  psam_error_regions: fn = gt & !(logit > 0), fp = !gt & (logit > 0)
  * (logits == NULL: fn = gt, fp = 0) -- sample_fixed_points, pc_sam/model/common.py:388-405.  psam_border_farthest: per
@@ -136,12 +143,15 @@ void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring con
  *              into [2^14, 2^15) -- out_k1 = 2^15 sqrt(K) max_n ||W[n]||_2, out_k2 = max |bias| (Cauchy-Schwarz);
  *   stats    : [M, psam_gemm_f16x3p_stat_segs(N), 2] (mean, centred sum of squares) of every 32-column segment of the gated rows over
  *              the columns < stat_cols; psam_ln_stats_finalize merges them (fixed order) into the LayerNorm's mean / rstd per row;
+ *   gmax_*   : gmax_out [M / gmax_k, >= N] (row stride gmax_ld) = per-column maximum over every group of gmax_k (32 or 64) consecutive
+ *              output rows -- PatchEncoder's max-pool over the group members (common.py:491,497); no_store: C is not written;
  *   ln_*     : LayerNorm of the A rows folded into the GEMM: C = rstd[row] (A W'^T - mean[row] c[col]) + bias (+ residual), with the
  *              caller's W' = W * gamma (per column), c = W' 1, bias = W beta + b. */
 typedef struct {
     float* out_scale; float out_k1, out_k2; int32_t pack_out;
     float* stats; int32_t stat_cols;
     const float* ln_mean; const float* ln_rstd; const float* ln_c;
+    float* gmax_out; int64_t gmax_ld; int32_t gmax_k; int32_t no_store;
 } psam_gemm_fuse_t;
 int32_t psam_gemm_f16x3p_stat_segs(int32_t N);
 int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C, int64_t ldc,

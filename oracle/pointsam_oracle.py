@@ -130,9 +130,10 @@ def knn_numpy(centers: np.ndarray, xyz: np.ndarray, k: int) -> np.ndarray:
     return np.argsort(d2, axis=1, kind="stable")[:, :k].astype(np.int64)
 
 
-def group_points(xyz, features, centers, knn_idx, radius=None) -> torch.Tensor:
+def group_points(xyz, features, centers, knn_idx, radius=None, center_idx=None) -> torch.Tensor:
     """[B,G,K,3+C]: neighbour xyz relative to its center (divided by `radius` when given, common.py:107-108), then neighbour
-    features (common.py:99-120; centralize_features=False as in every configs/model/*.yaml)."""
+    features (common.py:99-120); with center_idx [B,G] (`centralize_features`, common.py:116-118 / 183-186) also the neighbour
+    features minus the features of the group's centre point: [B,G,K,3+2C]."""
     B, N, _ = xyz.shape
     G, K = knn_idx.shape[1:]
     flat = (knn_idx + torch.arange(B).view(B, 1, 1) * N).reshape(-1)
@@ -140,15 +141,19 @@ def group_points(xyz, features, centers, knn_idx, radius=None) -> torch.Tensor:
     if radius is not None:
         nbr_xyz = nbr_xyz / radius
     nbr_f = features.reshape(-1, features.shape[-1])[flat].reshape(B, G, K, -1)
-    return torch.cat([nbr_xyz, nbr_f], dim=-1)
+    parts = [nbr_xyz, nbr_f]
+    if center_idx is not None:
+        parts.append(nbr_f - batch_index_select(features, center_idx).unsqueeze(2))
+    return torch.cat(parts, dim=-1)
 
 
-def knn_grouper(xyz, features, num_groups, group_size, mode="exact", radius=None) -> Dict[str, torch.Tensor]:
+def knn_grouper(xyz, features, num_groups, group_size, mode="exact", radius=None, centralize_features=False) -> Dict[str, torch.Tensor]:
     """KNNGrouper.forward (common.py:73-123)."""
     fps_idx = fps(xyz, num_groups)
     centers = batch_index_select(xyz, fps_idx)
     _, knn_idx = knn(centers, xyz, group_size, mode)
-    return dict(features=group_points(xyz, features, centers, knn_idx, radius), centers=centers, knn_idx=knn_idx, fps_idx=fps_idx)
+    feats = group_points(xyz, features, centers, knn_idx, radius, fps_idx if centralize_features else None)
+    return dict(features=feats, centers=centers, knn_idx=knn_idx, fps_idx=fps_idx)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -206,7 +211,7 @@ def eva_block(sd, p: str, x: torch.Tensor, vit) -> torch.Tensor:
 
 def pc_encoder(sd, cfg, coords, features, mode="exact"):
     """PointCloudEncoder.forward (pc_encoder.py:118-145) -> (embeddings [B,G,E], patches dict)."""
-    patches = knn_grouper(coords, features, cfg.num_groups, cfg.group_size, mode, getattr(cfg, "radius", None))
+    patches = knn_grouper(coords, features, cfg.num_groups, cfg.group_size, mode, getattr(cfg, "radius", None), getattr(cfg, "centralize_features", False))
     emb = patch_encoder(sd, "pc_encoder.patch_embed.patch_encoder", patches["features"], cfg.ln_eps)
     patches["embeddings"] = emb
     x = _lin(sd, "pc_encoder.patch_proj", emb)
@@ -240,17 +245,23 @@ def point_encoder(sd, points: torch.Tensor, labels: torch.Tensor) -> torch.Tenso
     return e
 
 
-def mask_encoder(sd, cfg, masks: Optional[torch.Tensor], coords, centers, knn_idx) -> torch.Tensor:
-    """MaskEncoder.forward (prompt_encoder.py:97-133) + group_with_centers_and_knn (common.py:126-187)."""
+def mask_encoder(sd, cfg, masks: Optional[torch.Tensor], coords, centers, knn_idx, center_idx=None) -> torch.Tensor:
+    """MaskEncoder.forward (prompt_encoder.py:97-133) + group_with_centers_and_knn (common.py:126-187).  The mask encoder has its OWN
+    radius / centralize_features options (prompt_encoder.py:78-93); center_idx [B,G] is passed by PointCloudSAM.forward only."""
     if masks is None:
         return sd["mask_encoder.no_mask_embed.weight"].reshape(1, 1, -1).expand(centers.shape[0], centers.shape[1], -1)
     B = coords.shape[0]
     rep = masks.shape[0] // B
-    rel = group_points(coords, coords, centers, knn_idx, getattr(cfg, "radius", None))[..., :3]  # [B,G,K,3]
+    radius = cfg.mask_encoder_radius if hasattr(cfg, "mask_encoder_radius") else getattr(cfg, "radius", None)
+    rel = group_points(coords, coords, centers, knn_idx, radius)[..., :3]  # [B,G,K,3]
     rel = rel.repeat_interleave(rep, dim=0)
     kidx = knn_idx.repeat_interleave(rep, dim=0)
     logit = torch.gather(masks, 1, kidx.reshape(masks.shape[0], -1)).reshape(*kidx.shape, 1)
-    return patch_encoder(sd, "mask_encoder.patch_encoder", torch.cat([rel, logit], dim=-1), cfg.ln_eps)
+    parts = [rel, logit]
+    if getattr(cfg, "mask_centralize_features", False):
+        cidx = center_idx.repeat_interleave(rep, dim=0)
+        parts.append(logit - torch.gather(masks, 1, cidx).reshape(masks.shape[0], -1, 1, 1))
+    return patch_encoder(sd, "mask_encoder.patch_encoder", torch.cat(parts, dim=-1), cfg.ln_eps)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -460,7 +471,7 @@ def forward_eval(sd, cfg, coords, features, gt_masks, prompt_iters=None, mode="e
         prompt_coords = torch.cat([prompt_coords, nc], dim=1)
         prompt_labels = torch.cat([prompt_labels, nl], dim=1)
         sparse = point_encoder(sd, prompt_coords, prompt_labels)
-        dense = mask_encoder(sd, cfg, prompt_masks, coords, centers, knn_idx)
+        dense = mask_encoder(sd, cfg, prompt_masks, coords, centers, knn_idx, patches["fps_idx"])   # pc_sam.py:151-157
         dense = dense.repeat_interleave(sparse.shape[0] // dense.shape[0], 0)
         masks, iou = mask_decoder(sd, cfg, pc_emb, pc_pe, sparse, dense, aux, i == 0, mode)
         if i == 0:

@@ -26,6 +26,7 @@ SIGNATURES = {
     "psam_group_gather_r": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),
     "psam_patch_l1": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, ptr, ptr]),
     "psam_patch_l1_r": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),
+    "psam_patch_l1_ex": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_error_regions": (i32, [ptr, ptr, ptr, ptr, i64, ptr]),
     "psam_border_farthest_workspace_bytes": (size_t, [i32, i32]),
     "psam_border_farthest": (i32, [ptr, ptr, i32, i32, i32, ptr, ptr, ptr, size_t, ptr]),
@@ -63,7 +64,7 @@ SIGNATURES = {
 class GemmFuse(ctypes.Structure):
     """psam_gemm_fuse_t (include/pointsam_hip.h)."""
     _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
-                ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr)]
+                ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32)]
 
 
 _lib = None

@@ -40,7 +40,23 @@ class ModelConfig:
     num_multimask: int = 3       # mask_decoder.py:26
     prompt_iters: int = 5
     ln_eps: float = 1e-5         # torch.nn.LayerNorm default used by every non-timm LayerNorm
-    radius: float = None         # KNNGrouper.radius and MaskEncoder.radius (configs/model/enc_with_radius.yaml: 0.1 both); None = off
+    radius: float = None         # KNNGrouper.radius (configs/model/enc_with_radius.yaml: 0.1); None = off
+    mask_radius: float = "same"  # MaskEncoder.radius (prompt_encoder.py:78-93): an independent option in the reference; "same" = radius
+    centralize_features: bool = False   # KNNGrouper.centralize_features (common.py:116-118): + (neighbour - centre) features, in_channels 3 + 2*3
+    mask_centralize_features: bool = False   # MaskEncoder.centralize_features (common.py:183-186): needs center_idx, i.e. only the
+                                             # forward() protocol passes it (pc_sam.py:151-157); in_channels 3 + 2*1
+
+    @property
+    def mask_encoder_radius(self):
+        return self.radius if self.mask_radius == "same" else self.mask_radius
+
+    @property
+    def patch_in_channels(self) -> int:
+        return 3 + (self.in_channels - 3) * (2 if self.centralize_features else 1)
+
+    @property
+    def mask_in_channels(self) -> int:
+        return 3 + (2 if self.mask_centralize_features else 1)
 
     @property
     def num_mask_tokens(self) -> int:
@@ -69,6 +85,8 @@ CONFIGS = {
     # configs/model/enc_with_radius.yaml on top of default.yaml / on the tiny test transformer
     "large_radius": ModelConfig(VIT_LARGE, 1024, 256, prompt_iters=5, radius=0.1),
     "tiny_radius": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3, radius=0.1),
+    # centralised group features (KNNGrouper.centralize_features) + different grouper / mask-encoder radii on the tiny test transformer
+    "tiny_central": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3, radius=0.2, mask_radius=0.1, centralize_features=True),
 }
 
 

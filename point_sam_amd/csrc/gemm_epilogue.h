@@ -40,6 +40,9 @@ __device__ __forceinline__ void ep_wave_sync() {
 //    the 18 binades of full-precision range and cannot overflow.  The output can then feed the next GEMM with no pass in between.
 //  * stats (with the SwiGLU gate): per row and per wave-wide column segment (TN*16 gated outputs) the segment's mean and centred sum
 //    of squares over the columns < stat_cols -- the partials of a LayerNorm over the gated row (merged by psam_ln_stats_finalize).
+//  * gmax_out / gmax_k: the max over every group of gmax_k (32 or 64) consecutive rows of the finished output, per column -> gmax_out
+//    [M / gmax_k, N] (PatchEncoder's max-pool over the group members, common.py:491,497); no_store: C itself is not written (when the
+//    pooled value is all the caller needs, the [M, N] activation never reaches HBM).
 //  * ln_mean / ln_rstd / ln_c: the LayerNorm of the A rows folded into this GEMM -- C = rstd[row] * (A W'^T - mean[row] * c[col]) + bias
 //    with W' = W * gamma (columns), c = W' 1, bias = W beta + b.
 template <int TM, int TN, bool SCALED = false, bool EXT = false, typename ArgsT>
@@ -70,6 +73,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
             for (int e = 0; e < 4; ++e) { m0[e] *= inv_pow2(p.scaleW[pcol + e]); if (swiglu) m1[e] *= inv_pow2(p.scaleW[pcol + 32 + e]); }
         }
     }
+    [[maybe_unused]] ep_f32x4 gm = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // running group maximum of this lane's 4 columns (EXT)
     constexpr int NPMAX = TN * 8 > 32 ? 32 : (TN * 8 > 16 ? 16 : 8), NB = 2;   // NB = 4 doubles the epilogue register footprint (190 VGPRs) and costs a wave of occupancy
 
 #pragma unroll
@@ -132,6 +136,9 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             if (p.act == 1) v = ep_f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
                             else if (p.act == 2) v = ep_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                             if (R) v += res[q];
+                            if constexpr (EXT) {
+                                if (p.gmax_out) gm = ep_f32x4{fmaxf(gm[0], v[0]), fmaxf(gm[1], v[1]), fmaxf(gm[2], v[2]), fmaxf(gm[3], v[3])};
+                            }
                         }
                         bool stored = false;
                         if constexpr (EXT) {
@@ -149,8 +156,22 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                                 stored = true;
                             }
                         }
+                        if constexpr (EXT) { if (p.no_store) stored = true; }
                         if (!stored) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
                     }
+                }
+            }
+            if constexpr (EXT) {
+                if (p.gmax_out && (p.gmax_k == 32 || (i & 1))) {      // a whole group of rows has passed through this lane's columns
+#pragma unroll
+                    for (int o = c4n; o < 64; o <<= 1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gm[e] = fmaxf(gm[e], __shfl_xor(gm[e], o, 64));
+                    if (rl0 == 0) {
+                        const int grp = (row_base + i * 32) / p.gmax_k;      // gmax_k = 64: stripe i - 1 starts the group, same quotient
+                        *reinterpret_cast<ep_f32x4*>(p.gmax_out + (int64_t)grp * p.gmax_ld + pcol) = gm;
+                    }
+                    gm = ep_f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
             }
         } else {

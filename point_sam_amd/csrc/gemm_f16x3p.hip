@@ -41,6 +41,7 @@ struct F16PArgs {
     float* out_scale; float out_k1, out_k2; int pack_out;
     float* stats; int stat_cols, stat_segs;
     const float* ln_mean; const float* ln_rstd; const float* ln_c;
+    float* gmax_out; int64_t gmax_ld; int gmax_k, no_store;
 };
 
 #define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
@@ -381,24 +382,34 @@ static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
 
 // Tile configuration for a shape.  Measured per-CU rates of the configurations are within ~15 % of each other once a CU is busy
-// (profiles/r02_gemm_p_sweep_*.log); what differs is how many rounds of workgroups a launch needs and how much of the last round is
-// empty.  cost = rounds x tile area x (K + 300) x penalty: the 300 stands for the epilogue of a tile (12-14 us of the 77 us, K = 1024
-// qkv GEMM), the penalty for the operand bytes per flop of the smaller tiles (LDS-DMA path ~32 B/clk/CU).
-static int f16x3p_pick(int M, int N, int K, int act) {
+// (profiles/r02_gemm_p_sweep_*.log; the kernel is power-limited, profiles/r02_gemm_power_limit.txt); what differs is how many rounds
+// of workgroups a launch needs, how full the last one is -- and how a launch behaves when a few CUs are NOT available: the tokenizer
+// of the next batch (FPS: one 1024-thread workgroup per cloud, a whole CU each, ~2 ms per step) runs beside the dense stage, and a
+// launch of exactly #CU one-per-CU workgroups then needs a second round for the last few tiles (twice the time).  So the rounds are
+// counted on #CU - 8 and configurations with two workgroups per CU (64-70 KiB of LDS) are candidates for the shapes that would
+// otherwise sit exactly at one round.
+//   cost = rounds x tile area x (K + 300) x penalty x share
+// (300 ~ the epilogue of a tile in k-steps; penalty: operand bytes per flop of the smaller tiles, LDS-DMA path ~32 B/clk/CU; share: two
+// resident tiles on a CU each progress at ~60 % of a lone tile's speed).
+static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     }
-    struct Cand { int cfg, bm, bn; bool swiglu; double pen; };
-    static const Cand cands[] = {{14, 256, 256, true, 1.0}, {23, 256, 192, false, 1.0}, {4, 256, 128, true, 1.05}, {9, 128, 128, true, 1.15}};
+    const int ncu_eff = ncu > 16 ? ncu - 8 : ncu;
+    struct Cand { int cfg, bm, bn, per_cu; bool swiglu, two_wide; double pen; };
+    static const Cand cands[] = {{14, 256, 256, 1, true, false, 1.0}, {23, 256, 192, 1, false, false, 1.0}, {4, 256, 128, 1, true, true, 1.05},
+                                 {9, 128, 128, 1, true, true, 1.15},  {21, 128, 128, 2, true, true, 1.15},  {28, 128, 128, 2, true, true, 1.2}};
     int best = 9;
     double best_cost = 1e300;
     for (const Cand& c : cands) {
         if (act == 3 && !c.swiglu) continue;
-        const double tiles = (double)psam_cdiv(M, c.bm) * (double)psam_cdiv(N, c.bn);
-        const double rounds = (double)psam_cdiv((int64_t)tiles, ncu);
-        const double cost = rounds * c.bm * c.bn * (K + 300.0) * c.pen;
+        if (two_wide_only && !c.two_wide) continue;
+        const int64_t tiles = psam_cdiv(M, c.bm) * psam_cdiv(N, c.bn);
+        const double rounds = (double)psam_cdiv(tiles, (int64_t)ncu_eff * c.per_cu);
+        const double share = (c.per_cu == 2 && tiles * 2 > (int64_t)ncu_eff * 3) ? 1.6 : 1.0;
+        const double cost = rounds * c.bm * c.bn * (K + 300.0) * c.pen * share;
         if (cost < best_cost) { best_cost = cost; best = c.cfg; }
     }
     return best;
@@ -433,6 +444,7 @@ struct psam_gemm_fuse_t {
     float* out_scale; float out_k1, out_k2; int32_t pack_out;       // g8-packed output rows with a bound-derived scale
     float* stats; int32_t stat_cols;                                // LayerNorm partials of the SwiGLU-gated rows: [M, segs, 2]
     const float* ln_mean; const float* ln_rstd; const float* ln_c;  // LayerNorm of the A rows folded into this GEMM
+    float* gmax_out; int64_t gmax_ld; int32_t gmax_k; int32_t no_store;   // per-column max over groups of gmax_k (32 | 64) rows; C not written
 };
 
 // segments (of 32 gated columns) per row of the stats buffer of a SwiGLU GEMM with N packed weight rows
@@ -458,9 +470,10 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
     p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
+    p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
     int cfg = g_f16x3p_cfg;
-    if (cfg < 0) cfg = f16x3p_pick(M, N, K, act);
-    if (fuse && (fuse->pack_out || fuse->stats || fuse->ln_c)) {
+    if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
+    if (fuse && (fuse->pack_out || fuse->stats || fuse->ln_c || fuse->gmax_out)) {
         // The fused epilogue paths exist for interior tiles of the two-tile-wide wave tiles only: whole 256-row / 128-column tiles.
         PSAM_REQUIRE((M & 255) == 0 && (N & 127) == 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: fused extras need M % 256 == 0 and N % 128 == 0");
         PSAM_REQUIRE(!fuse->pack_out || (fuse->out_scale && (ldc & 7) == 0 && ((uintptr_t)C & 31) == 0), PSAM_EINVAL,
@@ -472,7 +485,15 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         p.out_scale = fuse->out_scale; p.out_k1 = fuse->out_k1; p.out_k2 = fuse->out_k2; p.pack_out = fuse->pack_out;
         p.stats = fuse->stats; p.stat_cols = fuse->stat_cols; p.stat_segs = psam_gemm_f16x3p_stat_segs(N);
         p.ln_mean = fuse->ln_mean; p.ln_rstd = fuse->ln_rstd; p.ln_c = fuse->ln_c;
-        if (cfg != 4 && cfg != 9) cfg = (N >= 2048) ? 4 : 9;      // 256x128 / 128x128 tiles: wave tiles two 32-column tiles wide
+        PSAM_REQUIRE(!fuse->gmax_out || ((fuse->gmax_k == 32 || fuse->gmax_k == 64) && act != 3 && (fuse->gmax_ld & 3) == 0 && fuse->gmax_ld >= N &&
+                                         ((uintptr_t)fuse->gmax_out & 15) == 0), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: group maximum needs groups of 32 or 64 rows, no SwiGLU, a 16-byte aligned [M / k, >= N] output");
+        PSAM_REQUIRE(!fuse->no_store || fuse->gmax_out, PSAM_EINVAL, "psam_gemm_f16x3p_ex: no_store only together with the group maximum");
+        p.gmax_out = fuse->gmax_out; p.gmax_ld = fuse->gmax_ld; p.gmax_k = fuse->gmax_k; p.no_store = fuse->no_store;
+        // group maximum: wave tiles of 64 rows (two stripes): 256x128 (cfg 4), 256x256 (cfg 14, N % 256 == 0), 128x128 of four waves (cfg 21);
+        // row statistics / everything else: wave tiles two 32-column tiles wide (cfg 4, 9, 21, 28)
+        if (fuse->gmax_out) { if (cfg != 4 && cfg != 14 && cfg != 21) cfg = (N % 256 == 0 && !fuse->stats) ? 14 : 4; }
+        else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
     }
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2

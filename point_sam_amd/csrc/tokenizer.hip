@@ -596,21 +596,25 @@ PSAM_API int32_t psam_group_gather(const float* xyz, const float* feats, const f
 //   h = GELU(LayerNorm_128(W[128,3+C] @ [xyz[idx]-center, feats[idx]] + bias))       (common.py:486-489,499)
 // One wave per row, two channels per lane; weights live in registers.
 // ------------------------------------------------------------------------------------------------
-template <int CIN>
+// CIN = 3 + C (+ C more with `centralize`: the neighbour's features minus the group centre's, common.py:116-118 / 183-186).  Lane l owns
+// the output channels 2l, 2l+1.  PACK: the row leaves as the g8-packed A operand of the f16x3p GEMM (csrc/gemm_f16x3p.hip) -- per 8
+// channels [hi x8 | lo x8] fp16 of the row scaled by scale_out[row] (its maximum into [2^14, 2^15)) -- instead of fp32.
+template <int CIN, bool CENTRAL, bool PACK>
 __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__ xyz, const float* __restrict__ feats,
                                                        const float* __restrict__ centers, const int64_t* __restrict__ knn_idx,
-                                                       const float* __restrict__ W, const float* __restrict__ bias,
-                                                       const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, int rep,
-                                                       int N, int G, int K, int64_t rows, float inv_radius, float* __restrict__ out) {
-    constexpr int C = CIN - 3;
+                                                       const int64_t* __restrict__ center_idx, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                       float eps, int rep, int N, int G, int K, int64_t rows, float inv_radius,
+                                                       float* __restrict__ out, float* __restrict__ scale_out) {
+    constexpr int C = CENTRAL ? (CIN - 3) / 2 : CIN - 3;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     float w0[CIN], w1[CIN];
 #pragma unroll
-    for (int i = 0; i < CIN; ++i) { w0[i] = W[lane * CIN + i]; w1[i] = W[(lane + 64) * CIN + i]; }
-    const float b0 = bias[lane], b1 = bias[lane + 64];
-    const float g0 = lnw[lane], g1 = lnw[lane + 64], e0 = lnb[lane], e1 = lnb[lane + 64];
+    for (int i = 0; i < CIN; ++i) { w0[i] = W[(2 * lane) * CIN + i]; w1[i] = W[(2 * lane + 1) * CIN + i]; }
+    const float b0 = bias[2 * lane], b1 = bias[2 * lane + 1];
+    const float g0 = lnw[2 * lane], g1 = lnw[2 * lane + 1], e0 = lnb[2 * lane], e1 = lnb[2 * lane + 1];
     for (int64_t row = wave; row < rows; row += nwaves) {
         const int k = (int)(row % K);
         const int g = (int)((row / K) % G);
@@ -624,6 +628,11 @@ __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__
         const float* f = feats + (bf * N + n) * C;
 #pragma unroll
         for (int i = 0; i < C; ++i) in[3 + i] = f[i];
+        if (CENTRAL) {
+            const float* fc = feats + (bf * N + center_idx[b * G + g]) * C;
+#pragma unroll
+            for (int i = 0; i < C; ++i) in[3 + C + i] = f[i] - fc[i];
+        }
         float y0 = b0, y1 = b1;
 #pragma unroll
         for (int i = 0; i < CIN; ++i) { y0 = fmaf(w0[i], in[i], y0); y1 = fmaf(w1[i], in[i], y1); }
@@ -631,26 +640,51 @@ __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__
         const float a0 = y0 - mean, a1 = y1 - mean;
         const float var = wave_sum(a0 * a0 + a1 * a1) * (1.0f / 128.0f);
         const float r = 1.0f / sqrtf(var + eps);
-        out[row * 128 + lane] = gelu_erf(a0 * r * g0 + e0);
-        out[row * 128 + lane + 64] = gelu_erf(a1 * r * g1 + e1);
+        const float o0 = gelu_erf(a0 * r * g0 + e0), o1 = gelu_erf(a1 * r * g1 + e1);
+        if (PACK) {
+            const float sc = f16_row_scale(wave_max(fmaxf(fabsf(o0), fabsf(o1))));
+            if (lane == 0) scale_out[row] = sc;
+            unsigned hi, lo;
+            psam_split2_f16(o0, o1, sc, hi, lo);
+            unsigned* orow = reinterpret_cast<unsigned*>(out) + row * 128 + (lane >> 2) * 8 + (lane & 3);   // group of 8 channels = 4 lanes
+            orow[0] = hi;
+            orow[4] = lo;
+        } else {
+            *reinterpret_cast<psam_f32x2*>(out + row * 128 + 2 * lane) = psam_f32x2{o0, o1};
+        }
     }
 }
 
-// W [128, 3+C] (nn.Linear layout), bias/lnw/lnb [128]; out [B*rep*G*K, 128].  C in {1, 3}.
-PSAM_API int32_t psam_patch_l1_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,
-                                 const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
-                                 int32_t G, int32_t K, int32_t C, float radius, float* out, hipStream_t stream) {
+// W [128, Cin] (nn.Linear layout), Cin = 3 + C or 3 + 2C (centralize: center_idx [B, G] = the groups' FPS indices), bias/lnw/lnb [128];
+// out [B*rep*G*K, 128] fp32, or (scale_out != null) the g8-packed rows + their scales.  C in {1, 3}.
+PSAM_API int32_t psam_patch_l1_ex(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const int64_t* center_idx,
+                                  const float* W, const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep,
+                                  int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, float* scale_out, hipStream_t stream) {
     PSAM_REQUIRE(xyz && feats && centers && knn_idx && W && bias && lnw && lnb && out, PSAM_EINVAL, "psam_patch_l1: null pointer");
     PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0, PSAM_EINVAL, "psam_patch_l1: bad shape");
     PSAM_REQUIRE(C == 1 || C == 3, PSAM_EINVAL, "psam_patch_l1: C must be 1 (mask logit) or 3 (rgb)");
+    PSAM_REQUIRE(!scale_out || ((uintptr_t)out & 31) == 0, PSAM_EALIGN, "psam_patch_l1: packed output rows must be 32-byte aligned");
     const int64_t rows = (int64_t)B * rep * G * K;
     const int64_t blocks = rows / 4 < 8192 ? (rows + 3) / 4 : 8192;
-#define L1_LAUNCH(CIN)                                                                                                              \
-    hipLaunchKernelGGL(patch_l1_kernel<CIN>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, feats, centers, knn_idx, W, bias, lnw, \
-                       lnb, eps, rep, N, G, K, rows, radius > 0.f ? 1.0f / radius : 1.0f, out)
-    if (C == 3) L1_LAUNCH(6); else L1_LAUNCH(4);
+    const float inv_r = radius > 0.f ? 1.0f / radius : 1.0f;
+#define L1_LAUNCH(CIN, CEN, PK)                                                                                                          \
+    hipLaunchKernelGGL((patch_l1_kernel<CIN, CEN, PK>), dim3((unsigned)blocks), dim3(256), 0, stream, xyz, feats, centers, knn_idx, center_idx, W, \
+                       bias, lnw, lnb, eps, rep, N, G, K, rows, inv_r, out, scale_out)
+#define L1_PICK(PK)                                                          \
+    do {                                                                     \
+        if (center_idx) { if (C == 3) L1_LAUNCH(9, true, PK); else L1_LAUNCH(5, true, PK); } \
+        else { if (C == 3) L1_LAUNCH(6, false, PK); else L1_LAUNCH(4, false, PK); }          \
+    } while (0)
+    if (scale_out) L1_PICK(true); else L1_PICK(false);
+#undef L1_PICK
 #undef L1_LAUNCH
     return psam_launch_status("psam_patch_l1: launch failed");
+}
+
+PSAM_API int32_t psam_patch_l1_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,
+                                 const float* bias, const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N,
+                                 int32_t G, int32_t K, int32_t C, float radius, float* out, hipStream_t stream) {
+    return psam_patch_l1_ex(xyz, feats, centers, knn_idx, nullptr, W, bias, lnw, lnb, eps, B, rep, N, G, K, C, radius, out, nullptr, stream);
 }
 
 PSAM_API int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W,

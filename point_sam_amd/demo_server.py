@@ -3,11 +3,14 @@
 The reference's ``demo/app.py`` is a Flask app whose routes mutate module-global state and call
 ``sam.set_pointcloud`` / ``sam.predict_masks`` (demo/app.py:177-206).  Here the same request/response contract is a
 plain class (``DemoSession``: one method per route, JSON-shaped dicts in and out, same keys and status strings) and a
-thin stdlib ``http.server`` binding -- Flask / flask_cors are not needed (nor installed in this image); the static
-three.js front end (demo/static) is UI and out of scope, but it can talk to this server unchanged.
+thin stdlib ``http.server`` binding -- Flask / flask_cors are not needed (nor installed in this image).  The static three.js
+front end (demo/static) is UI and is not rebuilt, but its files are SERVED from ``--static-dir`` exactly as the reference does,
+so the reference's front end talks to this server unchanged with no second file server.
 
-Routes (reference line):  POST /sampled_pointcloud (app.py:92-108) . GET /pointcloud/<name> (:111-141) . POST /clear (:144-150)
+Routes (reference line):  GET / (app.py:71-73: index.html) . GET /static/<path> (:76-78) . GET /mesh/<path> (:81-89: models/<path>)
+POST /sampled_pointcloud (app.py:92-108) . GET /pointcloud/<name> (:111-141) . POST /clear (:144-150)
 POST /next (:153-159) . POST /save (:162-175) . POST /segment (:177-206).
+Every path taken from a URL is resolved INSIDE its root directory (no `..`, no absolute paths, no symlink escape).
 
     python -m point_sam_amd.demo_server --config large --ckpt model.safetensors --models-dir demo/static/models
 """
@@ -22,14 +25,31 @@ import torch
 
 from .evaluation import load_ply
 
+MIME = {".html": "text/html; charset=utf-8", ".js": "application/javascript", ".css": "text/css", ".json": "application/json", ".ply": "application/octet-stream",
+        ".obj": "text/plain", ".mtl": "text/plain", ".png": "image/png", ".jpg": "image/jpeg", ".jpeg": "image/jpeg", ".svg": "image/svg+xml", ".ico": "image/x-icon"}
+
+
+def safe_join(root: str, rel: str) -> str:
+    """`rel` (a URL path, possibly percent-encoded) resolved under `root`; ValueError if it would leave the directory."""
+    from urllib.parse import unquote
+    rel = unquote(rel).replace("\\", "/")
+    if rel.startswith("/") or "\x00" in rel:
+        raise ValueError(f"illegal path {rel!r}")
+    base = os.path.realpath(root)
+    full = os.path.realpath(os.path.join(base, rel))
+    if full != base and not full.startswith(base + os.sep):
+        raise ValueError(f"path {rel!r} leaves the served directory")
+    return full
+
 
 class DemoSession:
     """The demo's state machine.  ``predictor`` needs ``set_pointcloud(xyz, rgb)`` and
     ``predict_masks(points, labels, prompt_mask, multimask_output) -> (mask, scores, logits)``."""
 
-    def __init__(self, predictor, models_dir: str = ".", pointcloud: str = None, output_dir: str = "results", device="cuda"):
+    def __init__(self, predictor, models_dir: str = ".", pointcloud: str = None, output_dir: str = "results", device="cuda", static_dir: str = None):
         self.predictor = predictor
         self.models_dir, self.pointcloud, self.output_dir = models_dir, pointcloud, output_dir
+        self.static_dir = static_dir           # the front end's files (reference: demo/static); None = not served
         self.device = torch.device(device)
         self.lock = threading.Lock()          # the reference is single-threaded; requests are serialised here
         self.pc_xyz = self.pc_rgb = None
@@ -55,7 +75,7 @@ class DemoSession:
         """Loads an ASCII PLY from models_dir, normalises it into the unit ball, rgb / 255 (app.py:111-141).  As in the
         reference, a configured --pointcloud overrides the requested name."""
         name = self.pointcloud or path
-        pts = load_ply(os.path.join(self.models_dir, name))
+        pts = load_ply(safe_join(self.models_dir, name))
         xyz, rgb = pts[:, :3], pts[:, 3:6] / 255
         shift = xyz.mean(0)
         scale = np.linalg.norm(xyz - shift, axis=-1).max()
@@ -65,6 +85,16 @@ class DemoSession:
             self.pc_xyz = torch.from_numpy(xyz).to(self.device).float()[None]
             self.pc_rgb = torch.from_numpy(rgb).to(self.device).float()[None]
         return {"xyz": xyz.flatten().tolist(), "rgb": rgb.flatten().tolist()}
+
+    def static_file(self, rel: str):
+        """(bytes, mime type) of a front-end file under static_dir (app.py:71-89)."""
+        if self.static_dir is None:
+            raise FileNotFoundError("no --static-dir configured: front-end files are not served")
+        full = safe_join(self.static_dir, rel)
+        if not os.path.isfile(full):
+            raise FileNotFoundError(rel)
+        with open(full, "rb") as f:
+            return f.read(), MIME.get(os.path.splitext(full)[1].lower(), "application/octet-stream")
 
     def clear(self) -> dict:
         with self.lock:
@@ -132,11 +162,32 @@ def make_handler(session: DemoSession, allow_origin: str = "*"):
         def do_OPTIONS(self):
             self._send(200, {})
 
+        def _send_file(self, rel):
+            try:
+                body, mime = session.static_file(rel)
+            except ValueError as e:
+                return self._send(400, {"error": f"ValueError: {e}"})
+            except FileNotFoundError as e:
+                return self._send(404, {"error": f"not found: {e}"})
+            self.send_response(200)
+            self.send_header("Content-Type", mime)
+            self.send_header("Content-Length", str(len(body)))
+            self.send_header("Access-Control-Allow-Origin", allow_origin)
+            self.end_headers()
+            self.wfile.write(body)
+
         def do_GET(self):
-            if self.path.startswith("/pointcloud/"):
-                self._run(session.load_pointcloud, self.path[len("/pointcloud/"):])
+            path = self.path.split("?", 1)[0]
+            if path.startswith("/pointcloud/"):
+                self._run(session.load_pointcloud, path[len("/pointcloud/"):])
+            elif path == "/":
+                self._send_file("index.html")                                   # app.py:71-73
+            elif path.startswith("/static/"):
+                self._send_file(path[len("/static/"):])                         # app.py:76-78
+            elif path.startswith("/mesh/"):
+                self._send_file("models/" + path[len("/mesh/"):])               # app.py:81-89
             else:
-                self._send(404, {"error": "static front-end files are not served by this back end"})
+                self._send(404, {"error": f"no route {path}"})
 
         def do_POST(self):
             n = int(self.headers.get("Content-Length") or 0)
@@ -169,11 +220,12 @@ def main():
     ap.add_argument("--ckpt", "--ckpt_path", dest="ckpt", default=None, help="safetensors checkpoint (random weights if omitted)")
     ap.add_argument("--pointcloud", default=None)
     ap.add_argument("--models-dir", default="demo/static/models")
+    ap.add_argument("--static-dir", default="demo/static", help="the reference front end's files (index.html, *.js, models/)")
     ap.add_argument("--precision", default="f16x3")
     args = ap.parse_args()
     from .predictor import PointSAMPredictor
     pred = PointSAMPredictor.from_config(args.config, args.ckpt, precision=args.precision)
-    srv = serve(DemoSession(pred, args.models_dir, args.pointcloud), args.host, args.port)
+    srv = serve(DemoSession(pred, args.models_dir, args.pointcloud, static_dir=args.static_dir), args.host, args.port)
     print(f"Point-SAM demo back end on http://{args.host}:{args.port}")
     srv.serve_forever()
 

@@ -70,6 +70,7 @@ class PointCloudSAM:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
         self.precision = precision
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
+        self.fuse_patch = True    # "f16x3": mini-PointNet hand-overs packed, max-pools in the GEMM epilogues (False = separate kernels)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -118,12 +119,17 @@ class PointCloudSAM:
         # "f16x3": every static weight that can feed the packed-operand GEMM (csrc/gemm_f16x3p.hip) is scaled, split and packed ONCE,
         # here, and owned by this model (fw: name -> ops.F16Weight; launches below the split thresholds use its fp32 original)
         self.fw = {}
+        self.pe_bound = {}
         if self.precision == "f16x3":
             h0 = cfg.patch_hidden[0]
             for name, t in w.items():
                 if name.endswith(".weight") and t.dim() == 2 and ops.F16Weight.eligible(*t.shape) and not name.startswith("pc_encoder.transformer."):
                     self.fw[name] = ops.F16Weight(t)
+            self.pe_bound = {}
             for prefix in ("pc_encoder.patch_embed.patch_encoder", "mask_encoder.patch_encoder"):   # cat([max, x]) @ W^T as two GEMMs
+                w13 = w[prefix + ".conv1.3.weight"]     # bound of |conv1.3 row| from the scale of its (packed) input row: see psam_gemm_fuse_t
+                self.pe_bound[prefix] = (float(2.0 ** 15 * math.sqrt(w13.shape[1]) * w13.double().norm(dim=1).max().item()),
+                                         float(w[prefix + ".conv1.3.bias"].abs().max().item()))
                 w2a = w[prefix + ".conv2.0.weight"]
                 for tag, sl in (("#max", w2a[:, :h0]), ("#x", w2a[:, h0:])):
                     if ops.F16Weight.eligible(*sl.shape):
@@ -166,17 +172,40 @@ class PointCloudSAM:
             return False, None
         return True, torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
 
-    def _patch_encoder(self, prefix, coords, feats, centers, knn_idx):
-        """PatchEncoder.forward on gathered groups (common.py:499-506) -> [B*rep*G, Cout]."""
+    def _patch_encoder(self, prefix, coords, feats, centers, knn_idx, radius=None, center_idx=None):
+        """PatchEncoder.forward on gathered groups (common.py:499-506) -> [B*rep*G, Cout].  center_idx [B,G]: centralize_features."""
         w, eps = self.w, self.cfg.ln_eps
         K = knn_idx.shape[2]
         h0 = self.cfg.patch_hidden[0]
-        h1 = ops.patch_l1(coords, feats, centers, knn_idx, w[prefix + ".conv1.0.weight"], w[prefix + ".conv1.0.bias"],
-                          w[prefix + ".conv1.1.weight"], w[prefix + ".conv1.1.bias"], eps, radius=self.cfg.radius)
+        rows = feats.shape[0] * knn_idx.shape[1] * K
+        l1 = (w[prefix + ".conv1.0.weight"], w[prefix + ".conv1.0.bias"], w[prefix + ".conv1.1.weight"], w[prefix + ".conv1.1.bias"], eps)
+        w2a = w[prefix + ".conv2.0.weight"]
+        fused = (self.precision == "f16x3" and self.fuse_patch and K in (32, 64) and ops.fuse_supported(rows, 128) and prefix in self.pe_bound
+                 and all((prefix + n) in self.fw for n in (".conv1.3.weight", ".conv2.0.weight#x", ".conv2.3.weight")))
+        if fused:
+            # every hand-over stays in the GEMMs' packed form and both max-pools happen in GEMM epilogues: the [rows, 128] / [rows, 512]
+            # activations are written once (packed) or not at all (conv2.3 only leaves its pooled [groups, Cout] rows)
+            groups = rows // K
+            s1 = torch.empty(rows, dtype=torch.float32, device=coords.device)
+            h1 = ops.patch_l1(coords, feats, centers, knn_idx, *l1, radius=radius, center_idx=center_idx, scale_out=s1)
+            h2 = torch.empty(rows, h0, dtype=torch.float32, device=coords.device)          # g8-packed container
+            s2 = torch.empty(rows, dtype=torch.float32, device=coords.device)
+            y1 = torch.empty(groups, h0, dtype=torch.float32, device=coords.device)
+            k1, k2 = self.pe_bound[prefix]
+            self._lin(prefix + ".conv1.3", h1, x_scale=s1, x_packed=True, out=h2, pack_out=(s2, k1, k2), group_max_out=y1, group_max_k=K)
+            del h1
+            g1 = ops.linear(y1, self.fw.get(prefix + ".conv2.0.weight#max", w2a[:, :h0]), w[prefix + ".conv2.0.bias"])
+            h3 = ops.linear(h2, self.fw[prefix + ".conv2.0.weight#x"], None, rowbias=g1, rowgroup=K, x_scale=s2, x_packed=True)
+            del h2
+            pk, rs = self._ln_feeds_gemm(h3, prefix + ".conv2.3")
+            self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3, scale_out=rs, pack=pk)
+            emb = torch.empty(groups, self.w[prefix + ".conv2.3.weight"].shape[0], dtype=torch.float32, device=coords.device)
+            self._lin(prefix + ".conv2.3", h3, x_scale=rs, x_packed=pk, group_max_out=emb, group_max_k=K, no_store=True)
+            return emb
+        h1 = ops.patch_l1(coords, feats, centers, knn_idx, *l1, radius=radius, center_idx=center_idx)
         h2 = self._lin(prefix + ".conv1.3", h1)
         del h1
         y1 = ops.group_max(h2, K)
-        w2a = w[prefix + ".conv2.0.weight"]
         # cat([max, x]) @ W^T = max @ W[:, :h0]^T (one row per group) + x @ W[:, h0:]^T
         g1 = ops.linear(y1, self.fw.get(prefix + ".conv2.0.weight#max", w2a[:, :h0]), w[prefix + ".conv2.0.bias"])
         h3 = ops.linear(h2, self.fw.get(prefix + ".conv2.0.weight#x", w2a[:, h0:]), None, rowbias=g1, rowgroup=K)
@@ -259,7 +288,8 @@ class PointCloudSAM:
         cfg, w = self.cfg, self.w
         fps_idx, centers, knn_idx = tok.fps_idx, tok.centers, tok.knn_idx
         G = centers.shape[1]
-        emb = self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, centers, knn_idx)
+        emb = self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, centers, knn_idx, radius=cfg.radius,
+                                  center_idx=fps_idx if cfg.centralize_features else None)
         x = self._lin("pc_encoder.patch_proj", emb)
         p1 = ops.pos_l1(centers, w["pc_encoder.pos_embed.0.weight"], w["pc_encoder.pos_embed.0.bias"])
         self._lin("pc_encoder.pos_embed.2", p1, residual=x, out=x)
@@ -320,12 +350,13 @@ class PointCloudSAM:
         return self._lin(prefix + ".layers.2", h, out=out)
 
     @torch.no_grad()
-    def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True):
-        """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState."""
+    def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, use_center_idx=False):
+        """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState.  use_center_idx: the mask
+        encoder receives the groups' FPS indices (what PointCloudSAM.forward does, pc_sam.py:156; predict_masks does not, :65-70)."""
         with ops.gemm_mode(self.precision):
-            return self._decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output)
+            return self._decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output, use_center_idx)
 
-    def _decode(self, st, prompt_coords, prompt_labels, prompt_masks, multimask_output):
+    def _decode(self, st, prompt_coords, prompt_labels, prompt_masks, multimask_output, use_center_idx=False):
         cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
         B, N, _ = st.coords.shape
         G = st.centers.shape[1]
@@ -353,7 +384,11 @@ class PointCloudSAM:
             pm = prompt_masks.to(self.device, torch.float32).contiguous()
             if pm.shape != (Z, N):
                 raise AssertionError((tuple(pm.shape), (Z, N)))
-            dense = self._patch_encoder("mask_encoder.patch_encoder", st.coords, pm.view(Z, N, 1), st.centers, st.knn_idx)
+            if cfg.mask_centralize_features and not use_center_idx:
+                raise ValueError("MaskEncoder.centralize_features needs center_idx: only PointCloudSAM.forward passes it (pc_sam.py:151-157); "
+                                 "predict_masks would fail in the reference too (prompt_encoder.py:122-131 with center_idx=None)")
+            dense = self._patch_encoder("mask_encoder.patch_encoder", st.coords, pm.view(Z, N, 1), st.centers, st.knn_idx, radius=cfg.mask_encoder_radius,
+                                        center_idx=st.fps_idx if cfg.mask_centralize_features else None)
             ops.add_bcast(st.pc_embeddings, rep, dense, src, Z, G, E)
         hs, keys = self._two_way(src.view(Z * G, E), st.pc_pe, tokens.view(Z * T, E), Z, G, T, rep)
         hs = hs.view(Z, T, E)
@@ -452,7 +487,7 @@ class PointCloudSAM:
             nc, nl = self.sample_prompts(coords, gt_masks, prompt_masks, is_eval)
             prompt_coords = torch.cat([prompt_coords, nc], dim=1)
             prompt_labels = torch.cat([prompt_labels, nl], dim=1)
-            masks, iou_preds = self.decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output=(i == 0))
+            masks, iou_preds = self.decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output=(i == 0), use_center_idx=True)
             if i == 0:  # pc_sam.py:176-180
                 max_iou_pred_ind = torch.argmax(iou_preds, dim=1)
                 prompt_masks = torch.gather(masks, 1, max_iou_pred_ind.view(-1, 1, 1).expand(-1, 1, N))[:, 0].contiguous()

@@ -147,20 +147,25 @@ def group_gather(xyz, feats, centers, knn_idx, radius=None):
     return out
 
 
-def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None, radius=None):
-    """Fused gather + Linear(3+C,128) + LayerNorm + GELU -> [B*rep*G*K, 128].  common.py:486-489."""
+def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None, radius=None, center_idx=None, scale_out=None):
+    """Fused gather + Linear(Cin,128) + LayerNorm + GELU -> [B*rep*G*K, 128].  common.py:486-489.
+    center_idx [B,G] (FPS indices): centralize_features (Cin = 3 + 2C, common.py:116-118); scale_out [rows]: the rows leave g8-packed
+    for the f16x3 GEMM (linear(..., x_scale=scale_out, x_packed=True))."""
     _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64); _chk(W)
     B, N, _ = xyz.shape
     rep = feats.shape[0] // B
     G, K = knn_idx.shape[1:]
     C = feats.shape[-1]
-    assert W.shape == (128, 3 + C), W.shape
+    cin = 3 + C * (2 if center_idx is not None else 1)
+    assert W.shape == (128, cin), (W.shape, cin)
+    if center_idx is not None:
+        _chk(center_idx, torch.int64, "center_idx")
     rows = B * rep * G * K
     if out is None:
         out = torch.empty(rows, 128, dtype=torch.float32, device=xyz.device)
-    check(_lib.load().psam_patch_l1_r(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), W.data_ptr(), bias.data_ptr(),
-                                      lnw.data_ptr(), lnb.data_ptr(), eps, B, rep, N, G, K, C, float(radius or 0.0), out.data_ptr(), _stream()),
-          "psam_patch_l1")
+    check(_lib.load().psam_patch_l1_ex(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), _p(center_idx), W.data_ptr(),
+                                       bias.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), eps, B, rep, N, G, K, C, float(radius or 0.0), out.data_ptr(),
+                                       _p(scale_out), _stream()), "psam_patch_l1")
     return out
 
 
@@ -277,14 +282,16 @@ def ln_stats_finalize(stats, cols, eps):
 
 
 def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False,
-           pack_out=None, stats=None, ln_fold=None):
+           pack_out=None, stats=None, ln_fold=None, group_max_out=None, group_max_k=0, no_store=False):
     """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views, or W an F16Weight
     (prepared static weight).
     "f16x3" mode with an F16Weight and M above the threshold runs the packed-operand GEMM (csrc/gemm_f16x3p.hip): x is either already
     g8-packed by its producer (x_packed=True with x_scale: LayerNorm / scale_pack_rows_g8 output, [M, >= K padded to 32]) or is
     scaled and packed here in one extra pass.  Fused extras of that GEMM (fuse_supported shapes; include/pointsam_hip.h psam_gemm_fuse_t):
     pack_out=(scale_out [M], k1, k2): `out` receives g8-packed rows + their bound-derived scales; stats=(buf [M, stat_segs(N), 2], cols):
-    LayerNorm partials of the SwiGLU-gated rows; ln_fold=(mean [M], rstd [M], c [N]): LayerNorm of x folded into the GEMM."""
+    LayerNorm partials of the SwiGLU-gated rows; ln_fold=(mean [M], rstd [M], c [N]): LayerNorm of x folded into the GEMM;
+    group_max_out [M / group_max_k, N] (group_max_k 32 | 64): per-column max over consecutive row groups of the output, no_store: the
+    [M, N] output itself is not written (out may then be None)."""
     fw = None
     if isinstance(W, F16Weight):
         fw, W = W, W.fp32
@@ -297,9 +304,13 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         assert x_packed or x.shape[1] == K, (x.shape, W.shape)
     elif fw is not None and K != fw.K:
         fw = None
-    if out is None:
-        out = torch.empty(M, N // 2 if act == ACT_SWIGLU else N, dtype=torch.float32, device=x.device)
-    op, ldo = _row_view(out, "out")
+    fused = pack_out is not None or stats is not None or ln_fold is not None or group_max_out is not None
+    if no_store and group_max_out is not None and out is None:
+        op, ldo = group_max_out.data_ptr(), N       # never dereferenced
+    else:
+        if out is None:
+            out = torch.empty(M, N // 2 if act == ACT_SWIGLU else N, dtype=torch.float32, device=x.device)
+        op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
     if GEMM_MODE == "f16x3" and fw is not None and M >= SPLIT_MIN_M:
@@ -310,8 +321,10 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         else:
             xa, sa = scale_pack_rows_g8(x, K)
         fuse = None
-        if pack_out is not None or stats is not None or ln_fold is not None:
+        if fused:
             fuse = _lib.GemmFuse()
+            if group_max_out is not None:
+                fuse.gmax_out, fuse.gmax_ld, fuse.gmax_k, fuse.no_store = group_max_out.data_ptr(), group_max_out.stride(0), int(group_max_k), int(bool(no_store))
             if pack_out is not None:
                 fuse.out_scale, fuse.out_k1, fuse.out_k2, fuse.pack_out = pack_out[0].data_ptr(), float(pack_out[1]), float(pack_out[2]), 1
             if stats is not None:
@@ -321,7 +334,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         _f16x3p_call((xa.data_ptr(), xa.stride(0), sa.data_ptr(), fw.packed.data_ptr(), fw.packed.stride(0), fw.scale.data_ptr(), op, ldo, _p(bias),
                       rp, ldr, rbp, ldrb, rowgroup, M, N, fw.Kp, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K, fuse)
         return out
-    if pack_out is not None or stats is not None or ln_fold is not None:
+    if fused:
         raise ValueError("fused GEMM extras exist only on the f16x3 packed-operand path")
     if x_packed:
         raise ValueError("x_packed activations can only feed an f16x3 GEMM with a prepared F16Weight (M above the split threshold)")

@@ -53,7 +53,7 @@ def expected_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
         linear(prefix + ".conv2.3", h1, cout)
 
     # --- pc_encoder (pc_encoder.py:84-116)
-    patch_encoder("pc_encoder.patch_embed.patch_encoder", cfg.in_channels, cfg.patch_out)
+    patch_encoder("pc_encoder.patch_embed.patch_encoder", cfg.patch_in_channels, cfg.patch_out)
     linear("pc_encoder.patch_proj", cfg.patch_out, D)
     linear("pc_encoder.pos_embed.0", 3, 128)
     linear("pc_encoder.pos_embed.2", 128, D)
@@ -85,7 +85,7 @@ def expected_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     s["point_encoder.pe_layer.positional_encoding_gaussian_matrix"] = (3, E // 2)
     s["point_encoder.point_embeddings.0.weight"] = (1, E)
     s["point_encoder.point_embeddings.1.weight"] = (1, E)
-    patch_encoder("mask_encoder.patch_encoder", 4, E)
+    patch_encoder("mask_encoder.patch_encoder", cfg.mask_in_channels, E)
     s["mask_encoder.no_mask_embed.weight"] = (1, E)
     # --- mask decoder (mask_decoder.py:21-63, transformer.py:15-59,103-142,179-202,240-249)
     s["mask_decoder.iou_token.weight"] = (1, E)

@@ -40,6 +40,11 @@ def golden_radius():
 
 
 @pytest.fixture(scope="session")
+def golden_central():
+    return load_golden("ref_tiny_central")
+
+
+@pytest.fixture(scope="session")
 def golden_forward():
     return load_golden("ref_tiny_forward_eval")
 

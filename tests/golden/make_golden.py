@@ -163,9 +163,11 @@ def build_reference_model(cfg, sd):
 
     model = PointCloudSAM(
         pc_encoder=PointCloudEncoder(
-            PatchEmbed(cfg.in_channels, cfg.patch_out, cfg.num_groups, cfg.group_size, radius=cfg.radius), StandInEva(cfg.vit), cfg.embed_dim
+            PatchEmbed(cfg.patch_in_channels, cfg.patch_out, cfg.num_groups, cfg.group_size, radius=cfg.radius, centralize_features=cfg.centralize_features),
+            StandInEva(cfg.vit), cfg.embed_dim
         ),
-        mask_encoder=MaskEncoder(cfg.embed_dim, radius=cfg.radius),
+        mask_encoder=MaskEncoder(cfg.embed_dim, in_channels=cfg.mask_in_channels, radius=cfg.mask_encoder_radius,
+                                 centralize_features=cfg.mask_centralize_features),
         mask_decoder=MaskDecoder(cfg.embed_dim, TwoWayTransformer(cfg.dec_depth, cfg.embed_dim, cfg.dec_heads, cfg.dec_mlp)),
         prompt_iters=cfg.prompt_iters,
     )
@@ -285,11 +287,15 @@ def make_ply_cases(name, cfg_name, G, K, seed):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "central":  # only the centralize_features fixture
+        make_case("ref_tiny_central", "tiny_central", B=2, N=800, M=2, P=1, seed=9)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ply":      # only the demo-PLY fixture
         make_ply_cases("ref_demo_ply", "tiny", G=128, K=32, seed=13)
         sys.exit(0)
     make_case("ref_tiny_swiglu", "tiny", B=2, N=1024, M=2, P=2, seed=7)
     make_case("ref_tiny_gelu", "tiny_gelu", B=1, N=777, M=1, P=1, seed=11)
     make_case("ref_tiny_radius", "tiny_radius", B=2, N=900, M=1, P=2, seed=5)
+    make_case("ref_tiny_central", "tiny_central", B=2, N=800, M=2, P=1, seed=9)
     make_forward_case("ref_tiny_forward_eval", "tiny", B=2, N=1024, seed=7, iters=4)
     make_ply_cases("ref_demo_ply", "tiny", G=128, K=32, seed=13)

@@ -96,3 +96,45 @@ def test_sampled_pointcloud_and_errors(server):
     assert _req(port, "POST", "/next")[0] == 400                       # nothing segmented yet
     assert _req(port, "POST", "/nope")[0] == 404 and _req(port, "GET", "/index.html")[0] == 404
     assert _req(port, "GET", "/pointcloud/missing.ply")[0] == 400
+
+
+def test_static_routes_and_path_sanitisation(tmp_path):
+    """GET /, /static/<path>, /mesh/<path> serve the front end's files like demo/app.py:71-89; every URL path stays inside its
+    root directory (the reference's Flask send_static_file guarantees the same)."""
+    static = tmp_path / "static"
+    (static / "models" / "Rhino").mkdir(parents=True)
+    (static / "index.html").write_text("<html>demo</html>")
+    (static / "viewer.js").write_text("console.log(1)")
+    (static / "models" / "Rhino" / "rhino.obj").write_text("v 0 0 0")
+    (tmp_path / "secret.txt").write_text("top secret")
+    (static / "models" / "toy.ply").write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\n"
+                                               "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n0 0 0 1 2 3\n")
+    sess = DemoSession(FakePredictor(), models_dir=str(static / "models"), device="cpu", static_dir=str(static))
+    srv = serve(sess, "127.0.0.1", 0)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    port = srv.server_address[1]
+    try:
+        def get(path):
+            c = http.client.HTTPConnection("127.0.0.1", port, timeout=10)
+            c.request("GET", path)
+            r = c.getresponse()
+            return r.status, r.read(), dict(r.getheaders())
+        st, body, hdr = get("/")
+        assert st == 200 and body == b"<html>demo</html>" and hdr["Content-Type"].startswith("text/html")
+        st, body, hdr = get("/static/viewer.js")
+        assert st == 200 and body == b"console.log(1)" and hdr["Content-Type"] == "application/javascript"
+        st, body, _ = get("/mesh/Rhino/rhino.obj")
+        assert st == 200 and body == b"v 0 0 0"
+        assert get("/static/nope.js")[0] == 404
+        for evil in ("/static/../secret.txt", "/static/%2e%2e/secret.txt", "/mesh/../../secret.txt", "/static//etc/passwd", "/pointcloud/../../secret.txt",
+                     "/pointcloud/%2e%2e%2f%2e%2e%2fsecret.txt"):
+            st, body, _ = get(evil)
+            assert st in (400, 404) and b"top secret" not in body, evil
+        assert get("/pointcloud/toy.ply")[0] == 200
+    finally:
+        srv.shutdown()
+    from point_sam_amd.demo_server import safe_join
+    assert safe_join(str(static), "models/toy.ply").endswith("toy.ply")
+    for bad in ("../x", "a/../../x", "/abs", "models/../../secret.txt"):
+        with pytest.raises(ValueError):
+            safe_join(str(static), bad)

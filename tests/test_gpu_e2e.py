@@ -28,7 +28,7 @@ def _maxerr(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 
 
-@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius"])
+@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius", "golden_central"])
 def test_against_reference_golden(gpu, which, request):
     meta, a = request.getfixturevalue(which)
     cfg = get_config(meta["cfg"])
@@ -111,6 +111,45 @@ def test_fused_mlp_matches_unfused_model(gpu):
     e_emb, e_m = _maxerr(outs[0][0], outs[1][0]), _maxerr(outs[0][1], outs[1][1])
     print(f"\n[fused vs unfused MLP, ViT-L x24] max|diff| embeddings {e_emb:.2e} masks {e_m:.2e}")
     assert e_emb < 1e-4 and e_m < 1e-4
+
+
+def test_fused_patch_encoder_matches_unfused(gpu):
+    """Mini-PointNet with packed hand-overs and the two max-pools inside GEMM epilogues vs the separate-kernel sequence, for the point
+    patch encoder (6 input channels) and the mask encoder (4 channels, second click), groups of 64 and of 32."""
+    for G, K in ((128, 64), (256, 32)):
+        cfg = get_config("tiny", G, K)
+        sd = random_state_dict(cfg, seed=3)
+        xyz, rgb, prompt, labels = O.synthetic_batch(2, 9000, seed=4)
+        outs = []
+        for fuse in (True, False):
+            model = gpu(cfg, sd, precision="f16x3")
+            model.fuse_patch = fuse
+            st = model.encode(xyz.cuda(), rgb.cuda())
+            m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+            m2, i2 = model.decode(st, prompt.cuda(), labels.cuda(), m1[:, 0].contiguous(), False)
+            outs.append((st.patch_embeddings, m1, m2))
+        e = [_maxerr(a, b) for a, b in zip(*outs)]
+        print(f"\n[fused vs unfused patch encoder G={G} K={K}] max|diff| patch embeddings {e[0]:.2e} masks {e[1]:.2e} click-2 masks {e[2]:.2e}")
+        assert max(e) < 5e-5, e
+
+
+def test_mask_encoder_centralize_in_forward(gpu):
+    """MaskEncoder.centralize_features (logit minus the centre point's logit, common.py:183-186): only reachable through
+    PointCloudSAM.forward, which passes center_idx (pc_sam.py:151-157); predict_masks raises as the reference would fail."""
+    from dataclasses import replace as dc_replace
+    cfg = dc_replace(get_config("tiny"), mask_centralize_features=True, mask_radius=0.3)
+    sd = random_state_dict(cfg, seed=12)
+    xyz, rgb, prompt, labels = O.synthetic_batch(2, 700, seed=3)
+    gt = torch.stack([xyz[..., 0] > 0.1, xyz[..., 2] < -0.2], 1)
+    want = O.forward_eval(sd, cfg, xyz, rgb, gt, prompt_iters=3)
+    model = gpu(cfg, sd)
+    model.prompt_iters = 3
+    outs = model(xyz.cuda(), rgb.cuda(), gt.cuda(), is_eval=True)
+    for o, w in zip(outs, want):
+        assert torch.equal(o["prompt_coords"].cpu(), w["prompt_coords"])
+        assert _maxerr(o["masks"], w["masks"]) < TOL and _maxerr(o["iou_preds"], w["iou_preds"]) < TOL
+    with pytest.raises(ValueError):
+        model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda(), prompt_masks=outs[0]["prompt_masks"][:2])
 
 
 def test_properties_full_size(gpu):

@@ -17,7 +17,7 @@ def _setup(golden):
     return meta, a, cfg, sd
 
 
-@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius"])
+@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius", "golden_central"])
 def test_oracle_reference_mode_matches_reference(which, request):
     meta, a, cfg, sd = _setup(request.getfixturevalue(which))
     # tokenizer: FPS indices are the stub's (= oracle) by construction; kNN via cdist+topk is reference code
@@ -43,7 +43,7 @@ def test_oracle_reference_mode_matches_reference(which, request):
     assert torch.equal(ii.sort(-1).values, a["interp_index"].sort(-1).values)
 
 
-@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius"])
+@pytest.mark.parametrize("which", ["golden_swiglu", "golden_gelu", "golden_radius", "golden_central"])
 def test_oracle_exact_mode_close_to_reference(which, request):
     """'exact' distances (what the HIP kernels implement) vs the reference's cdist: same neighbour sets on these
     inputs, logits within the north_star tolerance (1e-3)."""
