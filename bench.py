@@ -26,18 +26,26 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16
 
 
-def cpu_baseline(cfg, sd, N, seed):
-    """The oracle (CPU restatement of the reference, PyTorch fp32 + C tokenizer) on a bounded sample: ONE cloud of the
-    same workload.  Reported next to the GPU number; never the thing measured above."""
+def cpu_baseline(cfg, sd, N, seed, iters=3):
+    """The oracle (CPU restatement of the reference, PyTorch fp32 + C tokenizer) on a bounded sample: ONE cloud of the same workload,
+    one warm-up run + `iters` timed runs (median).  Reported next to the GPU number; never the thing measured above."""
     from oracle import pointsam_oracle as O
     xyz, rgb, prompt, labels = O.synthetic_batch(1, N, seed=seed)
     cores = torch.get_num_threads()
     O.fps(xyz[:, :4096], 16)  # build/load the C library outside the timed region
-    t0 = time.perf_counter()
-    O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="reference")
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
-            "sample": f"1 cloud of the workload (ViT-L, N={N}, 512x64, 1 prompt), oracle mode='reference' (torch.cdist+topk), {dt:.1f} s"}
+    run = lambda: O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="reference")
+    run()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    return {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port", "iterations": iters,
+            "seconds_per_cloud": {"median": round(dt, 3), "min": round(ts[0], 3), "max": round(ts[-1], 3)},
+            "sample": f"1 cloud of the workload (ViT-L, N={N}, 512x64, 1 prompt), oracle mode='reference' (torch.cdist+topk), 1 warm-up + {iters} timed runs, "
+                      f"median {dt:.1f} s; torch {torch.__version__}, {cores} threads"}
 
 
 def main():
@@ -56,6 +64,11 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="dense-stage HIP streams: batches in flight (1 = only the tokenizer of the next batch overlaps)")
     ap.add_argument("--no-pipeline", action="store_true", help="run FPS/kNN of each batch inline instead of one batch ahead on a side stream")
     ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")
+    ap.add_argument("--graphs", dest="graphs", action="store_true", default=True,
+                    help="replay the two stages of a batch as captured HIP graphs (default; host enqueue ~0.1 ms per step)")
+    ap.add_argument("--no-graphs", dest="graphs", action="store_false", help="issue every kernel launch from Python (BatchPipeline)")
+    ap.add_argument("--slots", type=int, default=3, help="batches in flight with --graphs (static buffer sets)")
+    ap.add_argument("--no-stage-times", action="store_true", help="skip the per-stage timing pass after the timed region")
     args = ap.parse_args()
 
     from point_sam_amd import dist as psdist
@@ -78,19 +91,56 @@ def main():
     xyz, rgb, prompt, labels = xyz.to(dev), rgb.to(dev), prompt.to(dev), labels.to(dev)
     total = B * world
 
-    from point_sam_amd.model import BatchPipeline
+    from point_sam_amd.model import BatchPipeline, GraphPipeline
+    use_graphs = args.graphs and not args.no_pipeline
     pipe = BatchPipeline(model, dense_streams=args.streams) if not args.no_pipeline else None
+    gpipe = GraphPipeline(model, xyz, rgb, prompt, labels, None, True, slots=args.slots, dense_streams=args.streams) if use_graphs else None
+
+    side_gather = psdist.SideStreamGather(dev)       # N > 1: the all_gather of a step's logits runs on its own stream
+    pending = []
 
     def finish(masks, iou):
-        if world > 1:
-            masks = psdist.gather_results(masks, total)
-            iou = psdist.gather_results(iou, total)
-        return masks, iou
+        """Starts the gather of this step's results (side stream) and completes the previous step's: the collective of step k overlaps
+        the dense stage of the batches behind it.  Returns the newest COMPLETED (gathered) results."""
+        if world == 1:
+            return masks, iou
+        pending.append(side_gather.start((masks, iou), total))
+        return side_gather.finish(pending.pop(0)) if len(pending) > 1 else (masks, iou)
 
-    def run_steps(n, prof=None):
-        """n full passes (every batch is tokenized, encoded and decoded inside this call).  With the pipeline the tokenizer stage of a
-        step runs on its own stream ahead of the dense stage, and `pipe.depth` batches are in flight.  prof: sample the GEMM launches
-        of the LAST step (every 3rd one, HIP events on the launch stream, the other dense stream held off during a sampled launch)."""
+    def drain():
+        out = None
+        while pending:
+            out = side_gather.finish(pending.pop(0))
+        return out
+
+    main_stream = torch.cuda.current_stream(dev)
+
+    def mark(events):
+        if events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(main_stream)
+            events.append(e)
+
+    def run_graph_steps(n, events=None):
+        """n full passes through the captured graphs: `slots` batches in flight, next() before the slot is submitted again."""
+        out = None
+        mark(events)
+        for k in range(min(gpipe.depth, n)):
+            gpipe.submit(xyz, rgb, prompt, labels, None, True)
+        for k in range(n):
+            out = finish(*gpipe.next())
+            mark(events)
+            if k + gpipe.depth < n:
+                if side_gather.stream is not None:      # the slot's static outputs are still being read by the gather just started
+                    main_stream.wait_stream(side_gather.stream)
+                gpipe.submit(xyz, rgb, prompt, labels, None, True)
+        return out
+
+    def run_steps(n, prof=None, events=None):
+        """n full passes (every batch is tokenized, encoded and decoded inside this call), every launch issued from Python.  With the
+        pipeline the tokenizer stage of a step runs on its own stream ahead of the dense stage, and `pipe.depth` batches are in flight.
+        prof: sample the GEMM launches of the LAST step (every 3rd one, HIP events on the launch stream, the other dense stream held
+        off during a sampled launch)."""
         def dense_call(k, fn):   # fn enqueues the dense stage of step k
             if prof is None or k != n - 1:
                 return fn()
@@ -104,9 +154,11 @@ def main():
             finally:
                 ops.GEMM_PROFILE, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER, ops.GEMM_PROFILE_EVERY = None, (), 0, 29
         out = None
+        mark(events)
         if pipe is None:
             for k in range(n):
                 out = finish(*dense_call(k, lambda: model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False)))
+                mark(events)
             return out
         sub = lambda: pipe.submit(xyz, rgb, prompt, labels, None, True)
         for k in range(min(pipe.depth, n)):
@@ -115,6 +167,7 @@ def main():
             if k + pipe.depth < n:
                 dense_call(k + pipe.depth, sub) if pipe.dense else sub()
             out = finish(*(pipe.next() if pipe.dense else dense_call(k, pipe.next)))
+            mark(events)
         return out
 
     def fence():
@@ -123,11 +176,16 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup:
-        run_steps(args.warmup)
+        run_graph_steps(args.warmup) if use_graphs else run_steps(args.warmup)
+        drain()
     prof = None if args.no_gemm_profile else []
+    step_events = []
     fence()
     t0 = time.perf_counter()
-    out = run_steps(args.steps, prof)
+    # timed region: exactly --steps passes.  With graphs the per-launch GEMM sampling cannot sit inside a replay: it runs in one
+    # extra eager pass AFTER the timed region (same process, same workload, same kernels); without graphs it samples the last timed step.
+    out = run_graph_steps(args.steps, step_events) if use_graphs else run_steps(args.steps, prof, step_events)
+    out = drain() or out                       # N > 1: the last step's gather completes inside the timed region
     t_enqueued = time.perf_counter() - t0      # host time to issue every launch of the timed region (no sync inside)
     fence()
     elapsed = time.perf_counter() - t0
@@ -137,6 +195,17 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    gaps = sorted(a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:]))
+    step_stats = {"median": round(gaps[len(gaps) // 2], 3), "min": round(gaps[0], 3), "max": round(gaps[-1], 3),
+                  "note": "ms between consecutive step completions on the caller's stream (HIP events); the first steps of the region fill the pipeline"} if gaps else None
+    if use_graphs and prof is not None:
+        run_steps(2, prof)       # untimed eager pass for the per-launch GEMM durations (see above)
+        torch.cuda.synchronize()
+    stage_ms = tok_roof = None
+    if rank == 0 and not args.no_stage_times:
+        from point_sam_amd.profiling import stage_times, tokenizer_roofline
+        stage_ms = stage_times(model, xyz, rgb, prompt, labels, passes=3, warmup=1)
+        tok_roof = tokenizer_roofline(stage_ms, B, N, args.groups, args.group_size)
 
     roofline = None
     if prof:
@@ -171,12 +240,15 @@ def main():
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "traffic_note": f"bytes/launch (launch-weighted mean over the kernel's tile configurations), rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
                         "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
-                        "sampling": ("every 3rd GEMM launch of the last step of the timed region, HIP events on the launch stream" +
+                        "sampling": (("every 3rd GEMM launch of one eager (un-graphed) pass right after the timed region, HIP events on the launch stream" if use_graphs else
+                                      "every 3rd GEMM launch of the last step of the timed region, HIP events on the launch stream") +
                                      ("; second half of that step only, when the previous batch has drained, and the other dense stream is held off during a sampled launch: the duration is the kernel's own" if (pipe is not None and pipe.depth > 1) else "")),
                         "avg_launch_ms": round(tot_ms / len(sel), 4), "avg_launch_gflop": round(tot_fl / len(sel) / 1e9, 3)}
             # whole-path figure of SURVEY.md 8(d): algorithmic flops of the path (3.72e11 per cloud at this workload) / step time
             if args.config == "large" and N == 32768 and args.groups == 512 and args.group_size == 64:
                 roofline["whole_path_achieved"] = round(3.72e11 * total / world / (elapsed / args.steps) / 1e12, 2)
+                roofline["whole_path_frac"] = round(roofline["whole_path_achieved"] / peak, 4)
+            roofline["tokenizer"] = tok_roof
 
     if rank == 0:
         res = {
@@ -187,9 +259,12 @@ def main():
                       "f16x3": "f32 (fp32 in/out/accumulate; large GEMMs as row-scaled 2-way fp16 split x 3 MFMA products, fp32-grade error)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"ViT-{args.config} N={N} g={args.groups}x{args.group_size} batch={B}/GPU 1 point prompt multimask",
-                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None, "batches_in_flight": (pipe.depth if pipe is not None else 1),
+                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None,
+                       "batches_in_flight": (gpipe.depth if use_graphs else (pipe.depth if pipe is not None else 1)), "dense_streams": args.streams, "hip_graphs": use_graphs,
                        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3), "gemm_precision": args.precision, "weights": "seeded random init (no checkpoint offline)"},
             "roofline": roofline,
+            "step_ms": step_stats,
+            "stage_ms": stage_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, N, 42)

@@ -22,6 +22,7 @@
 //   * epilogue: gemm_epilogue.h (LDS transposition, float4 rows).
 // Tile shapes (waves WM x WN, each TM x TN accumulator tiles of 32x32) and S are template parameters; the host picks per shape.
 #include <type_traits>
+#include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -397,7 +398,15 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     }
-    const int ncu_eff = ncu > 16 ? ncu - 8 : ncu;
+    static int reserve = -1;
+    static double share2 = 0.0;
+    if (reserve < 0) {      // tuning hooks (environment, read once): CUs assumed busy elsewhere; slowdown of two co-resident tiles
+        const char* e = getenv("PSAM_GEMM_RESERVE_CUS");
+        reserve = e ? atoi(e) : 8;
+        const char* f = getenv("PSAM_GEMM_SHARE");
+        share2 = f ? atof(f) : 1.6;
+    }
+    const int ncu_eff = ncu > 2 * reserve ? ncu - reserve : ncu;
     struct Cand { int cfg, bm, bn, per_cu; bool swiglu, two_wide; double pen; };
     static const Cand cands[] = {{14, 256, 256, 1, true, false, 1.0}, {23, 256, 192, 1, false, false, 1.0}, {4, 256, 128, 1, true, true, 1.05},
                                  {9, 128, 128, 1, true, true, 1.15},  {21, 128, 128, 2, true, true, 1.15},  {28, 128, 128, 2, true, true, 1.2}};
@@ -408,7 +417,7 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
         if (two_wide_only && !c.two_wide) continue;
         const int64_t tiles = psam_cdiv(M, c.bm) * psam_cdiv(N, c.bn);
         const double rounds = (double)psam_cdiv(tiles, (int64_t)ncu_eff * c.per_cu);
-        const double share = (c.per_cu == 2 && tiles * 2 > (int64_t)ncu_eff * 3) ? 1.6 : 1.0;
+        const double share = (c.per_cu == 2 && tiles * 2 > (int64_t)ncu_eff * 3) ? share2 : 1.0;
         const double cost = rounds * c.bm * c.bn * (K + 300.0) * c.pen * share;
         if (cost < best_cost) { best_cost = cost; best = c.cfg; }
     }

@@ -58,3 +58,39 @@ def gather_results(local: torch.Tensor, total: int, async_op: bool = False):
     if async_op:
         return finish, work
     return finish()
+
+
+class SideStreamGather:
+    """The per-step all_gather of the results on its own HIP stream, so that the collective (RCCL over xGMI; latency-bound: 3.1 MB per
+    rank at BASELINE config #4) overlaps the dense stage of the following batches instead of sitting between them.
+
+        g = SideStreamGather(device)
+        h = g.start((masks, iou), total)      # on the caller's stream, after the results were produced
+        ...                                   # enqueue more work
+        masks_all, iou_all = g.finish(h)      # makes the caller's stream wait for the collective
+
+    With one process (no process group) start/finish pass the tensors through."""
+
+    def __init__(self, device=None):
+        self.stream = torch.cuda.Stream(device=device) if (torch.cuda.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+    def start(self, tensors, total: int):
+        if self.stream is None:
+            return tuple(tensors), None
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            outs = tuple(gather_results(t, total) for t in tensors)
+            for t in tensors:
+                t.record_stream(self.stream)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return outs, ev
+
+    def finish(self, handle):
+        outs, ev = handle
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            for t in outs:
+                t.record_stream(torch.cuda.current_stream())
+        return outs

@@ -456,3 +456,82 @@ def test_evaluation_harness(gpu):
     res = E.evaluate_clouds(model, samples, adapt_grouper=False)
     assert res["per_cloud"].shape == (2, 3)
     assert np.allclose(res["per_cloud"], np.array(want), atol=2e-3), (res["per_cloud"], want)
+
+
+def test_graph_pipeline_matches_eager(gpu):
+    """The two stages of a batch replayed as captured HIP graphs (GraphPipeline: static buffers, `slots` batches in flight) give
+    bit-identical results to the eager path, also when the inputs change from step to step."""
+    from point_sam_amd.model import GraphPipeline
+    cfg = get_config("tiny", 64, 16)
+    model = gpu(cfg, random_state_dict(cfg, 4), precision="f16x3")
+    batches = []
+    for i in range(7):
+        xyz, rgb, prompt, labels = O.synthetic_batch(2, 3000, seed=40 + i)
+        batches.append(tuple(t.cuda() for t in (xyz, rgb, prompt, labels)))
+    want = [model.predict_masks(*b) for b in batches]
+    pipe = GraphPipeline(model, *batches[0], None, True, slots=3, dense_streams=2)
+    got = []
+    for k in range(min(pipe.depth, len(batches))):
+        pipe.submit(*batches[k])
+    with pytest.raises(RuntimeError):
+        pipe.submit(*batches[0])                     # all slots in flight
+    for k in range(len(batches)):
+        m, i = pipe.next()
+        got.append((m.clone(), i.clone()))           # static outputs: copy before the slot is reused
+        if k + pipe.depth < len(batches):
+            pipe.submit(*batches[k + pipe.depth])
+    torch.cuda.synchronize()
+    for (m1, i1), (m2, i2) in zip(want, got):
+        assert torch.equal(m1, m2) and torch.equal(i1, i2)
+    model.check_coordinate_range()
+
+
+def _nccl_worker(rank, world, port, q):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from point_sam_amd import dist as psdist
+    from point_sam_amd.model import PointCloudSAM
+    r, w, local = psdist.init_from_env(backend="nccl")
+    torch.cuda.set_device(local)
+    cfg = get_config("tiny", 64, 16)
+    sd = random_state_dict(cfg, 5)
+    total = 4
+    xyz, rgb, prompt, labels = O.synthetic_batch(total, 4000, seed=9)
+    lo, hi = psdist.shard_range(total, r, w)
+    model = PointCloudSAM(cfg, sd, f"cuda:{local}", precision="f16x3")
+    dev = lambda t: t[lo:hi].contiguous().to(f"cuda:{local}")
+    masks, iou = model.predict_masks(dev(xyz), dev(rgb), dev(prompt), dev(labels))
+    g = psdist.SideStreamGather(torch.device("cuda", local))
+    all_masks, all_iou = g.finish(g.start((masks, iou), total))
+    torch.cuda.synchronize()
+    if r == 0:
+        full = lambda t: t.to(f"cuda:{local}")
+        ref_masks, ref_iou = model.predict_masks(full(xyz), full(rgb), full(prompt), full(labels))
+        q.put((bool(torch.equal(all_masks, ref_masks)), bool(torch.equal(all_iou, ref_iou)), tuple(all_masks.shape)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_match_one_rank(gpu):
+    """BASELINE config #4's mechanism on two GPUs of one node (skipped with fewer): one process per GPU, each rank runs its shard of
+    the clouds, the logits are all-gathered over RCCL on a side stream; the gathered result equals the single-rank run bit for bit
+    (clouds never interact)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    ok_m, ok_i, shape = q.get(timeout=10)
+    assert ok_m and ok_i and shape[0] == 4
