@@ -193,6 +193,13 @@ int32_t psam_attention_f32(const float* q, int64_t ldq, int64_t sq, const float*
 int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                            int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
                            float scale, psam_stream_t stream);
+/* The same with a PACKED output for the output projection (psam_gemm_f16x3p): a_scale [B*Lk] = the row scales of the qkv GEMM's A
+ * operand (LayerNorm output), k1 = 2^15 sqrt(D) max_n ||W_v[n]||_2, k2 = max |b_v|: every |V| of a cloud -- hence every attention
+ * output, a convex combination of V rows -- is below B = k1 / min_rows(a_scale) + k2; o receives the g8-packed rows scaled by the
+ * power of two that puts B into [2^14, 2^15), o_scale [B*Lq] that scale.  a_scale == NULL: plain fp32 output. */
+int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                                int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
+                                const float* a_scale, float k1, float k2, float* o_scale, psam_stream_t stream);
 
 /* Same contraction for the decoder's token-sized problems (any hd, few queries or few keys).
  * Replaces Attention.forward's matmul-softmax-matmul: pc_sam/model/transformer.py:226-233. */

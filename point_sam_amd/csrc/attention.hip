@@ -25,6 +25,11 @@ struct FlashArgs {
     int64_t ldq, ldk, ldv, ldo, sq, sk, sv, so;
     int H, Lq, Lk;
     float scale_log2e;
+    // packed output (flash_attn_f16x3_kernel only): o receives the g8-packed rows (the A operand of the output projection,
+    // gemm_f16x3p.hip), scaled by o_scale[row] = the power of two that puts the BOUND k1 / min_rows(a_scale) + k2 of |V| over the cloud
+    // into [2^14, 2^15) -- attention outputs are convex combinations of V rows, so the bound holds for them; a_scale = the row scales
+    // of the qkv GEMM's A operand (LayerNorm output), k1 = 2^15 sqrt(D) max_n ||W_v[n]||, k2 = max |b_v|.
+    const float* a_scale; float* o_scale; float k1, k2;
 };
 
 template <int HD8, int DT>
@@ -194,6 +199,7 @@ PSAM_API int32_t psam_attention_f32(const float* q, int64_t ldq, int64_t sq, con
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
     p.H = H; p.Lq = Lq; p.Lk = Lk;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.a_scale = nullptr; p.o_scale = nullptr; p.k1 = p.k2 = 0.f;
     const dim3 grid((unsigned)psam_cdiv(Lq, FA_BQ), H, B), block(256);
 #define FA_LAUNCH(HD8, DT) hipLaunchKernelGGL((flash_attn_f32_kernel<HD8, DT>), grid, block, 0, stream, p)
     switch (hd) {
@@ -263,6 +269,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     const float* Q = p.q + b * p.sq + head * HD;
     const float* K = p.k + b * p.sk + head * HD;
     const float* V = p.v + b * p.sv + head * HD;
+
+    float out_scale = 0.f;     // packed output: one scale for every row of the cloud (see FlashArgs)
+    if (p.o_scale) {
+        float smin = INFINITY;
+        for (int i = tid; i < p.Lk; i += 256) smin = fminf(smin, p.a_scale[(int64_t)b * p.Lk + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) smin = fminf(smin, __shfl_xor(smin, o, 64));
+        if (lane == 0) smax[0][wave][0] = smin;
+        __syncthreads();
+        smin = fminf(fminf(smax[0][0][0], smax[0][1][0]), fminf(smax[0][2][0], smax[0][3][0]));
+        __syncthreads();       // smax is reused by the tile scales below
+        out_scale = f16_row_scale(p.k1 / smin + p.k2);
+    }
 
     // ---- this lane's query row: d-slots 16s + 8h .. +7 of every k16 step, scaled by the row's power of two, split
     fa_f16x8 qh[KS], ql[KS];
@@ -478,6 +497,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);          // 2^14 * sum of probabilities
     const float inv = fa_inv_pow2(sv_acc) / l_tot;                  // (oacc / (2^14 sv)) / (l_tot / 2^14)
     const int qrow = q0 + r32;
+    if (p.o_scale) {
+        // g8-packed rows: this lane holds channels d0..d0+3 of its query row, lane ^ 32 the other four of the same group of 8: the
+        // lower half-wave collects the 16-byte hi chunk, the upper one the lo chunk (one exchange); both land at container d0
+        if (head == 0 && h == 0 && qrow < p.Lq) p.o_scale[(int64_t)b * p.Lq + qrow] = out_scale;
+        float* op = p.o + b * p.so + (int64_t)(qrow < p.Lq ? qrow : 0) * p.ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = d * 32 + 8 * g + 4 * h;
+                unsigned h0, l0, h1, l1;
+                fa_split2(fa_f32x2{oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv} * out_scale, h0, l0);
+                fa_split2(fa_f32x2{oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv} * out_scale, h1, l1);
+                const unsigned r0 = __shfl_xor(h ? h0 : l0, 32, 64), r1 = __shfl_xor(h ? h1 : l1, 32, 64);
+                if (qrow < p.Lq) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
+            }
+        return;
+    }
     if (qrow < p.Lq) {
         float* op = p.o + b * p.so + (int64_t)qrow * p.ldo + head * HD;
 #pragma unroll
@@ -491,11 +528,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     }
 }
 
-// Same contract as psam_attention_f32; head_dim in {64, 128}.
-PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
-                                      int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
-                                      float scale, hipStream_t stream) {
+// Same contract as psam_attention_f32; head_dim in {64, 128}.  a_scale != NULL: packed output (FlashArgs), o_scale [B*Lq] receives the row
+// scales; o must then be 32-byte aligned with ldo % 8 == 0 and H*hd % 8 == 0.
+PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                                         int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                                         float scale, const float* a_scale, float k1, float k2, float* o_scale, hipStream_t stream) {
     PSAM_REQUIRE(q && k && v && o, PSAM_EINVAL, "psam_attention_f16x3: null pointer");
+    PSAM_REQUIRE((a_scale == nullptr) == (o_scale == nullptr), PSAM_EINVAL, "psam_attention_f16x3: packed output needs both a_scale and o_scale");
+    PSAM_REQUIRE(!o_scale || ((ldo & 7) == 0 && ((uintptr_t)o & 31) == 0 && (so & 7) == 0 && Lq == Lk), PSAM_EINVAL,
+                 "psam_attention_f16x3: packed output needs 32-byte aligned rows and self-attention (Lq == Lk)");
     PSAM_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, PSAM_EINVAL, "psam_attention_f16x3: bad shape");
     PSAM_REQUIRE(B <= 65535 && H <= 65535, PSAM_EINVAL, "psam_attention_f16x3: B/H too large");
     PSAM_REQUIRE(((ldq | ldk | ldv | ldo | sq | sk | sv | so) & 3) == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
@@ -507,6 +548,7 @@ PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, c
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
     p.H = H; p.Lq = Lq; p.Lk = Lk;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.a_scale = a_scale; p.o_scale = o_scale; p.k1 = k1; p.k2 = k2;
     const dim3 grid((unsigned)psam_cdiv(Lq, FA_BQ), H, B), block(256);
     switch (hd) {
         case 64: hipLaunchKernelGGL((flash_attn_f16x3_kernel<64>), grid, block, 0, stream, p); break;
@@ -516,4 +558,10 @@ PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, c
             return PSAM_EINVAL;
     }
     return psam_launch_status("psam_attention_f16x3: launch failed");
+}
+
+PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                                      int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                                      float scale, hipStream_t stream) {
+    return psam_attention_f16x3_ex(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, B, H, Lq, Lk, hd, scale, nullptr, 0.f, 0.f, nullptr, stream);
 }

@@ -70,6 +70,7 @@ class PointCloudSAM:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
         self.precision = precision
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
+        self.fuse_attn_pack = True  # "f16x3": the attention kernel writes its output packed for the output projection (bound-derived scale)
         self.fuse_patch = True    # "f16x3": mini-PointNet hand-overs packed, max-pools in the GEMM epilogues (False = separate kernels)
         self.cfg = cfg
         self.device = torch.device(device)
@@ -148,6 +149,10 @@ class PointCloudSAM:
                     blk.w2g = ops.F16Weight(w2g.float().contiguous())
                     blk.k1 = float(2.0 ** 15 * math.sqrt(D) * blk.w1.double().norm(dim=1).max().item())
                     blk.k2 = float(blk.b1.abs().max().item())
+                # bound of |V| from the scale of the (LayerNorm) row that produced it: the attention kernel packs its output with it
+                wv = blk.wqkv[2 * D:].double()
+                blk.vk1 = float(2.0 ** 15 * math.sqrt(D) * wv.norm(dim=1).max().item())
+                blk.vk2 = float(blk.bqkv[2 * D:].abs().max().item())
                 for attr in ("wqkv", "w1", "w2"):
                     t = getattr(blk, attr)
                     if ops.F16Weight.eligible(*t.shape):
@@ -228,8 +233,13 @@ class PointCloudSAM:
         h = self._ln(p + ".norm1", x, vit.ln_eps, scale_out=rs, pack=pk)
         qkv = ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs, x_packed=pk)
         o = torch.empty_like(x)
-        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5)
-        self._lin(p + ".attn.proj", o, residual=x, out=x)
+        if pk and self.fuse_attn_pack and ops.attention_can_pack(hd) and D % 32 == 0 and (p + ".attn.proj.weight") in self.fw:
+            so = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)      # the attention kernel leaves its rows packed for proj
+            ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5, pack=(rs, blk.vk1, blk.vk2, so))
+            self._lin(p + ".attn.proj", o, residual=x, out=x, x_scale=so, x_packed=True)
+        else:
+            ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5)
+            self._lin(p + ".attn.proj", o, residual=x, out=x)
         self._ln(p + ".norm2", x, vit.ln_eps, out=h, scale_out=rs, pack=pk)
         if vit.swiglu:
             # fc1 with the SiLU gate fused in the GEMM epilogue -> u [M, Hp] (pad columns exactly 0), inner LayerNorm over

@@ -382,12 +382,25 @@ def swiglu_ln(gx, xoff, H, w, b, eps, out):
     return out
 
 
-def attention(q, k, v, out, B, H, Lq, Lk, hd, scale):
-    """q/k/v/out: 2-D row views [B*L, >=H*hd] (may be column slices of a fused qkv buffer)."""
+def attention_can_pack(hd: int) -> bool:
+    return GEMM_MODE == "f16x3" and hd in (64, 128)
+
+
+def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
+    """q/k/v/out: 2-D row views [B*L, >=H*hd] (may be column slices of a fused qkv buffer).
+    pack=(a_scale [B*Lk], k1, k2, o_scale [B*Lq]) ("f16x3", hd 64 / 128, self-attention): out receives the g8-packed rows for the output
+    projection and o_scale their (bound-derived, per-cloud) scales -- linear(out, W, x_scale=o_scale, x_packed=True)."""
     qp, ldq = _row_view(q, "q"); kp, ldk = _row_view(k, "k"); vp, ldv = _row_view(v, "v"); op, ldo = _row_view(out, "out")
     L = _lib.load()
+    args = (qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale)
+    if pack is not None:
+        if not attention_can_pack(hd):
+            raise ValueError("packed attention output needs the f16x3 kernel (head dim 64 or 128)")
+        a_scale, k1, k2, o_scale = pack
+        check(L.psam_attention_f16x3_ex(*args, a_scale.data_ptr(), float(k1), float(k2), o_scale.data_ptr(), _stream()), "psam_attention")
+        return out
     fn = L.psam_attention_f16x3 if (GEMM_MODE == "f16x3" and hd in (64, 128)) else L.psam_attention_f32
-    check(fn(qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale, _stream()), "psam_attention")
+    check(fn(*args, _stream()), "psam_attention")
     return out
 
 

@@ -96,6 +96,23 @@ def test_against_oracle(gpu, name, precision):
     assert _maxerr(masks2, want2) < TOL and _maxerr(iou2, want_iou2) < TOL, (_maxerr(masks2, want2), _maxerr(iou2, want_iou2))
 
 
+def test_attention_packed_output_is_transparent(gpu):
+    """Attention writing its output packed for the projection (bound-derived per-cloud scale) vs fp32 output + separate pack pass: a
+    power-of-two scale does not change the decoded hi + lo except where lo goes subnormal (elements ~2^-10 below the row maximum, since
+    the bound sits a few binades above the actual outputs): the model outputs agree to fp32 round-off."""
+    cfg = get_config("base", 128, 32)
+    sd = random_state_dict(cfg, seed=2)
+    xyz, rgb, prompt, labels = O.synthetic_batch(2, 4096, seed=6)
+    outs = []
+    for fuse in (True, False):
+        model = gpu(cfg, sd, precision="f16x3")
+        model.fuse_attn_pack = fuse
+        outs.append(model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda()))
+    e_m, e_i = _maxerr(outs[0][0], outs[1][0]), _maxerr(outs[0][1], outs[1][1])
+    print(f"\n[packed attention output vs fp32 + pack pass, ViT-B x12] max|diff| masks {e_m:.2e} iou {e_i:.2e}")
+    assert e_m < 5e-5 and e_i < 5e-5
+
+
 def test_fused_mlp_matches_unfused_model(gpu):
     """The two-GEMM MLP (inner LayerNorm folded into fc2, packed hand-over) vs the three-kernel sequence on a whole ViT-L stack."""
     cfg = get_config("large", 256, 32)

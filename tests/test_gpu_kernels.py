@@ -602,6 +602,32 @@ def test_flash_attention_f16x3(ops, hd, H, Lq, Lk):
     assert err < 2e-6 and err < 4 * err32 + 2e-7, (err, err32)
 
 
+@pytest.mark.parametrize("hd,H,L", [(64, 4, 512), (64, 2, 130), (128, 2, 200)])
+def test_flash_attention_f16x3_packed_output(ops, hd, H, L):
+    """Packed output of the fp16-split attention (for the output projection): decodes to the fp32 output's hi + lo (22 bits), one
+    power-of-two scale per cloud derived from the BOUND of |V|, never overflowing fp16."""
+    g = torch.Generator().manual_seed(hd + L)
+    B, D = 3, H * hd
+    qkv = (torch.randn(B * L, 3 * D, generator=g) * torch.exp(torch.randn(B * L, 1, generator=g))).cuda()
+    a_scale = torch.exp2(torch.randint(-3, 12, (B * L,), generator=g).float()).cuda()     # stand-in for the LayerNorm row scales
+    vmax = qkv[:, 2 * D:].abs().view(B, L * D).max(1).values
+    smin = a_scale.view(B, L).min(1).values
+    k2 = 0.25
+    k1 = float(((vmax - k2).clamp_min(0) * smin).max().item() * 1.5 + 1.0)               # any k1 with k1 / smin + k2 >= max|V| per cloud
+    assert (k1 / smin + k2 >= vmax).all()
+    with ops.gemm_mode("f16x3"):
+        want = torch.empty(B * L, D, device="cuda")
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], want, B, H, L, L, hd, hd ** -0.5)
+        got = torch.empty(B * L, D, device="cuda"); so = torch.empty(B * L, device="cuda")
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], got, B, H, L, L, hd, hd ** -0.5, pack=(a_scale, k1, k2, so))
+    assert (torch.log2(so) == torch.log2(so).round()).all()
+    assert torch.equal(so.view(B, L), so.view(B, L)[:, :1].expand(B, L)), "one scale per cloud"
+    assert (want.abs().view(B, L * D).max(1).values * so.view(B, L)[:, 0] < 2.0 ** 15).all()
+    # identical bits to packing the fp32 output with the same scales
+    ref = ops.pack_rows_g8(want, so)
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+
+
 def test_flash_attention_f16x3_spike(ops):
     g = torch.Generator().manual_seed(9)
     B, H, hd, L = 1, 1, 64, 256
