@@ -145,6 +145,10 @@ void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring con
  *              the columns < stat_cols; psam_ln_stats_finalize merges them (fixed order) into the LayerNorm's mean / rstd per row;
  *   gmax_*   : gmax_out [M / gmax_k, >= N] (row stride gmax_ld) = per-column maximum over every group of gmax_k (32 or 64) consecutive
  *              output rows -- PatchEncoder's max-pool over the group members (common.py:491,497); no_store: C is not written;
+ *   row_ln_* : (N == 256) LayerNorm over each output row before the activation -- Linear -> LayerNorm -> GELU of the decoder's upscaling
+ *              MLP (mask_decoder.py:53-59) in one epilogue (with pack_out pass out_k1 = 0, out_k2 >= sqrt(255) max|gamma| + max|beta|);
+ *   hyper    : (N == 256) masks[z, c, n] = <hyper[z, c, :], out[z * hyper_rows + n, :]>, c < hyper_c <= 4, hyper_rows % 32 == 0 -- the hyper-network product
+ *              of mask_decoder.py:171-176 taken from the rows as they are finished (with no_store the [rows, 256] output is not written);
  *   ln_*     : LayerNorm of the A rows folded into the GEMM: C = rstd[row] (A W'^T - mean[row] c[col]) + bias (+ residual), with the
  *              caller's W' = W * gamma (per column), c = W' 1, bias = W beta + b. */
 typedef struct {
@@ -152,6 +156,8 @@ typedef struct {
     float* stats; int32_t stat_cols;
     const float* ln_mean; const float* ln_rstd; const float* ln_c;
     float* gmax_out; int64_t gmax_ld; int32_t gmax_k; int32_t no_store;
+    const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
+    const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
 } psam_gemm_fuse_t;
 int32_t psam_gemm_f16x3p_stat_segs(int32_t N);
 int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C, int64_t ldc,
@@ -227,6 +233,9 @@ int32_t psam_add_bcast(const float* a, int64_t sa, int32_t rep, const float* b, 
  * pc_sam/model/common.py:258-274 (mask_decoder.py:163). */
 int32_t psam_interp3(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C,
                      psam_stream_t stream);
+/* scale_out [Z*N] != NULL (C == 256): out receives the g8-packed rows (A operand of psam_gemm_f16x3p) and scale_out their row scales. */
+int32_t psam_interp3_ex(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C,
+                        float* scale_out, psam_stream_t stream);
 
 #ifdef __cplusplus
 }

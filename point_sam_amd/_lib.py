@@ -58,6 +58,7 @@ SIGNATURES = {
     "psam_fourier_pe": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i64, ptr, ptr]),
     "psam_add_bcast": (i32, [ptr, i64, i32, ptr, i64, i64, ptr, i64, i64, i64, i32, ptr]),
     "psam_interp3": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr]),
+    "psam_interp3_ex": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr, ptr]),
 }
 
 
@@ -65,7 +66,8 @@ SIGNATURES = {
 class GemmFuse(ctypes.Structure):
     """psam_gemm_fuse_t (include/pointsam_hip.h)."""
     _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
-                ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32)]
+                ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
+                ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32)]
 
 
 _lib = None

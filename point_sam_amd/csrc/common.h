@@ -64,10 +64,32 @@ __device__ __forceinline__ void psam_split2_f16(float x0, float x1, float s, uns
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, psam_f16x2));
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// Reductions on the VALU's data-parallel-primitive path instead of ds_bpermute (an LDS round trip, ~100+ cycles per step, six steps for a
+// wave): quad_perm xor 1 / xor 2, row_half_mirror, row_mirror leave every lane of a 16-lane row with the row's result in four
+// few-cycle steps; the four rows are combined through v_readlane (SGPRs).  Whole wave must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v)); v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
     return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+    v = min(v, dpp_i32<DPP_XOR1>(v)); v = min(v, dpp_i32<DPP_XOR2>(v));
+    v = min(v, dpp_i32<DPP_HALF_MIRROR>(v)); v = min(v, dpp_i32<DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float wave_max(float v) {      // wave-uniform result
+    v = row16_max(v);
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    v = row16_min(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 // exact (erf) GELU, as torch.nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

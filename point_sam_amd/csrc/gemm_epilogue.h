@@ -43,6 +43,13 @@ __device__ __forceinline__ void ep_wave_sync() {
 //  * gmax_out / gmax_k: the max over every group of gmax_k (32 or 64) consecutive rows of the finished output, per column -> gmax_out
 //    [M / gmax_k, N] (PatchEncoder's max-pool over the group members, common.py:491,497); no_store: C itself is not written (when the
 //    pooled value is all the caller needs, the [M, N] activation never reaches HBM).
+//  * full-row wave tiles only (TN == 8: a wave owns whole 256-column rows -- the decoder's upscaling MLP, mask_decoder.py:53-59,171-176):
+//    row_ln_g / row_ln_b / row_ln_eps: LayerNorm over the output row BEFORE the activation (`Linear -> LayerNorm -> GELU` in one
+//    epilogue); hyper / masks: the C (<= 4) hyper-network dot products of every finished row, masks[z, c, n] = sum_e hyper[z, c, e]
+//    out[z * hyper_rows + n, e], so the [rows, 256] activation itself need not be stored (no_store).  Both are ROW passes over the
+//    staged stripe -- lane -> (row lane & 31, column half lane >> 5), 128 sequential columns per lane and ONE cross-lane exchange per
+//    row -- not per-row wave reductions: with one wave per SIMD (the 133 KiB tile) 32 dependent shuffle chains per stripe measured
+//    ~0.25 ms per GEMM, several times the K loop.
 //  * ln_mean / ln_rstd / ln_c: the LayerNorm of the A rows folded into this GEMM -- C = rstd[row] * (A W'^T - mean[row] * c[col]) + bias
 //    with W' = W * gamma (columns), c = W' 1, bias = W beta + b.
 template <int TM, int TN, bool SCALED = false, bool EXT = false, typename ArgsT>
@@ -66,6 +73,9 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     ep_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, m0 = {alpha, alpha, alpha, alpha}, m1 = m0;
     ep_f32x4 lnc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EXT) { if (interior && lane_on && p.ln_c) lnc = ep_load4(p.ln_c + pcol); }
+    constexpr bool FULLROW = EXT && TN == 8;
+    [[maybe_unused]] ep_f32x4 rg = {1.f, 1.f, 1.f, 1.f}, rbt = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FULLROW) { if (interior && p.row_ln_g) { rg = ep_load4(p.row_ln_g + pcol); rbt = ep_load4(p.row_ln_b + pcol); } }
     if (interior && lane_on) {
         if (p.bias) { b0 = ep_load4(p.bias + pcol); if (swiglu) b1 = ep_load4(p.bias + pcol + 32); }
         if constexpr (SCALED) {
@@ -84,6 +94,46 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
 #pragma unroll
             for (int r = 0; r < 16; ++r) lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + j * 32 + r32] = acc[i][j][r];
         ep_wave_sync();
+        [[maybe_unused]] float row_mean = 0.f, row_rstd = 1.f;      // of row (lane & 31) of this stripe (FULLROW, row_ln)
+        [[maybe_unused]] bool finalized = false;
+        if constexpr (FULLROW) {
+            if (interior && p.row_ln_g && !swiglu) {
+                // finish the stripe in place (un-scale, bias) and take each row's LayerNorm statistics, two-pass
+                float* rowp = lw + r32 * LD + h * (TN * 16);
+                const int colh = col_base + h * (TN * 16);
+                float rsr = 1.f;
+                if constexpr (SCALED) rsr = inv_pow2(p.scaleA[row_base + i * 32 + r32]);
+                float sm = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < TN * 4; ++c) {
+                    ep_f32x4 x = ep_load4(rowp + 4 * c);
+                    ep_f32x4 mm = {alpha, alpha, alpha, alpha}, bb = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (SCALED) {
+                        const ep_f32x4 sw = ep_load4(p.scaleW + colh + 4 * c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mm[e] *= inv_pow2(sw[e]);
+                    }
+                    if (p.bias) bb = ep_load4(p.bias + colh + 4 * c);
+                    x = x * rsr * mm + bb;
+                    *reinterpret_cast<ep_f32x4*>(rowp + 4 * c) = x;
+                    sm += (x[0] + x[1]) + (x[2] + x[3]);
+                }
+                sm += __shfl_xor(sm, 32, 64);
+                const float inv_n = 1.0f / (float)(TN * 32);
+                row_mean = sm * inv_n;
+                float qq = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < TN * 4; ++c) {
+                    const ep_f32x4 x = ep_load4(rowp + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = x[e] - row_mean; qq += d * d; }
+                }
+                qq += __shfl_xor(qq, 32, 64);
+                row_rstd = 1.0f / sqrtf(qq * inv_n + p.row_ln_eps);
+                finalized = true;
+                ep_wave_sync();
+            }
+        }
         if (interior) {
 #pragma unroll
             for (int q0 = 0; q0 < NPMAX; q0 += NB) {     // batches of NB passes: loads first, then arithmetic and stores
@@ -102,10 +152,12 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                         const int rl = (q0 + q) * rpp + rl0;
                         const int row = row_base + i * 32 + rl;
                         ep_f32x4 v = ep_load4(lw + rl * LD + scol);
-                        if constexpr (SCALED) v *= rs[q];
-                        if constexpr (EXT) {
-                            if (p.ln_c) { v = (v * m0 - lnc * p.ln_mean[row]) * p.ln_rstd[row] + b0; } else v = v * m0 + b0;
-                        } else v = v * m0 + b0;
+                        if (!finalized) {
+                            if constexpr (SCALED) v *= rs[q];
+                            if constexpr (EXT) {
+                                if (p.ln_c) { v = (v * m0 - lnc * p.ln_mean[row]) * p.ln_rstd[row] + b0; } else v = v * m0 + b0;
+                            } else v = v * m0 + b0;
+                        }
                         if (swiglu) {
                             ep_f32x4 x = ep_load4(lw + rl * LD + scol + 32);
                             if constexpr (SCALED) x *= rs[q];
@@ -133,11 +185,20 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             }
                         } else {
                             if (p.rowbias) v += rb[q];
+                            if constexpr (FULLROW) {
+                                if (finalized) {      // LayerNorm over the 256 columns of this row (rpp == 1: row rl is wave-uniform)
+                                    const float mean = __shfl(row_mean, rl, 64), rr = __shfl(row_rstd, rl, 64);
+                                    v = (v - mean) * rr * rg + rbt;
+                                }
+                            }
                             if (p.act == 1) v = ep_f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
                             else if (p.act == 2) v = ep_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                             if (R) v += res[q];
                             if constexpr (EXT) {
                                 if (p.gmax_out) gm = ep_f32x4{fmaxf(gm[0], v[0]), fmaxf(gm[1], v[1]), fmaxf(gm[2], v[2]), fmaxf(gm[3], v[3])};
+                            }
+                            if constexpr (FULLROW) {
+                                if (p.hyper) *reinterpret_cast<ep_f32x4*>(lw + rl * LD + scol) = v;      // finished value back in place for the row pass below
                             }
                         }
                         bool stored = false;
@@ -158,6 +219,30 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                         }
                         if constexpr (EXT) { if (p.no_store) stored = true; }
                         if (!stored) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
+                    }
+                }
+            }
+            if constexpr (FULLROW) {
+                if (p.hyper && !swiglu) {      // hyper-network dot products of the stripe's finished rows (hyper_rows % 32 == 0: one z per stripe)
+                    ep_wave_sync();
+                    const int row0 = row_base + i * 32, z = row0 / p.hyper_rows, n0 = row0 - z * p.hyper_rows;
+                    const float* rowp = lw + r32 * LD + h * (TN * 16);
+                    const float* hb = p.hyper + (int64_t)z * p.hyper_c * (TN * 32) + h * (TN * 16);
+                    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                    for (int c = 0; c < TN * 4; ++c) {
+                        const ep_f32x4 x = ep_load4(rowp + 4 * c);
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+                            if (cc < p.hyper_c) {
+                                const ep_f32x4 hv = ep_load4(hb + cc * (TN * 32) + 4 * c);
+                                dot[cc] += (x[0] * hv[0] + x[1] * hv[1]) + (x[2] * hv[2] + x[3] * hv[3]);
+                            }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        dot[cc] += __shfl_xor(dot[cc], 32, 64);
+                        if (cc < p.hyper_c && h == 0) p.masks[((int64_t)z * p.hyper_c + cc) * p.hyper_rows + n0 + r32] = dot[cc];
                     }
                 }
             }

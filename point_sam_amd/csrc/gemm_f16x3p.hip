@@ -43,6 +43,8 @@ struct F16PArgs {
     float* stats; int stat_cols, stat_segs;
     const float* ln_mean; const float* ln_rstd; const float* ln_c;
     float* gmax_out; int64_t gmax_ld; int gmax_k, no_store;
+    const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
+    const float* hyper; float* masks; int hyper_c, hyper_rows;
 };
 
 #define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
@@ -454,6 +456,10 @@ struct psam_gemm_fuse_t {
     float* stats; int32_t stat_cols;                                // LayerNorm partials of the SwiGLU-gated rows: [M, segs, 2]
     const float* ln_mean; const float* ln_rstd; const float* ln_c;  // LayerNorm of the A rows folded into this GEMM
     float* gmax_out; int64_t gmax_ld; int32_t gmax_k; int32_t no_store;   // per-column max over groups of gmax_k (32 | 64) rows; C not written
+    // N == 256 only (a wave owns whole rows): LayerNorm of the output row before the activation;
+    // hyper-network dot products masks[z, c, n] = <hyper[z, c, :], out[z * hyper_rows + n, :]> (c < hyper_c <= 4)
+    const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
+    const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
 };
 
 // segments (of 32 gated columns) per row of the stats buffer of a SwiGLU GEMM with N packed weight rows
@@ -480,8 +486,26 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
+    p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
+    if (fuse && (fuse->row_ln_g || fuse->hyper)) {
+        // full-row epilogues: a wave owns whole rows of N == 256 columns (128x256 tiles, four waves of 32 rows)
+        PSAM_REQUIRE(N == 256 && (M & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm / hyper products need N == 256, M % 128 == 0");
+        PSAM_REQUIRE(!fuse->stats && !fuse->ln_c && !fuse->gmax_out, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row epilogues do not combine with stats / folded LN / group max");
+        PSAM_REQUIRE(!fuse->row_ln_g || fuse->row_ln_b, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm needs gamma and beta");
+        PSAM_REQUIRE(!fuse->hyper || (fuse->masks && fuse->hyper_c > 0 && fuse->hyper_c <= 4 && fuse->hyper_rows > 0), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: hyper products need masks, 1 <= hyper_c <= 4, hyper_rows > 0");
+        PSAM_REQUIRE(!fuse->pack_out || (fuse->out_scale && (ldc & 7) == 0 && ((uintptr_t)C & 31) == 0), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: packed output needs out_scale and 32-byte aligned output rows");
+        PSAM_REQUIRE(!fuse->hyper || fuse->hyper_rows % 32 == 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: hyper_rows must be a multiple of 32");
+        PSAM_REQUIRE(!fuse->no_store || fuse->hyper, PSAM_EINVAL, "psam_gemm_f16x3p_ex: no_store needs an epilogue product that keeps the result");
+        PSAM_REQUIRE((((uintptr_t)fuse->row_ln_g | (uintptr_t)fuse->row_ln_b | (uintptr_t)fuse->hyper) & 15) == 0, PSAM_EALIGN, "psam_gemm_f16x3p_ex: 16-byte alignment");
+        p.row_ln_g = fuse->row_ln_g; p.row_ln_b = fuse->row_ln_b; p.row_ln_eps = fuse->row_ln_eps;
+        p.hyper = fuse->hyper; p.masks = fuse->masks; p.hyper_c = fuse->hyper_c; p.hyper_rows = fuse->hyper_rows;
+        p.pack_out = fuse->pack_out; p.out_scale = fuse->out_scale; p.out_k1 = fuse->out_k1; p.out_k2 = fuse->out_k2; p.no_store = fuse->no_store;
+        return launch_f16x3p<4, 1, 1, 8, 2, 0, 0, 2>(p, stream);
+    }
     if (fuse && (fuse->pack_out || fuse->stats || fuse->ln_c || fuse->gmax_out)) {
         // The fused epilogue paths exist for interior tiles of the two-tile-wide wave tiles only: whole 256-row / 128-column tiles.
         PSAM_REQUIRE((M & 255) == 0 && (N & 127) == 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: fused extras need M % 256 == 0 and N % 128 == 0");
@@ -526,6 +550,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         case 21: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 4 waves, mid-slab stage release
         case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);     // 256x192, mid-slab stage release
         case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 8 waves of 32x64, 2 stages, mid-slab release (70 KiB): 2 per CU
+        case 40: return launch_f16x3p<4, 1, 1, 8, 2, 0, 0, 2>(p, stream);     // 128x256, 4 waves of 32x256 (whole rows per wave: row epilogues), 133 KiB
         default: break;
     }
     psam_set_error("psam_gemm_f16x3p: unknown config");

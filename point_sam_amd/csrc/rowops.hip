@@ -433,7 +433,7 @@ PSAM_API int32_t psam_add_bcast(const float* a, int64_t sa, int32_t rep, const f
 // One wave per point, float4 per lane (C == 256).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx3, const float* __restrict__ w3,
-                                                      float* __restrict__ out, int rep, int64_t Z, int N, int G, int C) {
+                                                      float* __restrict__ out, int rep, int64_t Z, int N, int G, int C, float* __restrict__ scale_out) {
     const int lane = threadIdx.x & 63;
     const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wv >= Z * N) return;
@@ -450,16 +450,35 @@ __global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ 
         f32x4 v = a * w0;
         v = v + bb * w1;
         v = v + cc * w2;
-        *reinterpret_cast<f32x4*>(out + (z * N + n) * C + c) = v;
+        if (scale_out) {      // C == 256 (host-checked): the whole row is in this wave -> g8-packed row + its scale (gemm_f16x3p.hip)
+            const float sc = f16_row_scale(wave_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
+            if (lane == 0) scale_out[z * N + n] = sc;
+            unsigned h0, l0, h1, l1;
+            psam_split2_f16(v[0], v[1], sc, h0, l0);
+            psam_split2_f16(v[2], v[3], sc, h1, l1);
+            const bool odd = lane & 1;
+            const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+            typedef unsigned ip_u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<ip_u32x4*>(out + (z * N + n) * C + c) = odd ? ip_u32x4{r0, r1, l0, l1} : ip_u32x4{h0, h1, r0, r1};
+        } else {
+            *reinterpret_cast<f32x4*>(out + (z * N + n) * C + c) = v;
+        }
     }
+}
+
+// scale_out [Z*N] != NULL (C == 256 only): out receives the g8-packed rows (A operand of psam_gemm_f16x3p) and scale_out their scales.
+PSAM_API int32_t psam_interp3_ex(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G,
+                                 int32_t C, float* scale_out, hipStream_t stream) {
+    PSAM_REQUIRE(src && idx3 && w3 && out && rep > 0 && Z > 0 && N > 0 && G > 0 && C > 0, PSAM_EINVAL, "psam_interp3: bad argument");
+    PSAM_REQUIRE((C & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0, PSAM_EALIGN, "psam_interp3: C % 4 and 16B alignment");
+    PSAM_REQUIRE(!scale_out || (C == 256 && ((uintptr_t)out & 31) == 0), PSAM_EINVAL, "psam_interp3: packed output needs C == 256 and 32-byte aligned rows");
+    hipLaunchKernelGGL(interp3_kernel, dim3((unsigned)psam_cdiv(Z * N, 4)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, C, scale_out);
+    return psam_launch_status("psam_interp3: launch failed");
 }
 
 PSAM_API int32_t psam_interp3(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G,
                               int32_t C, hipStream_t stream) {
-    PSAM_REQUIRE(src && idx3 && w3 && out && rep > 0 && Z > 0 && N > 0 && G > 0 && C > 0, PSAM_EINVAL, "psam_interp3: bad argument");
-    PSAM_REQUIRE((C & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0, PSAM_EALIGN, "psam_interp3: C % 4 and 16B alignment");
-    hipLaunchKernelGGL(interp3_kernel, dim3((unsigned)psam_cdiv(Z * N, 4)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, C);
-    return psam_launch_status("psam_interp3: launch failed");
+    return psam_interp3_ex(src, idx3, w3, out, rep, Z, N, G, C, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -48,6 +48,24 @@ __global__ void fps_soa_kernel(const float* __restrict__ xyz, int N, int64_t npa
 // hold a 32768-point cloud (512 KiB of state), so an iteration touches no memory besides the 12-byte winner broadcast.
 // (SG = groups that would not fit and are re-read from L2 each iteration; 0 for every instantiated size.)
 // PPT4 == 0: any N, min-distances and coordinates streamed from the workspace (L2-resident).
+// x - c for four points as two packed subtractions (v_pk_add_f32 with the negate modifier on the SGPR-pair operand; a + (-c) is
+// a - c bit for bit).  Written as asm because the compiler keeps subtractions of a scalar as four v_sub_f32.
+typedef float fps_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 fps_sub_bcast(const f32x4 a, const fps_f32x2 c) {
+    fps_f32x2 lo = {a.x, a.y}, hi = {a.z, a.w}, rl, rh;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rl) : "v"(lo), "s"(c));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rh) : "v"(hi), "s"(c));
+    return f32x4{rl.x, rl.y, rh.x, rh.y};
+}
+
+// fminf() costs a second instruction per call (v_max_f32 x, x, x: NaN quieting of an operand the compiler cannot prove canonical);
+// coordinates are finite by contract (the distances are then never NaN), so the bare v_min_f32 gives the same bits.
+__device__ __forceinline__ float fps_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int PPT4>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, const float* __restrict__ soa,
                                                           float* __restrict__ mdg, int N, int64_t npad, int G,
@@ -111,11 +129,96 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     if (tid == 0) idx_out[(int64_t)b * G] = 0;
     if (tid < 3) centers_out[(int64_t)b * G * 3 + tid] = P[tid];
 
+    if constexpr (PPT4 > 0) {
+        // On-chip cloud.  An iteration is (a) the scan: 5.5 VALU instructions per point -- packed fp32 subtract / multiply / add (v_pk_*,
+        // two points per instruction, every operation individually rounded: the same bits as dist2_exact), one min per point, one
+        // v_max3 per two points for the thread's maximum VALUE only; (b) the maximum over the workgroup (wave reduction, LDS, barrier);
+        // (c) the index: only the lanes that hold the maximum look for its lowest slot, the lowest global index among them wins (wave
+        // minimum, then the minimum over the waves' records), and that lane publishes index AND coordinates from its own registers /
+        // LDS slots -- the next iteration starts from LDS instead of a dependent load through L2.
+        // (The earlier form carried (value, slot) through the scan at 12 instructions per point and fetched P[last] from memory.)
+        __shared__ float s_wmax[2][FPS_WAVES];
+        __shared__ int s_ci[2][FPS_WAVES];                                      // each wave's candidate: index, coordinates
+        __shared__ float s_cxyz[2][3][FPS_WAVES];
+        float cx = P[0], cy = P[1], cz = P[2];
+        for (int j = 1; j < G; ++j) {
+            float best = -1.0f;
+            const fps_f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};      // wave-uniform: SGPR pairs
+            auto visit = [&](f32x4& m, const f32x4 x, const f32x4 y, const f32x4 z) {
+                const f32x4 dx = fps_sub_bcast(x, c2x), dy = fps_sub_bcast(y, c2y), dz = fps_sub_bcast(z, c2z);
+                const f32x4 d = (dx * dx + dy * dy) + dz * dz;      // -ffp-contract=off: no FMA, each op rounded (dist2_exact)
+                m = f32x4{fps_min(m.x, d.x), fps_min(m.y, d.y), fps_min(m.z, d.z), fps_min(m.w, d.w)};
+                best = fmaxf(fmaxf(best, m.x), m.y);
+                best = fmaxf(fmaxf(best, m.z), m.w);
+            };
+            f32x4 sx, sy, sz;
+            if (SG > 0) { sx = gload(RG + LG, 0); sy = gload(RG + LG, 1); sz = gload(RG + LG, 2); }
+#pragma unroll
+            for (int g = 0; g < RG; ++g) visit(md[g], rx[g], ry[g], rz[g]);
+#pragma unroll
+            for (int g = 0; g < LG; ++g) {
+                __builtin_amdgcn_sched_barrier(0);  // one LDS group (12 VGPRs) in flight at a time: the register file is full
+                visit(md[RG + g], s_xyz[(g * 3 + 0) * FPS_THREADS + tid], s_xyz[(g * 3 + 1) * FPS_THREADS + tid], s_xyz[(g * 3 + 2) * FPS_THREADS + tid]);
+            }
+            if (SG > 0) visit(md[RG + LG], sx, sy, sz);
+            // (b) maximum value over the workgroup
+            const int slot = j & 1;
+            const float wmax = wave_max(best);
+            if (lane == 0) s_wmax[slot][wave] = wmax;
+            __syncthreads();
+            static_assert(FPS_WAVES == 16, "one 16-lane row holds the waves' partial results");
+            const float gmax = row16_max(s_wmax[slot][lane & 15]);
+            // (c) lowest index holding it
+            const bool mine = best == gmax;
+            if (__builtin_amdgcn_ballot_w64(mine) != 0) {      // wave-uniform
+                int cand = 0x7fffffff, bslot = 0;
+                if (mine) {
+#pragma unroll
+                    for (int g = NREG - 1; g >= 0; --g) {      // descending: the lowest slot is assigned last
+                        if (md[g].w == gmax) bslot = 4 * g + 3;
+                        if (md[g].z == gmax) bslot = 4 * g + 2;
+                        if (md[g].y == gmax) bslot = 4 * g + 1;
+                        if (md[g].x == gmax) bslot = 4 * g;
+                    }
+                    cand = ((bslot >> 2) * FPS_THREADS + tid) * 4 + (bslot & 3);
+                }
+                const int wmin = wave_min_dpp(cand);
+                if (mine && cand == wmin) {                     // one lane: global indices are unique
+                    const int g = bslot >> 2, k = bslot & 3;
+                    f32x4 X, Y, Z;
+                    if (g < RG) {
+                        X = rx[0]; Y = ry[0]; Z = rz[0];
+#pragma unroll
+                        for (int gg = 1; gg < RG; ++gg)
+                            if (g == gg) { X = rx[gg]; Y = ry[gg]; Z = rz[gg]; }
+                    } else if (g < RG + LG) {
+                        X = s_xyz[((g - RG) * 3 + 0) * FPS_THREADS + tid]; Y = s_xyz[((g - RG) * 3 + 1) * FPS_THREADS + tid];
+                        Z = s_xyz[((g - RG) * 3 + 2) * FPS_THREADS + tid];
+                    } else { X = gload(g, 0); Y = gload(g, 1); Z = gload(g, 2); }
+                    const float px = k == 0 ? X.x : (k == 1 ? X.y : (k == 2 ? X.z : X.w));
+                    const float py = k == 0 ? Y.x : (k == 1 ? Y.y : (k == 2 ? Y.z : Y.w));
+                    const float pz = k == 0 ? Z.x : (k == 1 ? Z.y : (k == 2 ? Z.z : Z.w));
+                    s_ci[slot][wave] = cand;
+                    s_cxyz[slot][0][wave] = px; s_cxyz[slot][1][wave] = py; s_cxyz[slot][2][wave] = pz;
+                }
+            } else if (lane == 0) {
+                s_ci[slot][wave] = 0x7fffffff;
+            }
+            __syncthreads();
+            last = __builtin_amdgcn_readfirstlane(row16_min(s_ci[slot][lane & 15]));
+            const int wwin = ((last >> 2) & (FPS_THREADS - 1)) >> 6;      // the wave that owns point `last`
+            cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_cxyz[slot][0][wwin])));
+            cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_cxyz[slot][1][wwin])));
+            cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_cxyz[slot][2][wwin])));
+            if (tid == 0) idx_out[(int64_t)b * G + j] = last;
+            if (tid < 3) centers_out[((int64_t)b * G + j) * 3 + tid] = tid == 0 ? cx : (tid == 1 ? cy : cz);
+        }
+        return;
+    }
+
     for (int j = 1; j < G; ++j) {
         const float cx = P[(int64_t)last * 3 + 0], cy = P[(int64_t)last * 3 + 1], cz = P[(int64_t)last * 3 + 2];
         float best = -1.0f;
-        // The winner is tracked as a slot number 4*g+k (an inline constant per compare -- per-point global indices would
-        // cost one loop-invariant VGPR each, 32 of the 128 available); the global index is rebuilt once after the scan.
         int bslot = -1;
         auto visit = [&](f32x4& m, const f32x4 x, const f32x4 y, const f32x4 z, int g) {
             float d;
@@ -124,29 +227,12 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
             d = dist2_exact(x.z, y.z, z.z, cx, cy, cz); m.z = fminf(m.z, d); if (m.z > best) { best = m.z; bslot = 4 * g + 2; }
             d = dist2_exact(x.w, y.w, z.w, cx, cy, cz); m.w = fminf(m.w, d); if (m.w > best) { best = m.w; bslot = 4 * g + 3; }
         };
-        if (PPT4 > 0) {
-            // ascending point index within the thread (register groups, LDS groups, streamed group) keeps "first maximum"
-            f32x4 sx, sy, sz;
-            if (SG > 0) { sx = gload(RG + LG, 0); sy = gload(RG + LG, 1); sz = gload(RG + LG, 2); }
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                visit(md[g], rx[g], ry[g], rz[g], g);
-                if (PPT4 > 5) __builtin_amdgcn_sched_barrier(0);  // bound the scheduler's live temporaries (4 waves/SIMD hide latency)
-            }
-#pragma unroll
-            for (int g = 0; g < LG; ++g) {
-                __builtin_amdgcn_sched_barrier(0);  // one LDS group (12 VGPRs) in flight at a time: the register file is full
-                visit(md[RG + g], s_xyz[(g * 3 + 0) * FPS_THREADS + tid], s_xyz[(g * 3 + 1) * FPS_THREADS + tid],
-                      s_xyz[(g * 3 + 2) * FPS_THREADS + tid], RG + g);
-            }
-            if (SG > 0) visit(md[RG + LG], sx, sy, sz, RG + LG);
-        } else {
-            for (int g = 0; g < ngroups; ++g) {
-                float4 m4 = MD4[g * FPS_THREADS + tid];
-                f32x4 m = {m4.x, m4.y, m4.z, m4.w};
-                visit(m, gload(g, 0), gload(g, 1), gload(g, 2), g);
-                MD4[g * FPS_THREADS + tid] = make_float4(m.x, m.y, m.z, m.w);
-            }
+        // any N: min-distances and coordinates streamed from the (L2-resident) workspace
+        for (int g = 0; g < ngroups; ++g) {
+            float4 m4 = MD4[g * FPS_THREADS + tid];
+            f32x4 m = {m4.x, m4.y, m4.z, m4.w};
+            visit(m, gload(g, 0), gload(g, 1), gload(g, 2), g);
+            MD4[g * FPS_THREADS + tid] = make_float4(m.x, m.y, m.z, m.w);
         }
         int besti = bslot < 0 ? 0x7fffffff : ((bslot >> 2) * FPS_THREADS + tid) * 4 + (bslot & 3);
         // wave arg-max, lowest index on ties

@@ -71,6 +71,11 @@ class PointCloudSAM:
         self.precision = precision
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
         self.fuse_attn_pack = True  # "f16x3": the attention kernel writes its output packed for the output projection (bound-derived scale)
+        self.fuse_upscale = True  # "f16x3": the 3-NN interpolation hands its rows to the upscaling MLP packed (no pack pass)
+        # "f16x3": the upscaling MLP's LayerNorm/GELU and the hyper-network products inside two full-row GEMM epilogues.  Parity-tested,
+        # but OFF: the 128x256 one-wave-per-SIMD tile it needs runs 383 us against 188 us for the 128x128 tile at [262144, 256, 256],
+        # so the chain measured 1146 us fused against 853 us (scripts/exp/upscale_bench.py, profiles/r02_upscale_chain.log).
+        self.fuse_upscale_rows = False
         self.fuse_patch = True    # "f16x3": mini-PointNet hand-overs packed, max-pools in the GEMM epilogues (False = separate kernels)
         self.cfg = cfg
         self.device = torch.device(device)
@@ -127,6 +132,7 @@ class PointCloudSAM:
                 if name.endswith(".weight") and t.dim() == 2 and ops.F16Weight.eligible(*t.shape) and not name.startswith("pc_encoder.transformer."):
                     self.fw[name] = ops.F16Weight(t)
             self.pe_bound = {}
+            self.up_ln_bound = ops.row_ln_bound(w["mask_decoder.output_upscaling.1.weight"], w["mask_decoder.output_upscaling.1.bias"])
             for prefix in ("pc_encoder.patch_embed.patch_encoder", "mask_encoder.patch_encoder"):   # cat([max, x]) @ W^T as two GEMMs
                 w13 = w[prefix + ".conv1.3.weight"]     # bound of |conv1.3 row| from the scale of its (packed) input row: see psam_gemm_fuse_t
                 self.pe_bound[prefix] = (float(2.0 ** 15 * math.sqrt(w13.shape[1]) * w13.double().norm(dim=1).max().item()),
@@ -405,19 +411,39 @@ class PointCloudSAM:
         # upscale: 3-NN interpolation G -> N, MLP, hyper-network dot product    (mask_decoder.py:146-176)
         if st.interp_index is None:
             st.interp_index, st.interp_weight = ops.three_nn(st.coords, st.centers)
-        up = torch.empty(Z * N, E, device=self.device)
-        ops.interp3(keys.view(Z, G, E), st.interp_index, st.interp_weight, up, rep)
-        u1 = self._lin("mask_decoder.output_upscaling.0", up)
-        pk, rs = self._ln_feeds_gemm(u1, "mask_decoder.output_upscaling.3")
-        self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1, scale_out=rs, pack=pk)
-        self._lin("mask_decoder.output_upscaling.3", u1, act=ACT_GELU, out=up, x_scale=rs, x_packed=pk)
         sel = list(range(1, nmt)) if multimask_output else [0]
         C = len(sel)
         hyper = torch.empty(Z, C, E, device=self.device)
         for j, i in enumerate(sel):
             self._mlp3(f"mask_decoder.output_hypernetworks_mlps.{i}", hs[:, 1 + i, :], out=hyper[:, j, :])
         masks = torch.empty(Z, C, N, device=self.device)
-        ops.gemm_batched(hyper, up, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
+        up = torch.empty(Z * N, E, device=self.device)
+        U0, U3 = "mask_decoder.output_upscaling.0", "mask_decoder.output_upscaling.3"
+        packed_interp = self.precision == "f16x3" and self.fuse_upscale and E == 256 and Z * N >= ops.SPLIT_MIN_M and (U0 + ".weight") in self.fw
+        if packed_interp and self.fuse_upscale_rows and (Z * N) % 128 == 0 and N % 32 == 0 and C <= 4 and (U3 + ".weight") in self.fw:
+            # interpolation -> Linear -> LayerNorm -> GELU -> Linear -> GELU -> hyper-network products as THREE kernels: the interpolated
+            # rows leave packed, the first GEMM's epilogue normalises / activates / re-packs whole rows (a wave owns a 256-column row;
+            # packed against the LayerNorm's a-priori bound),
+            # the second one's takes the C dot products per row: only the [Z, C, N] logits are written after the first GEMM.
+            s_up = torch.empty(Z * N, dtype=torch.float32, device=self.device)
+            ops.interp3(keys.view(Z, G, E), st.interp_index, st.interp_weight, up, rep, scale_out=s_up)
+            u1 = torch.empty(Z * N, E, device=self.device)
+            s1 = torch.empty(Z * N, dtype=torch.float32, device=self.device)
+            self._lin(U0, up, x_scale=s_up, x_packed=True, out=u1, act=ACT_GELU, pack_out=(s1, 0.0, self.up_ln_bound),
+                      row_ln=(w["mask_decoder.output_upscaling.1.weight"], w["mask_decoder.output_upscaling.1.bias"], cfg.ln_eps))
+            self._lin(U3, u1, x_scale=s1, x_packed=True, act=ACT_GELU, hyper=(hyper, masks, N), no_store=True)
+        else:
+            if packed_interp:
+                s_up = torch.empty(Z * N, dtype=torch.float32, device=self.device)
+                ops.interp3(keys.view(Z, G, E), st.interp_index, st.interp_weight, up, rep, scale_out=s_up)
+                u1 = self._lin(U0, up, x_scale=s_up, x_packed=True)
+            else:
+                ops.interp3(keys.view(Z, G, E), st.interp_index, st.interp_weight, up, rep)
+                u1 = self._lin(U0, up)
+            pk, rs = self._ln_feeds_gemm(u1, U3)
+            self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1, scale_out=rs, pack=pk)
+            self._lin(U3, u1, act=ACT_GELU, out=up, x_scale=rs, x_packed=pk)
+            ops.gemm_batched(hyper, up, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
         iou = self._mlp3("mask_decoder.iou_prediction_head", hs[:, 0, :])
         return masks, iou[:, sel[0]:sel[-1] + 1]
 

@@ -268,6 +268,13 @@ def fuse_supported(M: int, N: int) -> bool:
     return M % 256 == 0 and N % 128 == 0
 
 
+def row_ln_bound(gamma, beta) -> float:
+    """Bound on |LayerNorm(x) * gamma + beta| over a row of len(gamma) columns: a normalised element is at most sqrt(n - 1).
+    (GELU / ReLU after it only shrink magnitudes.)  The k2 of a packed output behind a row-LayerNorm epilogue."""
+    n = gamma.numel()
+    return float((n - 1) ** 0.5 * gamma.abs().max().item() + beta.abs().max().item())
+
+
 def stat_segs(N: int) -> int:
     return (N // 2 + 31) // 32
 
@@ -282,7 +289,7 @@ def ln_stats_finalize(stats, cols, eps):
 
 
 def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None, rowgroup=0, K=None, x_scale=None, x_packed=False,
-           pack_out=None, stats=None, ln_fold=None, group_max_out=None, group_max_k=0, no_store=False):
+           pack_out=None, stats=None, ln_fold=None, group_max_out=None, group_max_k=0, no_store=False, row_ln=None, hyper=None):
     """y = act(x @ W[:, :K]^T + bias + rowbias[row // rowgroup]) + residual.  x [M,>=K], W [N,>=K] row views, or W an F16Weight
     (prepared static weight).
     "f16x3" mode with an F16Weight and M above the threshold runs the packed-operand GEMM (csrc/gemm_f16x3p.hip): x is either already
@@ -291,7 +298,9 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
     pack_out=(scale_out [M], k1, k2): `out` receives g8-packed rows + their bound-derived scales; stats=(buf [M, stat_segs(N), 2], cols):
     LayerNorm partials of the SwiGLU-gated rows; ln_fold=(mean [M], rstd [M], c [N]): LayerNorm of x folded into the GEMM;
     group_max_out [M / group_max_k, N] (group_max_k 32 | 64): per-column max over consecutive row groups of the output, no_store: the
-    [M, N] output itself is not written (out may then be None)."""
+    [M, N] output itself is not written (out may then be None).  N == 256 only: row_ln=(gamma, beta, eps): LayerNorm of every output
+    row before the activation (with pack_out pass k1 = 0, k2 = row_ln_bound(gamma, beta));
+    hyper=(hyper [Z, C, 256], masks [Z, C, rows_per_z], rows_per_z): masks[z, c, n] = <hyper[z, c], out[z * rows_per_z + n]>."""
     fw = None
     if isinstance(W, F16Weight):
         fw, W = W, W.fp32
@@ -304,9 +313,9 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         assert x_packed or x.shape[1] == K, (x.shape, W.shape)
     elif fw is not None and K != fw.K:
         fw = None
-    fused = pack_out is not None or stats is not None or ln_fold is not None or group_max_out is not None
-    if no_store and group_max_out is not None and out is None:
-        op, ldo = group_max_out.data_ptr(), N       # never dereferenced
+    fused = pack_out is not None or stats is not None or ln_fold is not None or group_max_out is not None or row_ln is not None or hyper is not None
+    if no_store and (group_max_out is not None or hyper is not None) and out is None:
+        op, ldo = (group_max_out if group_max_out is not None else hyper[1]).data_ptr(), N       # never dereferenced
     else:
         if out is None:
             out = torch.empty(M, N // 2 if act == ACT_SWIGLU else N, dtype=torch.float32, device=x.device)
@@ -323,8 +332,16 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         fuse = None
         if fused:
             fuse = _lib.GemmFuse()
+            fuse.no_store = int(bool(no_store))
             if group_max_out is not None:
-                fuse.gmax_out, fuse.gmax_ld, fuse.gmax_k, fuse.no_store = group_max_out.data_ptr(), group_max_out.stride(0), int(group_max_k), int(bool(no_store))
+                fuse.gmax_out, fuse.gmax_ld, fuse.gmax_k = group_max_out.data_ptr(), group_max_out.stride(0), int(group_max_k)
+            if row_ln is not None:
+                fuse.row_ln_g, fuse.row_ln_b, fuse.row_ln_eps = row_ln[0].data_ptr(), row_ln[1].data_ptr(), float(row_ln[2])
+            if hyper is not None:
+                hy, mk, rpz = hyper
+                if not (hy.is_contiguous() and mk.is_contiguous() and hy.shape[-1] == N and mk.shape[:2] == hy.shape[:2] and mk.shape[2] == rpz):
+                    raise ValueError("hyper [Z, C, N] / masks [Z, C, rows_per_z] must be contiguous and consistent")
+                fuse.hyper, fuse.masks, fuse.hyper_c, fuse.hyper_rows = hy.data_ptr(), mk.data_ptr(), int(hy.shape[1]), int(rpz)
             if pack_out is not None:
                 fuse.out_scale, fuse.out_k1, fuse.out_k2, fuse.pack_out = pack_out[0].data_ptr(), float(pack_out[1]), float(pack_out[2]), 1
             if stats is not None:
@@ -445,11 +462,11 @@ def add_bcast(a, rep, b, out, Z, R, C, sa=None, sb=None, ldb=None, so=None):
     return out
 
 
-def interp3(src, idx3, w3, out, rep):
-    """src [Z,G,C], idx3/w3 [B,N,3] -> out [Z,N,C]."""
+def interp3(src, idx3, w3, out, rep, scale_out=None):
+    """src [Z,G,C], idx3/w3 [B,N,3] -> out [Z,N,C]; scale_out [Z*N] (C == 256): out receives the g8-packed rows + their scales."""
     Z, G, C = src.shape
     N = idx3.shape[1]
-    check(_lib.load().psam_interp3(src.data_ptr(), idx3.data_ptr(), w3.data_ptr(), out.data_ptr(), rep, Z, N, G, C, _stream()), "psam_interp3")
+    check(_lib.load().psam_interp3_ex(src.data_ptr(), idx3.data_ptr(), w3.data_ptr(), out.data_ptr(), rep, Z, N, G, C, _p(scale_out), _stream()), "psam_interp3")
     return out
 
 

@@ -113,6 +113,26 @@ def test_attention_packed_output_is_transparent(gpu):
     assert e_m < 5e-5 and e_i < 5e-5
 
 
+def test_fused_upscaling_matches_unfused(gpu):
+    """Decoder upscaling chain with the packed interpolation hand-over, and in three kernels (+ row LayerNorm + GELU + re-pack and the
+    hyper-network products in GEMM epilogues), vs the six-kernel sequence; multimask and single-mask outputs."""
+    cfg = get_config("tiny", 64, 16)
+    sd = random_state_dict(cfg, seed=8)
+    xyz, rgb, prompt, labels = O.synthetic_batch(2, 4096, seed=5)
+    outs = []
+    for fuse, rows in ((False, False), (True, False), (True, True)):
+        model = gpu(cfg, sd, precision="f16x3")
+        model.fuse_upscale, model.fuse_upscale_rows = fuse, rows
+        st = model.encode(xyz.cuda(), rgb.cuda())
+        m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+        m2, i2 = model.decode(st, prompt.cuda(), labels.cuda(), m1[:, 1].contiguous(), False)
+        outs.append((m1, i1, m2, i2))
+    for tag, got in (("packed interpolation", outs[1]), ("row epilogues", outs[2])):
+        e = [_maxerr(a, b) for a, b in zip(outs[0], got)]
+        print(f"\n[upscaling: {tag} vs unfused] max|diff| masks {e[0]:.2e} iou {e[1]:.2e} click-2 masks {e[2]:.2e}")
+        assert max(e) < 5e-5, e
+
+
 def test_fused_mlp_matches_unfused_model(gpu):
     """The two-GEMM MLP (inner LayerNorm folded into fc2, packed hand-over) vs the three-kernel sequence on a whole ViT-L stack."""
     cfg = get_config("large", 256, 32)

@@ -452,6 +452,39 @@ def test_fused_mlp_two_gemms(ops, M, D, H):
     assert e1 < 3e-6 and e1 < 4 * e0 + 5e-7, (e0, e1)
 
 
+def test_gemm_row_epilogues_upscaling_chain(ops):
+    """The decoder's upscaling MLP inside GEMM epilogues (N = 256: a wave owns whole rows): Linear -> LayerNorm -> GELU with the result
+    packed against the LayerNorm's bound, then Linear -> GELU -> hyper-network dot products, against fp64 (mask_decoder.py:53-59,164-176)."""
+    g = torch.Generator().manual_seed(21)
+    Z, Npts, E, C = 2, 640, 256, 3
+    M = Z * Npts
+    x = torch.randn(M, E, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))
+    W0, b0 = torch.randn(E, E, generator=g) / 16, torch.randn(E, generator=g) * 0.1
+    gam, bet = 1 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    W3, b3 = torch.randn(E, E, generator=g) / 16, torch.randn(E, generator=g) * 0.1
+    hyper = torch.randn(Z, C, E, generator=g)
+    u1 = F.gelu(F.layer_norm(F.linear(x.double(), W0.double(), b0.double()), (E,), gam.double(), bet.double(), 1e-5))
+    u2 = F.gelu(F.linear(u1, W3.double(), b3.double()))
+    want = torch.einsum("zce,zne->zcn", hyper.double(), u2.view(Z, Npts, E))
+    fw0, fw3 = ops.F16Weight(cu(W0)), ops.F16Weight(cu(W3))
+    bound = ops.row_ln_bound(gam, bet)
+    with ops.gemm_mode("f16x3"):
+        xp, sx = ops.scale_pack_rows_g8(cu(x))
+        u1p = torch.empty(M, E, device="cuda"); s1 = torch.empty(M, device="cuda")
+        ops.linear(xp, fw0, cu(b0), act=ops.ACT_GELU, x_scale=sx, x_packed=True, out=u1p, pack_out=(s1, 0.0, bound),
+                   row_ln=(cu(gam), cu(bet), 1e-5))
+        masks = torch.empty(Z, C, Npts, device="cuda")
+        ops.linear(u1p, fw3, cu(b3), act=ops.ACT_GELU, x_scale=s1, x_packed=True, hyper=(cu(hyper), masks, Npts), no_store=True)
+        full = ops.linear(u1p, fw3, cu(b3), act=ops.ACT_GELU, x_scale=s1, x_packed=True)      # the same GEMM with its output stored
+    dec = _unpack_g8(u1p, s1, E).cpu()
+    assert ((dec - u1).abs().max() / u1.abs().max()).item() < 2e-6
+    m = u1.abs().max(1).values * s1.cpu().double()
+    assert (s1 == s1[0]).all() and 2.0 ** 14 <= bound * s1[0].item() < 2.0 ** 15 and (m < 2.0 ** 15).all(), "scale from the LayerNorm bound"
+    _close(full, u2, 2e-5, what="second GEMM")
+    err = ((masks.cpu().double() - want).abs().max() / want.abs().max()).item()
+    assert err < 2e-6, err
+
+
 def test_gemm_bf16x6_epilogues(ops):
     g = torch.Generator().manual_seed(3)
     M, D, H, Hp, grp = 384, 128, 170, 192, 64
