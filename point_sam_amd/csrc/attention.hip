@@ -23,14 +23,24 @@ constexpr int FA_BKV = 64;   // keys per LDS tile
 struct FlashArgs {
     const float* q; const float* k; const float* v; float* o;
     int64_t ldq, ldk, ldv, ldo, sq, sk, sv, so;
-    int H, Lq, Lk;
+    int H, Lq, Lk, B;
     float scale_log2e;
     // packed output (flash_attn_f16x3_kernel only): o receives the g8-packed rows (the A operand of the output projection,
     // gemm_f16x3p.hip), scaled by o_scale[row] = the power of two that puts the BOUND k1 / min_rows(a_scale) + k2 of |V| over the cloud
     // into [2^14, 2^15) -- attention outputs are convex combinations of V rows, so the bound holds for them; a_scale = the row scales
     // of the qkv GEMM's A operand (LayerNorm output), k1 = 2^15 sqrt(D) max_n ||W_v[n]||, k2 = max |b_v|.
     const float* a_scale; float* o_scale; float k1, k2;
+#ifdef PSAM_ATTN_ABLATE
+    int abl;      // scripts/exp/attn_abl.*: 1 no per-tile convert+store, 2 no tile loads, 4 no exp/split, 8 no S MFMAs, 16 no PV MFMAs
+#endif
 };
+#ifdef PSAM_ATTN_ABLATE
+#define FA_ABL(bit) (p.abl & (bit))
+static int g_attn_abl = 0;
+PSAM_API void psam_attention_set_ablation(int32_t a) { g_attn_abl = a; }
+#else
+#define FA_ABL(bit) false
+#endif
 
 template <int HD8, int DT>
 __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs p) {
@@ -197,7 +207,7 @@ PSAM_API int32_t psam_attention_f32(const float* q, int64_t ldq, int64_t sq, con
     FlashArgs p;
     p.q = q; p.k = k; p.v = v; p.o = o;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
-    p.H = H; p.Lq = Lq; p.Lk = Lk;
+    p.H = H; p.Lq = Lq; p.Lk = Lk; p.B = B;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.a_scale = nullptr; p.o_scale = nullptr; p.k1 = p.k2 = 0.f;
     const dim3 grid((unsigned)psam_cdiv(Lq, FA_BQ), H, B), block(256);
@@ -264,56 +274,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * FA_BQ + wave * 32;
+    // 1-D grid: consecutive workgroup ids go to different XCDs (own L2 each), so the nq query blocks of one (batch, head) -- which all read the
+    // same K/V slice -- take ids 8 apart and share an XCD's L2 (rocprofv3 FETCH_SIZE at B=8, H=16, L=512 with the query block as the fastest
+    // grid dimension: 151 MB per launch against 50 MB of q/k/v -- four XCDs each fetched every slice)
+    const int nq = (p.Lq + FA_BQ - 1) / FA_BQ, HB = p.H * p.B;
+    int qb, hb;
+    if ((HB & 7) == 0) { const int id = blockIdx.x, grp = id / (8 * nq), r = id - grp * 8 * nq; hb = grp * 8 + (r & 7); qb = r >> 3; }
+    else { qb = blockIdx.x % nq; hb = blockIdx.x / nq; }
+    const int head = hb % p.H, b = hb / p.H;
+    const int q0 = qb * FA_BQ + wave * 32;
     const float* Q = p.q + b * p.sq + head * HD;
     const float* K = p.k + b * p.sk + head * HD;
     const float* V = p.v + b * p.sv + head * HD;
-
-    float out_scale = 0.f;     // packed output: one scale for every row of the cloud (see FlashArgs)
-    if (p.o_scale) {
-        float smin = INFINITY;
-        for (int i = tid; i < p.Lk; i += 256) smin = fminf(smin, p.a_scale[(int64_t)b * p.Lk + i]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) smin = fminf(smin, __shfl_xor(smin, o, 64));
-        if (lane == 0) smax[0][wave][0] = smin;
-        __syncthreads();
-        smin = fminf(fminf(smax[0][0][0], smax[0][1][0]), fminf(smax[0][2][0], smax[0][3][0]));
-        __syncthreads();       // smax is reused by the tile scales below
-        out_scale = f16_row_scale(p.k1 / smin + p.k2);
-    }
-
-    // ---- this lane's query row: d-slots 16s + 8h .. +7 of every k16 step, scaled by the row's power of two, split
-    fa_f16x8 qh[KS], ql[KS];
-    float q_inv;   // 1 / row scale
-    {
-        const int qrow = q0 + r32;
-        const bool ok = qrow < p.Lq;
-        const float* qp = Q + (int64_t)(ok ? qrow : 0) * p.ldq + h * 8;
-        f32x4 t[KS][2];
-        float amax = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                t[s][e] = ok ? *reinterpret_cast<const f32x4*>(qp + s * 16 + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(t[s][e][0]), fabsf(t[s][e][1]))), fmaxf(fabsf(t[s][e][2]), fabsf(t[s][e][3])));
-            }
-        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-        const float sq = f16_row_scale(amax);
-        q_inv = fa_inv_pow2(sq);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            unsigned hi[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                fa_split2(fa_f32x2{t[s][e][0], t[s][e][1]} * sq, hi[2 * e], lo[2 * e]);
-                fa_split2(fa_f32x2{t[s][e][2], t[s][e][3]} * sq, hi[2 * e + 1], lo[2 * e + 1]);
-            }
-            qh[s] = __builtin_bit_cast(fa_f16x8, fa_u32x4{hi[0], hi[1], hi[2], hi[3]});
-            ql[s] = __builtin_bit_cast(fa_f16x8, fa_u32x4{lo[0], lo[1], lo[2], lo[3]});
-        }
-    }
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -402,7 +374,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 
     const int ntiles = (p.Lk + FA_BKV - 1) / FA_BKV;
     float sk_cur, sv_cur;
-    load_tile(0);
+    load_tile(0);      // in flight while the query rows (and the packed output's scale) are fetched: one memory round trip, not three
+    float out_scale = 0.f;     // packed output: one scale for every row of the cloud (see FlashArgs)
+    if (p.o_scale) {
+        float smin = INFINITY;
+        for (int i = tid; i < p.Lk; i += 256) smin = fminf(smin, p.a_scale[(int64_t)b * p.Lk + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) smin = fminf(smin, __shfl_xor(smin, o, 64));
+        if (lane == 0) smax[0][wave][0] = smin;
+        __syncthreads();
+        smin = fminf(fminf(smax[0][0][0], smax[0][1][0]), fminf(smax[0][2][0], smax[0][3][0]));
+        __syncthreads();       // smax is reused by the tile scales below
+        out_scale = f16_row_scale(p.k1 / smin + p.k2);
+    }
+
+    // ---- this lane's query row: d-slots 16s + 8h .. +7 of every k16 step, scaled by the row's power of two, split
+    fa_f16x8 qh[KS], ql[KS];
+    float q_inv;   // 1 / row scale
+    {
+        const int qrow = q0 + r32;
+        const bool ok = qrow < p.Lq;
+        const float* qp = Q + (int64_t)(ok ? qrow : 0) * p.ldq + h * 8;
+        f32x4 t[KS][2];
+        float amax = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                t[s][e] = ok ? *reinterpret_cast<const f32x4*>(qp + s * 16 + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(t[s][e][0]), fabsf(t[s][e][1]))), fmaxf(fabsf(t[s][e][2]), fabsf(t[s][e][3])));
+            }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const float sq = f16_row_scale(amax);
+        q_inv = fa_inv_pow2(sq);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                fa_split2(fa_f32x2{t[s][e][0], t[s][e][1]} * sq, hi[2 * e], lo[2 * e]);
+                fa_split2(fa_f32x2{t[s][e][2], t[s][e][3]} * sq, hi[2 * e + 1], lo[2 * e + 1]);
+            }
+            qh[s] = __builtin_bit_cast(fa_f16x8, fa_u32x4{hi[0], hi[1], hi[2], hi[3]});
+            ql[s] = __builtin_bit_cast(fa_f16x8, fa_u32x4{lo[0], lo[1], lo[2], lo[3]});
+        }
+    }
+
     publish_max(0);
     __syncthreads();
     tile_scales(0, sk_cur, sv_cur);
@@ -411,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const unsigned char* st_base = smem + buf * STAGE;
-        if (t + 1 < ntiles) load_tile((t + 1) * FA_BKV);
+        if (t + 1 < ntiles && !FA_ABL(2)) load_tile((t + 1) * FA_BKV);
         const float c_s = p.scale_log2e * q_inv * fa_inv_pow2(sk_cur);     // S_scaled -> log2-domain logits
 #pragma unroll
         for (int kt = 0; kt < FA_BKV / 32; ++kt) {
@@ -428,6 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
                 const int off = ((2 * s + h) ^ ((krow >> 1) & KSW)) << 4;
                 const fa_f16x8 kh = *reinterpret_cast<const fa_f16x8*>(kb + off);
                 const fa_f16x8 kl = *reinterpret_cast<const fa_f16x8*>(kb + KPLANE + off);
+                if (FA_ABL(8)) { st[0] += (float)kh[0] + (float)kl[1]; continue; }
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], st, 0, 0, 0);
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c_s, -m14));   // probability * 2^14, in [0, 2^14]
+                st[r] = FA_ABL(4) ? __builtin_fmaf(st[r], c_s, -m14) : __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c_s, -m14));   // probability * 2^14, in [0, 2^14]
                 ps += st[r];
             }
             l_run = l_run * alpha + ps;
@@ -468,7 +486,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
             for (int s2 = 0; s2 < 2; ++s2) {
                 unsigned hi[4], lo[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fa_split2(fa_f32x2{st[8 * s2 + 2 * e], st[8 * s2 + 2 * e + 1]}, hi[e], lo[e]);
+                for (int e = 0; e < 4; ++e) {
+                    if (FA_ABL(4)) { hi[e] = __builtin_bit_cast(unsigned, st[8 * s2 + 2 * e]); lo[e] = __builtin_bit_cast(unsigned, st[8 * s2 + 2 * e + 1]); }
+                    else fa_split2(fa_f32x2{st[8 * s2 + 2 * e], st[8 * s2 + 2 * e + 1]}, hi[e], lo[e]);
+                }
                 ph[s2] = __builtin_bit_cast(fa_f16x8, fa_u32x4{hi[0], hi[1], hi[2], hi[3]});
                 pl[s2] = __builtin_bit_cast(fa_f16x8, fa_u32x4{lo[0], lo[1], lo[2], lo[3]});
             }
@@ -480,18 +501,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
                     const unsigned char* vb = st_base + 2 * KPLANE + vrow * ROWB + (((kt * 4 + s2 * 2 + h) ^ ((vrow >> 1) & 7)) << 4);
                     const fa_f16x8 vh = *reinterpret_cast<const fa_f16x8*>(vb);
                     const fa_f16x8 vl = *reinterpret_cast<const fa_f16x8*>(vb + VPLANE);
+                    if (FA_ABL(16)) { oacc[d][0] += (float)vh[0] + (float)vl[1] + (float)pl[s2][0] + (float)ph[s2][1]; continue; }
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], oacc[d], 0, 0, 0);
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], oacc[d], 0, 0, 0);
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], oacc[d], 0, 0, 0);
                 }
         }
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && !FA_ABL(1)) {
             publish_max(buf ^ 1);
             __syncthreads();
             tile_scales(buf ^ 1, sk_cur, sv_cur);
             store_tile(buf ^ 1, sk_cur, sv_cur);
         }
-        __syncthreads();
+        if (!FA_ABL(32)) __syncthreads();
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);          // 2^14 * sum of probabilities
@@ -538,7 +560,7 @@ PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq
     PSAM_REQUIRE(!o_scale || ((ldo & 7) == 0 && ((uintptr_t)o & 31) == 0 && (so & 7) == 0 && Lq == Lk), PSAM_EINVAL,
                  "psam_attention_f16x3: packed output needs 32-byte aligned rows and self-attention (Lq == Lk)");
     PSAM_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, PSAM_EINVAL, "psam_attention_f16x3: bad shape");
-    PSAM_REQUIRE(B <= 65535 && H <= 65535, PSAM_EINVAL, "psam_attention_f16x3: B/H too large");
+    PSAM_REQUIRE((int64_t)psam_cdiv(Lq, FA_BQ) * H * B < ((int64_t)1 << 31), PSAM_EINVAL, "psam_attention_f16x3: too many workgroups");
     PSAM_REQUIRE(((ldq | ldk | ldv | ldo | sq | sk | sv | so) & 3) == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
                  PSAM_EALIGN, "psam_attention_f16x3: strides must be multiples of 4 floats and pointers 16-byte aligned");
     PSAM_REQUIRE((int64_t)Lk * ldk < ((int64_t)1 << 29) && (int64_t)Lk * ldv < ((int64_t)1 << 29), PSAM_EINVAL,
@@ -546,10 +568,13 @@ PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq
     FlashArgs p;
     p.q = q; p.k = k; p.v = v; p.o = o;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
-    p.H = H; p.Lq = Lq; p.Lk = Lk;
+    p.H = H; p.Lq = Lq; p.Lk = Lk; p.B = B;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.a_scale = a_scale; p.o_scale = o_scale; p.k1 = k1; p.k2 = k2;
-    const dim3 grid((unsigned)psam_cdiv(Lq, FA_BQ), H, B), block(256);
+#ifdef PSAM_ATTN_ABLATE
+    p.abl = g_attn_abl;
+#endif
+    const dim3 grid((unsigned)(psam_cdiv(Lq, FA_BQ) * H * B)), block(256);      // 1-D over (query block, head, batch), see the kernel
     switch (hd) {
         case 64: hipLaunchKernelGGL((flash_attn_f16x3_kernel<64>), grid, block, 0, stream, p); break;
         case 128: hipLaunchKernelGGL((flash_attn_f16x3_kernel<128>), grid, block, 0, stream, p); break;

@@ -37,7 +37,7 @@ struct F16PArgs {
     int64_t lda, ldw, ldc, ldr, ldrb;     // lda / ldw in 32-bit containers
     int M, N, K, rowgroup, act;
     float alpha;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, panel;      // panel: width (in column tiles) of the column panels the tile order walks row-major (f16x3p_panel)
     // fused extras (psam_gemm_fuse_t, see gemm_epilogue.h): all null / 0 for the plain GEMM
     float* out_scale; float out_k1, out_k2; int pack_out;
     float* stats; int stat_cols, stat_segs;
@@ -75,14 +75,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     constexpr int NMF = 3 * TM * TN;                            // MFMAs per k16 step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    // ---- tile of this workgroup: XCD-contiguous ranges of the row-major tile order (consecutive workgroup ids go to different XCDs)
+    // ---- tile of this workgroup: consecutive workgroup ids go to different XCDs (each with its own 4 MiB L2), so XCD x takes the x-th
+    // CONTIGUOUS eighth of the tile order; the order walks column panels of `panel` tiles row-major (panel == tiles_n: plain row-major,
+    // an XCD reads an eighth of A and all of W; panel ~ tiles_n / 8: an XCD keeps its W panel in L2 and streams A once)
     const int ntiles = p.tiles_m * p.tiles_n;
     int tile = blockIdx.x;
     {
         const int q = ntiles >> 3, r = ntiles & 7, x = tile & 7, y = tile >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int pfull = p.tiles_m * p.panel, pn = tile / pfull, prem = tile - pn * pfull;
+    const int pw = p.tiles_n - pn * p.panel < p.panel ? p.tiles_n - pn * p.panel : p.panel;
+    const int m0 = (prem / pw) * BM, n0 = (pn * p.panel + prem % pw) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,6 +430,31 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
     return best;
 }
 
+// Column-panel width of the tile order (see the kernel).  Fabric-side traffic model per XCD, which owns ntiles / 8 consecutive tiles and
+// keeps about 2.5 MiB of operands in its L2: with panels of P column tiles the XCD's W panel (P * BN * K * 4 B) is fetched once per panel
+// it touches if it fits, once per group of concurrently running row bands if it does not; every A row band (BM * K * 4 B) of the panel
+// is fetched once.  The P with the least modelled traffic wins (ties: the widest).  PSAM_GEMM_PANEL overrides (0: plain row-major).
+// Measured (profiles/r02_gemm_panel_sweep.log): qkv 81.7 -> 79.6 us, fc1 143.4 -> 138.2 us, two-stream layer 303.9 -> 292 us.
+static int f16x3p_panel(int tiles_m, int tiles_n, int BM, int BN, int K) {
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("PSAM_GEMM_PANEL"); forced = e ? atoi(e) : -1; }
+    if (forced == 0) return tiles_n;
+    if (forced > 0) return forced < tiles_n ? forced : tiles_n;
+    const double l2 = 2.5 * 1048576.0, a_band = (double)BM * K * 4, w_col = (double)BN * K * 4;
+    const double chunk = (double)tiles_m * tiles_n / 8.0;
+    int best = tiles_n;
+    double best_cost = 1e300;
+    for (int P = tiles_n; P >= 1; P = P > 1 ? (P + 1) / 2 : 0) {
+        const double rows = chunk / P < tiles_m ? chunk / P : tiles_m;                 // row bands an XCD walks inside a panel
+        const double panels = chunk / ((double)tiles_m * P) > 1.0 ? chunk / ((double)tiles_m * P) : 1.0;   // panels it touches
+        const double wp = P * w_col, conc = 64.0 / P > 1.0 ? 64.0 / P : 1.0;           // ~64 tiles of an XCD in flight: conc row bands share a panel pass
+        const double w_cost = (wp <= l2 || rows <= conc) ? wp * panels : wp * (rows / conc) * panels;
+        const double cost = 8.0 * (w_cost + rows * a_band * panels);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = P; }
+    }
+    return best;
+}
+
 template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
 static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
@@ -438,6 +467,7 @@ static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     }
     p.tiles_m = (int)psam_cdiv(p.M, BM);
     p.tiles_n = (int)psam_cdiv(p.N, BN);
+    p.panel = f16x3p_panel(p.tiles_m, p.tiles_n, BM, BN, p.K);
     static bool attr_done = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
