@@ -54,6 +54,7 @@ SIGNATURES = {
     "psam_attention_f16x3": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3_ex": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, ptr]),
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
+    "psam_mlp3": (i32, [ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, ptr]),
     "psam_pos_l1": (i32, [ptr, ptr, ptr, ptr, i64, ptr]),
     "psam_fourier_pe": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i64, ptr, ptr]),
     "psam_add_bcast": (i32, [ptr, i64, i32, ptr, i64, i64, ptr, i64, i64, i64, i32, ptr]),

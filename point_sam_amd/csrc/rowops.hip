@@ -483,8 +483,13 @@ PSAM_API int32_t psam_interp3(const float* src, const int64_t* idx3, const float
 
 // ------------------------------------------------------------------------------------------------
 // Small multi-head attention for the decoder's token-sized problems (transformer.py:214-236): softmax(q k^T / sqrt(hd)) v.
-// One wave per (batch, head, query).  q/k/v/out are [Z, L, H*hd] with explicit row strides; keys are scored one per
-// lane, probabilities parked in LDS, then lanes own output channels.
+// q/k/v/out are [Z, L, H*hd] with explicit row strides.  Two shapes occur (7 output tokens against 512 patch tokens, both ways):
+//  * many keys (attention_small_kernel): one wave per (batch, head, query).  Keys are scored one per lane (float4 loads), the
+//    probabilities parked in LDS; for the output the wave is split into 64 / hd4 key groups x hd4 float4 channels, each lane sums
+//    its group's keys and the groups are added with fixed-order shuffles.  (The first version gave every output channel to one
+//    lane -- 16 active lanes walking all 512 keys: 52 us for the token -> image attention.)
+//  * few keys (Lk <= 16, attention_fewkeys_kernel): one THREAD per (batch, head, query): the scores, the softmax and the output
+//    stay in registers; consecutive threads are consecutive queries of one (batch, head), so every k / v address is wave-uniform.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attention_small_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq, const float* __restrict__ k,
                                                               int64_t ldk, int64_t sk, const float* __restrict__ v, int64_t ldv, int64_t sv,
@@ -501,11 +506,20 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     const float* kp = k + z * sk + hh * hd;
     const float* vp = v + z * sv + hh * hd;
     float* p = s_p + wave * Lk;
+    const bool vec = (hd & 3) == 0 && hd <= 64 && (64 % (hd >> 2)) == 0 && ((ldq | ldk | ldv | ldo | sq | sk | sv | so) & 3) == 0 &&
+                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0);      // wave-uniform
     float m = -INFINITY;
     for (int j = lane; j < Lk; j += 64) {
         const float* kr = kp + (int64_t)j * ldk;
         float s = 0.f;
-        for (int d = 0; d < hd; ++d) s = fmaf(qp[d], kr[d], s);
+        if (vec) {
+            for (int d = 0; d < hd; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(qp + d), b = *reinterpret_cast<const float4*>(kr + d);
+                s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+            }
+        } else {
+            for (int d = 0; d < hd; ++d) s = fmaf(qp[d], kr[d], s);
+        }
         s *= scale;
         p[j] = s;
         m = fmaxf(m, s);
@@ -517,6 +531,21 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     const float invl = 1.0f / l;
+    if (vec) {
+        const int hd4 = hd >> 2, ng = 64 / hd4, c4 = lane % hd4, grp = lane / hd4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = grp; j < Lk; j += ng) {
+            const float pj = p[j];
+            const float4 vv = *reinterpret_cast<const float4*>(vp + (int64_t)j * ldv + c4 * 4);
+            acc.x = fmaf(pj, vv.x, acc.x); acc.y = fmaf(pj, vv.y, acc.y); acc.z = fmaf(pj, vv.z, acc.z); acc.w = fmaf(pj, vv.w, acc.w);
+        }
+        for (int o = 32; o >= hd4; o >>= 1) {      // add the key groups (lanes hd4 apart), fixed order
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (grp == 0)
+            *reinterpret_cast<float4*>(out + z * so + (int64_t)qi * ldo + hh * hd + c4 * 4) = make_float4(acc.x * invl, acc.y * invl, acc.z * invl, acc.w * invl);
+        return;
+    }
     for (int d = lane; d < hd; d += 64) {
         float acc = 0.f;
         for (int j = 0; j < Lk; ++j) acc = fmaf(p[j], vp[(int64_t)j * ldv + d], acc);
@@ -524,13 +553,126 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     }
 }
 
+template <int HD4>   // head dim / 4
+__global__ __launch_bounds__(256) void attention_fewkeys_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq, const float* __restrict__ k,
+                                                                int64_t ldk, int64_t sk, const float* __restrict__ v, int64_t ldv, int64_t sv,
+                                                                float* __restrict__ out, int64_t ldo, int64_t so, int H, int Lq, int Lk, float scale) {
+    // grid: (ceil(Lq / 256), H, Z)
+    const int qi = blockIdx.x * 256 + threadIdx.x, hh = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    if (qi >= Lq) return;
+    const float* qp = q + z * sq + (int64_t)qi * ldq + hh * (HD4 * 4);
+    const float* kp = k + z * sk + hh * (HD4 * 4);
+    const float* vp = v + z * sv + hh * (HD4 * 4);
+    float4 qr[HD4];
+#pragma unroll
+    for (int d = 0; d < HD4; ++d) qr[d] = *reinterpret_cast<const float4*>(qp + 4 * d);
+    float sc[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        sc[j] = -INFINITY;
+        if (j < Lk) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD4; ++d) {
+                const float4 b = *reinterpret_cast<const float4*>(kp + (int64_t)j * ldk + 4 * d);
+                s = fmaf(qr[d].x, b.x, s); s = fmaf(qr[d].y, b.y, s); s = fmaf(qr[d].z, b.z, s); s = fmaf(qr[d].w, b.w, s);
+            }
+            sc[j] = s * scale;
+            m = fmaxf(m, sc[j]);
+        }
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { sc[j] = j < Lk ? __expf(sc[j] - m) : 0.f; l += sc[j]; }
+    const float invl = 1.0f / l;
+    float4 acc[HD4];
+#pragma unroll
+    for (int d = 0; d < HD4; ++d) acc[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < Lk) {
+#pragma unroll
+            for (int d = 0; d < HD4; ++d) {
+                const float4 vv = *reinterpret_cast<const float4*>(vp + (int64_t)j * ldv + 4 * d);
+                acc[d].x = fmaf(sc[j], vv.x, acc[d].x); acc[d].y = fmaf(sc[j], vv.y, acc[d].y);
+                acc[d].z = fmaf(sc[j], vv.z, acc[d].z); acc[d].w = fmaf(sc[j], vv.w, acc[d].w);
+            }
+        }
+    float* op = out + z * so + (int64_t)qi * ldo + hh * (HD4 * 4);
+#pragma unroll
+    for (int d = 0; d < HD4; ++d) *reinterpret_cast<float4*>(op + 4 * d) = make_float4(acc[d].x * invl, acc[d].y * invl, acc[d].z * invl, acc[d].w * invl);
+}
+
 PSAM_API int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v,
                                       int64_t ldv, int64_t sv, float* out, int64_t ldo, int64_t so, int64_t Z, int32_t H, int32_t Lq, int32_t Lk,
                                       int32_t hd, float scale, hipStream_t stream) {
     PSAM_REQUIRE(q && k && v && out && Z > 0 && H > 0 && Lq > 0 && Lk > 0 && hd > 0, PSAM_EINVAL, "psam_attention_small: bad argument");
     PSAM_REQUIRE((size_t)Lk * 16 <= 128 * 1024, PSAM_EINVAL, "psam_attention_small: Lk too large");
+    const bool aligned = ((ldq | ldk | ldv | ldo | sq | sk | sv | so) & 3) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0);
+    if (Lk <= 16 && Lq >= 64 && aligned && (hd == 16 || hd == 32) && Z <= 65535 && H <= 65535) {
+        const dim3 grid((unsigned)psam_cdiv(Lq, 256), H, (unsigned)Z);
+        if (hd == 16) hipLaunchKernelGGL(attention_fewkeys_kernel<4>, grid, dim3(256), 0, stream, q, ldq, sq, k, ldk, sk, v, ldv, sv, out, ldo, so, H, Lq, Lk, scale);
+        else hipLaunchKernelGGL(attention_fewkeys_kernel<8>, grid, dim3(256), 0, stream, q, ldq, sq, k, ldk, sk, v, ldv, sv, out, ldo, so, H, Lq, Lk, scale);
+        return psam_launch_status("psam_attention_small: launch failed");
+    }
     const int64_t waves = Z * H * Lq;
     hipLaunchKernelGGL(attention_small_kernel, dim3((unsigned)psam_cdiv(waves, 4)), dim3(256), (size_t)Lk * 16, stream, q, ldq, sq, k, ldk, sk, v,
                        ldv, sv, out, ldo, so, Z, H, Lq, Lk, hd, scale);
     return psam_launch_status("psam_attention_small: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Three-layer ReLU MLP on a handful of rows: the decoder's hyper-networks and IoU head (mask_decoder.py:171-180,189-211), 256-wide
+// layers applied to one token row per prompt.  As GEMMs these were nine + three launches of a one-workgroup kernel (~10 us each, all
+// latency); here one workgroup per (prompt row, MLP) walks the three layers with the activations in LDS.  Weights are given
+// TRANSPOSED ([in][out], prepared once at model load) so that thread j, which owns output j, reads row k of W^T together with its
+// neighbours (coalesced) and needs no cross-lane reduction: y[j] = b[j] + sum_k x[k] W^T[k][j], fp32 FMAs in k order.
+// MLP m of a stack reads x + z*ldx + m*sx and uses the m-th [in][out] matrix of each stacked weight.
+// ------------------------------------------------------------------------------------------------
+constexpr int MLP3_MAXD = 1024;
+__global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ x, int64_t ldx, int64_t sx, const float* __restrict__ w1t,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                   const float* __restrict__ w3t, const float* __restrict__ b3, float* __restrict__ out, int64_t ldo,
+                                                   int64_t so, int din, int dh, int dout) {
+    __shared__ float s_a[MLP3_MAXD], s_b[MLP3_MAXD];
+    const int z = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    const float* xp = x + (int64_t)z * ldx + (int64_t)m * sx;
+    for (int i = tid; i < din; i += 256) s_a[i] = xp[i];
+    __syncthreads();
+    auto layer = [&](const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ wt, const float* __restrict__ b, int ni, int no,
+                     bool relu, bool global_out) {
+        for (int j = tid; j < no; j += 256) {
+            float a0 = b[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four partial sums: independent FMA chains, combined in a fixed order
+            int kk = 0;
+            for (; kk + 4 <= ni; kk += 4) {
+                a0 = fmaf(src[kk], wt[(int64_t)kk * no + j], a0);
+                a1 = fmaf(src[kk + 1], wt[(int64_t)(kk + 1) * no + j], a1);
+                a2 = fmaf(src[kk + 2], wt[(int64_t)(kk + 2) * no + j], a2);
+                a3 = fmaf(src[kk + 3], wt[(int64_t)(kk + 3) * no + j], a3);
+            }
+            for (; kk < ni; ++kk) a0 = fmaf(src[kk], wt[(int64_t)kk * no + j], a0);
+            float y = (a0 + a1) + (a2 + a3);
+            if (relu) y = fmaxf(y, 0.f);
+            dst[global_out ? (int64_t)j : j] = y;
+        }
+    };
+    layer(s_a, s_b, w1t + (int64_t)m * din * dh, b1 + (int64_t)m * dh, din, dh, true, false);
+    __syncthreads();
+    layer(s_b, s_a, w2t + (int64_t)m * dh * dh, b2 + (int64_t)m * dh, dh, dh, true, false);
+    __syncthreads();
+    layer(s_a, out + (int64_t)z * ldo + (int64_t)m * so, w3t + (int64_t)m * dh * dout, b3 + (int64_t)m * dout, dh, dout, false, true);
+}
+
+// x rows [Z] (row stride ldx; MLP m reads at + m * sx), stacked transposed weights w1t [M, din, dh], w2t [M, dh, dh], w3t [M, dh, dout],
+// biases [M, dh], [M, dh], [M, dout]; out rows [Z] (stride ldo; MLP m writes dout values at + m * so).
+PSAM_API int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                           const float* w3t, const float* b3, float* out, int64_t ldo, int64_t so, int32_t Z, int32_t M, int32_t din, int32_t dh,
+                           int32_t dout, hipStream_t stream) {
+    PSAM_REQUIRE(x && w1t && b1 && w2t && b2 && w3t && b3 && out, PSAM_EINVAL, "psam_mlp3: null pointer");
+    PSAM_REQUIRE(Z > 0 && M > 0 && M <= 65535 && din > 0 && dh > 0 && dout > 0 && din <= MLP3_MAXD && dh <= MLP3_MAXD, PSAM_EINVAL,
+                 "psam_mlp3: bad shape (din, dh <= 1024)");
+    hipLaunchKernelGGL(mlp3_kernel, dim3((unsigned)Z, (unsigned)M), dim3(256), 0, stream, x, ldx, sx, w1t, b1, w2t, b2, w3t, b3, out, ldo, so, din, dh, dout);
+    return psam_launch_status("psam_mlp3: launch failed");
 }

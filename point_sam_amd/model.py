@@ -122,6 +122,11 @@ class PointCloudSAM:
             blk.p = p
             self.blocks.append(blk)
         self.out_tokens = torch.cat([w["mask_decoder.iou_token.weight"], w["mask_decoder.mask_tokens.weight"]], 0).contiguous()
+        # hyper-networks and IoU head as one launch each (psam_mlp3): transposed, stacked weights; multimask uses MLPs 1.., single mask MLP 0
+        mlp = lambda pfx: [(w[f"{pfx}.layers.{j}.weight"], w[f"{pfx}.layers.{j}.bias"]) for j in range(3)]
+        hyp = [mlp(f"mask_decoder.output_hypernetworks_mlps.{i}") for i in range(cfg.num_mask_tokens)]
+        self.hyper_mw = {True: ops.Mlp3Weights(hyp[1:]), False: ops.Mlp3Weights(hyp[:1])}
+        self.iou_mw = ops.Mlp3Weights([mlp("mask_decoder.iou_prediction_head")])
         # "f16x3": every static weight that can feed the packed-operand GEMM (csrc/gemm_f16x3p.hip) is scaled, split and packed ONCE,
         # here, and owned by this model (fw: name -> ops.F16Weight; launches below the split thresholds use its fp32 original)
         self.fw = {}
@@ -360,11 +365,6 @@ class PointCloudSAM:
         queries = self._ln(P + ".norm_final_attn", self._lin(P + ".final_attn_token_to_image.out_proj", a), eps, residual=queries)
         return queries, keys
 
-    def _mlp3(self, prefix, x, out=None):
-        h = self._lin(prefix + ".layers.0", x, act=ACT_RELU)
-        h = self._lin(prefix + ".layers.1", h, act=ACT_RELU)
-        return self._lin(prefix + ".layers.2", h, out=out)
-
     @torch.no_grad()
     def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, use_center_idx=False):
         """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState.  use_center_idx: the mask
@@ -408,14 +408,14 @@ class PointCloudSAM:
             ops.add_bcast(st.pc_embeddings, rep, dense, src, Z, G, E)
         hs, keys = self._two_way(src.view(Z * G, E), st.pc_pe, tokens.view(Z * T, E), Z, G, T, rep)
         hs = hs.view(Z, T, E)
+        assert hs.is_contiguous()
         # upscale: 3-NN interpolation G -> N, MLP, hyper-network dot product    (mask_decoder.py:146-176)
         if st.interp_index is None:
             st.interp_index, st.interp_weight = ops.three_nn(st.coords, st.centers)
         sel = list(range(1, nmt)) if multimask_output else [0]
         C = len(sel)
         hyper = torch.empty(Z, C, E, device=self.device)
-        for j, i in enumerate(sel):
-            self._mlp3(f"mask_decoder.output_hypernetworks_mlps.{i}", hs[:, 1 + i, :], out=hyper[:, j, :])
+        ops.mlp3(hs[:, 1 + sel[0], :], T * E, E, self.hyper_mw[bool(multimask_output)], hyper, C * E, E, Z)      # mask token i -> MLP i
         masks = torch.empty(Z, C, N, device=self.device)
         up = torch.empty(Z * N, E, device=self.device)
         U0, U3 = "mask_decoder.output_upscaling.0", "mask_decoder.output_upscaling.3"
@@ -444,7 +444,8 @@ class PointCloudSAM:
             self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1, scale_out=rs, pack=pk)
             self._lin(U3, u1, act=ACT_GELU, out=up, x_scale=rs, x_packed=pk)
             ops.gemm_batched(hyper, up, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
-        iou = self._mlp3("mask_decoder.iou_prediction_head", hs[:, 0, :])
+        iou = torch.empty(Z, nmt, device=self.device)
+        ops.mlp3(hs, T * E, 0, self.iou_mw, iou, nmt, 0, Z)      # token 0 = IoU token
         return masks, iou[:, sel[0]:sel[-1] + 1]
 
     # ------------------------------------------------------------------------------------------ reference API

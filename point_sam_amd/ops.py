@@ -421,6 +421,30 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
     return out
 
 
+class Mlp3Weights:
+    """Three Linear layers (ReLU between) of M stacked MLPs, transposed for psam_mlp3: w?t [M, in, out], b? [M, out]."""
+
+    def __init__(self, layers):
+        # layers: list over MLPs of [(W1, b1), (W2, b2), (W3, b3)] with W [out, in]
+        st = lambda i: (torch.stack([m[i][0].t().contiguous() for m in layers]).contiguous(), torch.stack([m[i][1] for m in layers]).contiguous())
+        (self.w1t, self.b1), (self.w2t, self.b2), (self.w3t, self.b3) = st(0), st(1), st(2)
+        self.M, self.din, self.dh = self.w1t.shape
+        self.dout = self.w3t.shape[2]
+        if self.w2t.shape[1:] != (self.dh, self.dh) or self.w3t.shape[1] != self.dh:
+            raise ValueError("Mlp3Weights: layer shapes do not chain")
+
+
+def mlp3(x, ldx, sx, mw: Mlp3Weights, out, ldo, so, Z):
+    """out[z, m] = W3_m relu(W2_m relu(W1_m x[z, m] + b1) + b2) + b3: row (z, m) of x at x.data_ptr() + 4 * (z * ldx + m * sx) (fp32
+    elements), of out at + 4 * (z * ldo + m * so).  One launch for all M MLPs and Z rows (mask_decoder.py:171-180,189-211)."""
+    for t in (x, out):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise _lib.PointSamHipError("mlp3: operands must be fp32 tensors on the GPU (there is no CPU fallback)")
+    check(_lib.load().psam_mlp3(x.data_ptr(), ldx, sx, mw.w1t.data_ptr(), mw.b1.data_ptr(), mw.w2t.data_ptr(), mw.b2.data_ptr(), mw.w3t.data_ptr(),
+                                mw.b3.data_ptr(), out.data_ptr(), ldo, so, Z, mw.M, mw.din, mw.dh, mw.dout, _stream()), "psam_mlp3")
+    return out
+
+
 def attention_small(q, k, v, out, Z, H, Lq, Lk, hd, scale):
     qp, ldq = _row_view(q, "q"); kp, ldk = _row_view(k, "k"); vp, ldv = _row_view(v, "v"); op, ldo = _row_view(out, "out")
     check(_lib.load().psam_attention_small(qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, Z, H, Lq, Lk, hd, scale,

@@ -685,7 +685,26 @@ def test_flash_attention_running_max_spike(ops):
     _close(out.view(B, L, hd), _sdpa(q, k, v, H, 1.0), 2e-5, what="flash spike")
 
 
-@pytest.mark.parametrize("hd,H,Lq,Lk", [(32, 8, 7, 7), (16, 8, 7, 512), (16, 8, 512, 7), (16, 8, 6, 2048), (24, 2, 3, 70)])
+@pytest.mark.parametrize("Z,M,din,dh,dout,T", [(8, 3, 256, 256, 256, 7), (5, 1, 256, 256, 4, 7), (2, 2, 64, 96, 10, 3)])
+def test_mlp3_hypernetworks(ops, Z, M, din, dh, dout, T):
+    """psam_mlp3 (the decoder's hyper-network MLPs / IoU head in one launch) vs fp64: MLP m reads token 1 + m of every prompt's row block."""
+    g = torch.Generator().manual_seed(Z * 100 + M)
+    hs = torch.randn(Z, T, din, generator=g)
+    layers = [[(torch.randn(o, i, generator=g) / i ** 0.5, torch.randn(o, generator=g) * 0.1) for i, o in ((din, dh), (dh, dh), (dh, dout))] for _ in range(M)]
+    mw = ops.Mlp3Weights([[(cu(W), cu(b)) for W, b in mlp] for mlp in layers])
+    hsd = cu(hs)
+    out = torch.full((Z, M, dout), float("nan"), device="cuda")
+    ops.mlp3(hsd[:, 1, :], T * din, din, mw, out, M * dout, dout, Z)
+    for m, mlp in enumerate(layers):
+        x = hs[:, 1 + m, :].double()
+        for li, (W, b) in enumerate(mlp):
+            x = F.linear(x, W.double(), b.double())
+            if li < 2:
+                x = F.relu(x)
+        _close(out[:, m, :], x, 2e-6, what=f"mlp3 m={m}")
+
+
+@pytest.mark.parametrize("hd,H,Lq,Lk", [(32, 8, 7, 7), (16, 8, 7, 512), (16, 8, 512, 7), (32, 4, 300, 12), (16, 8, 6, 2048), (24, 2, 3, 70)])
 def test_attention_small(ops, hd, H, Lq, Lk):
     g = torch.Generator().manual_seed(hd * Lk)
     Z, D = 3, H * hd
