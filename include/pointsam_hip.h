@@ -240,9 +240,12 @@ int32_t psam_add_bcast(const float* a, int64_t sa, int32_t rep, const float* b, 
  * pc_sam/model/common.py:258-274 (mask_decoder.py:163). */
 int32_t psam_interp3(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C,
                      psam_stream_t stream);
-/* scale_out [Z*N] != NULL (C == 256): out receives the g8-packed rows (A operand of psam_gemm_f16x3p) and scale_out their row scales. */
+/* scale_out [Z*N] != NULL (C == 256): out receives the g8-packed rows (A operand of psam_gemm_f16x3p) and scale_out their row scales.
+ * ln_gamma / ln_beta != NULL (C == 256): LayerNorm(ln_eps) and the activation `act` (none / GELU / ReLU) are applied to every interpolated
+ * row -- `interp -> Linear -> LayerNorm -> GELU` of mask_decoder.py:53-59,163 evaluated as `Linear (on the G patch rows) -> interp + LayerNorm
+ * + GELU`: the interpolation is an affine combination (weights sum to 1), so it commutes with the Linear layer. */
 int32_t psam_interp3_ex(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C,
-                        float* scale_out, psam_stream_t stream);
+                        float* scale_out, const float* ln_gamma, const float* ln_beta, float ln_eps, int32_t act, psam_stream_t stream);
 
 #ifdef __cplusplus
 }

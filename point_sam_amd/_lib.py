@@ -59,7 +59,7 @@ SIGNATURES = {
     "psam_fourier_pe": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i64, ptr, ptr]),
     "psam_add_bcast": (i32, [ptr, i64, i32, ptr, i64, i64, ptr, i64, i64, i64, i32, ptr]),
     "psam_interp3": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr]),
-    "psam_interp3_ex": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr, ptr]),
+    "psam_interp3_ex": (i32, [ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr, ptr, ptr, f32, i32, ptr]),
 }
 
 

@@ -431,9 +431,15 @@ PSAM_API int32_t psam_add_bcast(const float* a, int64_t sa, int32_t rep, const f
 // ------------------------------------------------------------------------------------------------
 // interpolate_features (common.py:258-274): out[z, n, :] = sum_k w3[b,n,k] * src[z, idx3[b,n,k], :], b = z / rep.
 // One wave per point, float4 per lane (C == 256).
+// ln_g != NULL (C == 256: the wave holds the whole row): LayerNorm(gamma, beta, eps) and the activation are applied to the interpolated
+// row before it is written.  This is how the decoder's upscaling MLP starts (mask_decoder.py:53-59,146-160): its first Linear is applied
+// to the G patch rows BEFORE the interpolation -- interpolation is an affine combination (weights sum to 1), so
+// Linear(interp(x)) = interp(Linear(x)) -- and the LayerNorm + GELU that follow it ride on the interpolation kernel: the [N, 256]
+// GEMM and the separate LayerNorm pass over [N, 256] disappear.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx3, const float* __restrict__ w3,
-                                                      float* __restrict__ out, int rep, int64_t Z, int N, int G, int C, float* __restrict__ scale_out) {
+                                                      float* __restrict__ out, int rep, int64_t Z, int N, int G, int C, float* __restrict__ scale_out,
+                                                      const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps, int act) {
     const int lane = threadIdx.x & 63;
     const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wv >= Z * N) return;
@@ -450,6 +456,14 @@ __global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ 
         f32x4 v = a * w0;
         v = v + bb * w1;
         v = v + cc * w2;
+        if (ln_g) {      // C == 256 (host-checked): two-pass LayerNorm over the row held by this wave, then the activation
+            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+            const f32x4 d = v - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f) + ln_eps);
+            v = d * rstd * *reinterpret_cast<const f32x4*>(ln_g + c) + *reinterpret_cast<const f32x4*>(ln_b + c);
+            if (act == 1) v = f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+            else if (act == 2) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        }
         if (scale_out) {      // C == 256 (host-checked): the whole row is in this wave -> g8-packed row + its scale (gemm_f16x3p.hip)
             const float sc = f16_row_scale(wave_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
             if (lane == 0) scale_out[z * N + n] = sc;
@@ -467,18 +481,23 @@ __global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ 
 }
 
 // scale_out [Z*N] != NULL (C == 256 only): out receives the g8-packed rows (A operand of psam_gemm_f16x3p) and scale_out their scales.
+// ln_gamma / ln_beta != NULL (C == 256 only): LayerNorm(ln_eps) + activation `act` (PSAM_ACT_NONE / GELU / RELU) of every interpolated row.
 PSAM_API int32_t psam_interp3_ex(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G,
-                                 int32_t C, float* scale_out, hipStream_t stream) {
+                                 int32_t C, float* scale_out, const float* ln_gamma, const float* ln_beta, float ln_eps, int32_t act,
+                                 hipStream_t stream) {
     PSAM_REQUIRE(src && idx3 && w3 && out && rep > 0 && Z > 0 && N > 0 && G > 0 && C > 0, PSAM_EINVAL, "psam_interp3: bad argument");
     PSAM_REQUIRE((C & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0, PSAM_EALIGN, "psam_interp3: C % 4 and 16B alignment");
     PSAM_REQUIRE(!scale_out || (C == 256 && ((uintptr_t)out & 31) == 0), PSAM_EINVAL, "psam_interp3: packed output needs C == 256 and 32-byte aligned rows");
-    hipLaunchKernelGGL(interp3_kernel, dim3((unsigned)psam_cdiv(Z * N, 4)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, C, scale_out);
+    PSAM_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr) && (!ln_gamma || (C == 256 && (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0)) &&
+                 act >= 0 && act <= 2 && (ln_gamma || act == 0), PSAM_EINVAL, "psam_interp3: row LayerNorm needs gamma and beta, C == 256, act in {none, gelu, relu}");
+    hipLaunchKernelGGL(interp3_kernel, dim3((unsigned)psam_cdiv(Z * N, 4)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, C, scale_out, ln_gamma,
+                       ln_beta, ln_eps, act);
     return psam_launch_status("psam_interp3: launch failed");
 }
 
 PSAM_API int32_t psam_interp3(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G,
                               int32_t C, hipStream_t stream) {
-    return psam_interp3_ex(src, idx3, w3, out, rep, Z, N, G, C, nullptr, stream);
+    return psam_interp3_ex(src, idx3, w3, out, rep, Z, N, G, C, nullptr, nullptr, nullptr, 0.f, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

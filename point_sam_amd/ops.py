@@ -486,11 +486,14 @@ def add_bcast(a, rep, b, out, Z, R, C, sa=None, sb=None, ldb=None, so=None):
     return out
 
 
-def interp3(src, idx3, w3, out, rep, scale_out=None):
-    """src [Z,G,C], idx3/w3 [B,N,3] -> out [Z,N,C]; scale_out [Z*N] (C == 256): out receives the g8-packed rows + their scales."""
+def interp3(src, idx3, w3, out, rep, scale_out=None, ln=None, act=ACT_NONE):
+    """src [Z,G,C], idx3/w3 [B,N,3] -> out [Z,N,C]; scale_out [Z*N] (C == 256): out receives the g8-packed rows + their scales;
+    ln=(gamma, beta, eps) (C == 256): LayerNorm and the activation `act` applied to every interpolated row."""
     Z, G, C = src.shape
     N = idx3.shape[1]
-    check(_lib.load().psam_interp3_ex(src.data_ptr(), idx3.data_ptr(), w3.data_ptr(), out.data_ptr(), rep, Z, N, G, C, _p(scale_out), _stream()), "psam_interp3")
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    check(_lib.load().psam_interp3_ex(src.data_ptr(), idx3.data_ptr(), w3.data_ptr(), out.data_ptr(), rep, Z, N, G, C, _p(scale_out), _p(g), _p(b),
+                                      float(eps), int(act), _stream()), "psam_interp3")
     return out
 
 

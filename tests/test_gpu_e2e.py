@@ -120,14 +120,14 @@ def test_fused_upscaling_matches_unfused(gpu):
     sd = random_state_dict(cfg, seed=8)
     xyz, rgb, prompt, labels = O.synthetic_batch(2, 4096, seed=5)
     outs = []
-    for fuse, rows in ((False, False), (True, False), (True, True)):
+    for first, fuse, rows in ((False, False, False), (False, True, False), (False, True, True), (True, True, False)):
         model = gpu(cfg, sd, precision="f16x3")
-        model.fuse_upscale, model.fuse_upscale_rows = fuse, rows
+        model.upscale_linear_first, model.fuse_upscale, model.fuse_upscale_rows = first, fuse, rows
         st = model.encode(xyz.cuda(), rgb.cuda())
         m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
         m2, i2 = model.decode(st, prompt.cuda(), labels.cuda(), m1[:, 1].contiguous(), False)
         outs.append((m1, i1, m2, i2))
-    for tag, got in (("packed interpolation", outs[1]), ("row epilogues", outs[2])):
+    for tag, got in (("packed interpolation", outs[1]), ("row epilogues", outs[2]), ("Linear before interpolation + LN/GELU in the interpolation kernel", outs[3])):
         e = [_maxerr(a, b) for a, b in zip(outs[0], got)]
         print(f"\n[upscaling: {tag} vs unfused] max|diff| masks {e[0]:.2e} iou {e[1]:.2e} click-2 masks {e[2]:.2e}")
         assert max(e) < 5e-5, e

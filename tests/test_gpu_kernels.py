@@ -586,7 +586,38 @@ def test_group_max_pos_fourier_addbcast_interp(ops):
     w3 = torch.rand(2, 300, 3, generator=g)
     out = torch.empty(4, 300, 256, device="cuda")
     ops.interp3(cu(src), cu(idx), cu(w3), out, 2)
-    _close(out, O.interpolate(src, idx.repeat_interleave(2, 0), w3.repeat_interleave(2, 0)), 1e-5, what="interp3")
+    want = O.interpolate(src, idx.repeat_interleave(2, 0), w3.repeat_interleave(2, 0))
+    _close(out, want, 1e-5, what="interp3")
+    # ... with LayerNorm + GELU of the interpolated row (the upscaling MLP's `interp -> Linear -> LN -> GELU`, Linear moved in front)
+    gam, bet = 1 + 0.2 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    want_ln = F.gelu(F.layer_norm(want.double(), (256,), gam.double(), bet.double(), 1e-5))
+    ops.interp3(cu(src), cu(idx), cu(w3), out, 2, ln=(cu(gam), cu(bet), 1e-5), act=ops.ACT_GELU)
+    _close(out, want_ln, 1e-5, what="interp3 + LN + GELU")
+    sc = torch.empty(4 * 300, device="cuda")
+    ops.interp3(cu(src), cu(idx), cu(w3), out, 2, scale_out=sc, ln=(cu(gam), cu(bet), 1e-5), act=ops.ACT_GELU)
+    dec = _unpack_g8(out.view(-1, 256), sc, 256).cpu()
+    assert ((dec - want_ln.view(-1, 256)).abs().max() / want_ln.abs().max()).item() < 2e-6, "packed interp3 + LN + GELU"
+
+
+def test_upscaling_linear_commutes_with_interpolation(ops):
+    """Linear(interp(x)) == interp(Linear(x)) to fp32 rounding for the real 3-NN weights (they sum to 1 up to 1 ulp): the identity the
+    decoder's upscaling path relies on (mask_decoder.py:53-59,163)."""
+    g = torch.Generator().manual_seed(77)
+    xyz, _ = _cloud(1, 4096, seed=9)
+    centers = xyz[:, torch.randperm(4096, generator=g)[:64]]
+    idx, w3 = ops.three_nn(cu(xyz), cu(centers))
+    assert ((w3.sum(-1) - 1).abs() < 3e-7).all()
+    src = torch.randn(1, 64, 256, generator=g)
+    W, b = torch.randn(256, 256, generator=g) / 16, torch.randn(256, generator=g)
+    a = torch.empty(1, 4096, 256, device="cuda"); bb = torch.empty(1, 4096, 256, device="cuda")
+    with ops.gemm_mode("f32"):
+        ops.interp3(cu(src), idx, w3, a, 1)
+        y0 = ops.linear(a.view(-1, 256), cu(W), cu(b))
+        k1 = ops.linear(cu(src).view(-1, 256), cu(W), cu(b))
+        ops.interp3(k1.view(1, 64, 256), idx, w3, bb, 1)
+    err = (y0 - bb.view(-1, 256)).abs().max().item() / y0.abs().max().item()
+    print(f"\n[Linear o interp vs interp o Linear] max rel diff {err:.2e}")
+    assert err < 2e-6
 
 
 def _sdpa(q, k, v, H, scale):
