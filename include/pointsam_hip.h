@@ -158,7 +158,13 @@ typedef struct {
     float* gmax_out; int64_t gmax_ld; int32_t gmax_k; int32_t no_store;
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
     const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
+    int64_t hyper_pstride;
 } psam_gemm_fuse_t;
+/* hyper without row_ln_*: any N % 128 == 0, M % 256 == 0; every 64-column wave tile contributes the partial products of its columns:
+ * masks then holds psam_gemm_f16x3p_hyper_planes(N, 0) = N / 64 planes of [Z, C, hyper_rows], hyper_pstride elements apart, and
+ * psam_sum_planes adds them in a fixed order.  With row_ln_* (full-row tile, N == 256) there is one plane. */
+int32_t psam_gemm_f16x3p_hyper_planes(int32_t N, int32_t with_row_ln);
+int32_t psam_sum_planes(const float* parts, int32_t P, int64_t pstride, int64_t count, float* out, psam_stream_t stream);
 int32_t psam_gemm_f16x3p_stat_segs(int32_t N);
 int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C, int64_t ldc,
                             const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,

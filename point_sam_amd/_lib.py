@@ -54,6 +54,8 @@ SIGNATURES = {
     "psam_attention_f16x3": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3_ex": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, ptr]),
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
+    "psam_gemm_f16x3p_hyper_planes": (i32, [i32, i32]),
+    "psam_sum_planes": (i32, [ptr, i32, i64, i64, ptr, ptr]),
     "psam_mlp3": (i32, [ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, ptr]),
     "psam_pos_l1": (i32, [ptr, ptr, ptr, ptr, i64, ptr]),
     "psam_fourier_pe": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i64, ptr, ptr]),
@@ -68,7 +70,7 @@ class GemmFuse(ctypes.Structure):
     """psam_gemm_fuse_t (include/pointsam_hip.h)."""
     _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
                 ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
-                ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32)]
+                ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64)]
 
 
 _lib = None

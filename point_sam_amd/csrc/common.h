@@ -36,11 +36,6 @@ static inline int64_t psam_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; 
 #ifdef __HIPCC__
 constexpr int WAVE = 64;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 // Power-of-two row scale of the f16x3 GEMM: 2^(14 - e), e = floor(log2(row maximum)) clamped below at -112 (scale and its inverse stay
 // normal fp32 numbers over the whole finite range: 2^-113 .. 2^126 and 2^-126 .. 2^113); 1 for an
 // all-zero / non-finite row (gemm_f16x3.hip).
@@ -66,7 +61,7 @@ __device__ __forceinline__ void psam_split2_f16(float x0, float x1, float s, uns
 
 // Reductions on the VALU's data-parallel-primitive path instead of ds_bpermute (an LDS round trip, ~100+ cycles per step, six steps for a
 // wave): quad_perm xor 1 / xor 2, row_half_mirror, row_mirror leave every lane of a 16-lane row with the row's result in four
-// few-cycle steps; the four rows are combined through v_readlane (SGPRs).  Whole wave must be active.
+// few-cycle steps.  Whole wave must be active.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 template <int CTRL>
@@ -82,14 +77,29 @@ __device__ __forceinline__ int row16_min(int v) {
     v = min(v, dpp_i32<DPP_HALF_MIRROR>(v)); v = min(v, dpp_i32<DPP_MIRROR>(v));
     return v;
 }
-__device__ __forceinline__ float readlane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ float wave_max(float v) {      // wave-uniform result
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<DPP_XOR1>(v); v += dpp_f32<DPP_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v); v += dpp_f32<DPP_MIRROR>(v);
+    return v;
+}
+// Wave reductions: four DPP steps inside the 16-lane rows, then two cross-row exchanges through ds_bpermute (xor 16, xor 32): every lane
+// ends up with the result, in a fixed order.  (A variant that combined the rows with v_readlane of lanes 0/16/32/48 was faster still but
+// gave run-to-run different LayerNorm statistics in one multi-stream test -- 9 failures in 10 runs against 0 in 10 for this form and for
+// the plain six-step shuffle butterfly -- so SGPR read-back of DPP results is not used.)
+__device__ __forceinline__ float wave_max(float v) {
     v = row16_max(v);
-    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float wave_sum(float v) {      // pairs, quads, 8s, 16s inside a row, then rows 16 apart, then 32 apart
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
 }
 __device__ __forceinline__ int wave_min_dpp(int v) {
     v = row16_min(v);
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    v = min(v, __shfl_xor(v, 16, 64));
+    return min(v, __shfl_xor(v, 32, 64));
 }
 // exact (erf) GELU, as torch.nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

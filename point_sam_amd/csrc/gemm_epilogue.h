@@ -74,6 +74,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     ep_f32x4 lnc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EXT) { if (interior && lane_on && p.ln_c) lnc = ep_load4(p.ln_c + pcol); }
     constexpr bool FULLROW = EXT && TN == 8;
+    constexpr bool HYPER = EXT && (TN == 8 || TN == 2);      // hyper products: full rows (one plane) or 64-column wave tiles (N / 64 partial planes)
     [[maybe_unused]] ep_f32x4 rg = {1.f, 1.f, 1.f, 1.f}, rbt = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FULLROW) { if (interior && p.row_ln_g) { rg = ep_load4(p.row_ln_g + pcol); rbt = ep_load4(p.row_ln_b + pcol); } }
     if (interior && lane_on) {
@@ -197,7 +198,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             if constexpr (EXT) {
                                 if (p.gmax_out) gm = ep_f32x4{fmaxf(gm[0], v[0]), fmaxf(gm[1], v[1]), fmaxf(gm[2], v[2]), fmaxf(gm[3], v[3])};
                             }
-                            if constexpr (FULLROW) {
+                            if constexpr (HYPER) {
                                 if (p.hyper) *reinterpret_cast<ep_f32x4*>(lw + rl * LD + scol) = v;      // finished value back in place for the row pass below
                             }
                         }
@@ -222,12 +223,14 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     }
                 }
             }
-            if constexpr (FULLROW) {
+            if constexpr (HYPER) {
                 if (p.hyper && !swiglu) {      // hyper-network dot products of the stripe's finished rows (hyper_rows % 32 == 0: one z per stripe)
+                    // over this wave's TN*32 columns: the whole row (TN == 8), or plane col_base / 64 of N / 64 partial sums (psam_sum_planes adds them)
                     ep_wave_sync();
                     const int row0 = row_base + i * 32, z = row0 / p.hyper_rows, n0 = row0 - z * p.hyper_rows;
                     const float* rowp = lw + r32 * LD + h * (TN * 16);
-                    const float* hb = p.hyper + (int64_t)z * p.hyper_c * (TN * 32) + h * (TN * 16);
+                    const float* hb = p.hyper + (int64_t)z * p.hyper_c * p.N + col_base + h * (TN * 16);
+                    float* mk = p.masks + (int64_t)(col_base / (TN * 32)) * p.hyper_pstride;
                     float dot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
                     for (int c = 0; c < TN * 4; ++c) {
@@ -235,14 +238,14 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc)
                             if (cc < p.hyper_c) {
-                                const ep_f32x4 hv = ep_load4(hb + cc * (TN * 32) + 4 * c);
+                                const ep_f32x4 hv = ep_load4(hb + (int64_t)cc * p.N + 4 * c);
                                 dot[cc] += (x[0] * hv[0] + x[1] * hv[1]) + (x[2] * hv[2] + x[3] * hv[3]);
                             }
                     }
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         dot[cc] += __shfl_xor(dot[cc], 32, 64);
-                        if (cc < p.hyper_c && h == 0) p.masks[((int64_t)z * p.hyper_c + cc) * p.hyper_rows + n0 + r32] = dot[cc];
+                        if (cc < p.hyper_c && h == 0) mk[((int64_t)z * p.hyper_c + cc) * p.hyper_rows + n0 + r32] = dot[cc];
                     }
                 }
             }

@@ -44,7 +44,7 @@ struct F16PArgs {
     const float* ln_mean; const float* ln_rstd; const float* ln_c;
     float* gmax_out; int64_t gmax_ld; int gmax_k, no_store;
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
-    const float* hyper; float* masks; int hyper_c, hyper_rows;
+    const float* hyper; float* masks; int hyper_c, hyper_rows; int64_t hyper_pstride;
 };
 
 #define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
@@ -490,7 +490,11 @@ struct psam_gemm_fuse_t {
     // hyper-network dot products masks[z, c, n] = <hyper[z, c, :], out[z * hyper_rows + n, :]> (c < hyper_c <= 4)
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
     const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
+    int64_t hyper_pstride;      // elements between the partial planes of `masks` (psam_gemm_f16x3p_hyper_planes of them)
 };
+
+// partial planes the hyper products of an N-column GEMM are delivered in: 1 with the row-LayerNorm (full-row) epilogue, N / 64 otherwise
+PSAM_API int32_t psam_gemm_f16x3p_hyper_planes(int32_t N, int32_t with_row_ln) { return with_row_ln ? 1 : N / 64; }
 
 // segments (of 32 gated columns) per row of the stats buffer of a SwiGLU GEMM with N packed weight rows
 PSAM_API int32_t psam_gemm_f16x3p_stat_segs(int32_t N) { return (N / 2 + 31) / 32; }
@@ -516,10 +520,21 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
-    p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1;
+    p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
-    if (fuse && (fuse->row_ln_g || fuse->hyper)) {
+    if (fuse && fuse->hyper && !fuse->row_ln_g) {
+        // hyper products from the 64-column wave tiles of the 128x128 / 256x128 configurations: N / 64 partial planes, added by psam_sum_planes
+        PSAM_REQUIRE((M & 255) == 0 && (N & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: hyper products need M % 256 == 0, N % 128 == 0, no SwiGLU");
+        PSAM_REQUIRE(!fuse->stats && !fuse->ln_c && !fuse->gmax_out && !fuse->pack_out, PSAM_EINVAL, "psam_gemm_f16x3p_ex: hyper products do not combine with other extras");
+        PSAM_REQUIRE(fuse->masks && fuse->hyper_c > 0 && fuse->hyper_c <= 4 && fuse->hyper_rows > 0 && fuse->hyper_rows % 32 == 0 &&
+                     (N == 64 || fuse->hyper_pstride >= (int64_t)(M / fuse->hyper_rows) * fuse->hyper_c * fuse->hyper_rows), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: hyper products need masks, 1 <= hyper_c <= 4, hyper_rows % 32 == 0 and a plane stride covering [Z, C, rows]");
+        PSAM_REQUIRE(((uintptr_t)fuse->hyper & 15) == 0, PSAM_EALIGN, "psam_gemm_f16x3p_ex: 16-byte alignment");
+        p.hyper = fuse->hyper; p.masks = fuse->masks; p.hyper_c = fuse->hyper_c; p.hyper_rows = fuse->hyper_rows; p.hyper_pstride = fuse->hyper_pstride;
+        p.no_store = fuse->no_store;
+        if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
+    } else if (fuse && (fuse->row_ln_g || fuse->hyper)) {
         // full-row epilogues: a wave owns whole rows of N == 256 columns (128x256 tiles, four waves of 32 rows)
         PSAM_REQUIRE(N == 256 && (M & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm / hyper products need N == 256, M % 128 == 0");
         PSAM_REQUIRE(!fuse->stats && !fuse->ln_c && !fuse->gmax_out, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row epilogues do not combine with stats / folded LN / group max");
@@ -536,7 +551,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         p.pack_out = fuse->pack_out; p.out_scale = fuse->out_scale; p.out_k1 = fuse->out_k1; p.out_k2 = fuse->out_k2; p.no_store = fuse->no_store;
         return launch_f16x3p<4, 1, 1, 8, 2, 0, 0, 2>(p, stream);
     }
-    if (fuse && (fuse->pack_out || fuse->stats || fuse->ln_c || fuse->gmax_out)) {
+    if (fuse && !fuse->hyper && (fuse->pack_out || fuse->stats || fuse->ln_c || fuse->gmax_out)) {
         // The fused epilogue paths exist for interior tiles of the two-tile-wide wave tiles only: whole 256-row / 128-column tiles.
         PSAM_REQUIRE((M & 255) == 0 && (N & 127) == 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: fused extras need M % 256 == 0 and N % 128 == 0");
         PSAM_REQUIRE(!fuse->pack_out || (fuse->out_scale && (ldc & 7) == 0 && ((uintptr_t)C & 31) == 0), PSAM_EINVAL,

@@ -695,3 +695,19 @@ PSAM_API int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float*
     hipLaunchKernelGGL(mlp3_kernel, dim3((unsigned)Z, (unsigned)M), dim3(256), 0, stream, x, ldx, sx, w1t, b1, w2t, b2, w3t, b3, out, ldo, so, din, dh, dout);
     return psam_launch_status("psam_mlp3: launch failed");
 }
+
+// out[i] = ((p0[i] + p1[i]) + p2[i]) + ...: the partial planes of a GEMM's hyper-product epilogue (psam_gemm_fuse_t.hyper), fixed order.
+__global__ __launch_bounds__(256) void sum_planes_kernel(const float* __restrict__ parts, int P, int64_t pstride, int64_t count4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    f32x4 a = *reinterpret_cast<const f32x4*>(parts + 4 * i);
+    for (int q = 1; q < P; ++q) a = a + *reinterpret_cast<const f32x4*>(parts + q * pstride + 4 * i);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = a;
+}
+
+PSAM_API int32_t psam_sum_planes(const float* parts, int32_t P, int64_t pstride, int64_t count, float* out, hipStream_t stream) {
+    PSAM_REQUIRE(parts && out && P > 0 && count > 0, PSAM_EINVAL, "psam_sum_planes: bad argument");
+    PSAM_REQUIRE((count & 3) == 0 && (pstride & 3) == 0 && (((uintptr_t)parts | (uintptr_t)out) & 15) == 0, PSAM_EALIGN, "psam_sum_planes: count, stride % 4 and 16B alignment");
+    hipLaunchKernelGGL(sum_planes_kernel, dim3((unsigned)psam_cdiv(count / 4, 256)), dim3(256), 0, stream, parts, P, pstride, count / 4, out);
+    return psam_launch_status("psam_sum_planes: launch failed");
+}

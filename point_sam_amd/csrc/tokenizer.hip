@@ -210,6 +210,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
             cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_cxyz[slot][0][wwin])));
             cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_cxyz[slot][1][wwin])));
             cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_cxyz[slot][2][wwin])));
+            asm volatile("s_nop 4");      // the SGPRs just written by the VALU feed packed-fp32 VALU operands (inline asm) at the top of the loop
             if (tid == 0) idx_out[(int64_t)b * G + j] = last;
             if (tid < 3) centers_out[((int64_t)b * G + j) * 3 + tid] = tid == 0 ? cx : (tid == 1 ? cy : cz);
         }

@@ -74,6 +74,7 @@ class PointCloudSAM:
         # upscaling MLP: the first Linear runs on the G patch rows BEFORE the 3-NN interpolation (an affine combination: it commutes with a
         # Linear layer) and the LayerNorm + GELU after it ride on the interpolation kernel -- the [N, 256] GEMM and LayerNorm pass are gone
         self.upscale_linear_first = True
+        self.fuse_hyper = True      # "f16x3": the hyper-network products taken inside the last upscaling GEMM's epilogue
         self.fuse_upscale = True  # "f16x3": the 3-NN interpolation hands its rows to the upscaling MLP packed (no pack pass)
         # "f16x3": the upscaling MLP's LayerNorm/GELU and the hyper-network products inside two full-row GEMM epilogues.  Parity-tested,
         # but OFF: the 128x256 one-wave-per-SIMD tile it needs runs 383 us against 188 us for the 128x128 tile at [262144, 256, 256],
@@ -429,8 +430,13 @@ class PointCloudSAM:
             s1 = torch.empty(Z * N, dtype=torch.float32, device=self.device) if pk else None
             ops.interp3(k1.view(Z, G, E), st.interp_index, st.interp_weight, up, rep, scale_out=s1,
                         ln=(w["mask_decoder.output_upscaling.1.weight"], w["mask_decoder.output_upscaling.1.bias"], cfg.ln_eps), act=ACT_GELU)
-            u2 = self._lin(U3, up, act=ACT_GELU, x_scale=s1, x_packed=pk)
-            ops.gemm_batched(hyper, u2, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
+            if pk and self.fuse_hyper and (Z * N) % 256 == 0 and N % 32 == 0 and C <= 4:
+                # second Linear + GELU + hyper-network products in one GEMM: each 64-column wave tile adds its part of the C dot products
+                # per row, the [N, 256] activation is never written (mask_decoder.py:171-176)
+                self._lin(U3, up, act=ACT_GELU, x_scale=s1, x_packed=True, hyper=(hyper, masks, N), no_store=True)
+            else:
+                u2 = self._lin(U3, up, act=ACT_GELU, x_scale=s1, x_packed=pk)
+                ops.gemm_batched(hyper, u2, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
         elif packed_interp and self.fuse_upscale_rows and (Z * N) % 128 == 0 and N % 32 == 0 and C <= 4 and (U3 + ".weight") in self.fw:
             # interpolation -> Linear -> LayerNorm -> GELU -> Linear -> GELU -> hyper-network products as THREE kernels: the interpolated
             # rows leave packed, the first GEMM's epilogue normalises / activates / re-packs whole rows (a wave owns a 256-column row;

@@ -330,6 +330,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         else:
             xa, sa = scale_pack_rows_g8(x, K)
         fuse = None
+        hyper_parts = None
         if fused:
             fuse = _lib.GemmFuse()
             fuse.no_store = int(bool(no_store))
@@ -342,6 +343,10 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
                 if not (hy.is_contiguous() and mk.is_contiguous() and hy.shape[-1] == N and mk.shape[:2] == hy.shape[:2] and mk.shape[2] == rpz):
                     raise ValueError("hyper [Z, C, N] / masks [Z, C, rows_per_z] must be contiguous and consistent")
                 fuse.hyper, fuse.masks, fuse.hyper_c, fuse.hyper_rows = hy.data_ptr(), mk.data_ptr(), int(hy.shape[1]), int(rpz)
+                planes = _lib.load().psam_gemm_f16x3p_hyper_planes(N, int(row_ln is not None))
+                if planes > 1:      # partial products per 64-column wave tile: N / 64 planes, added below in a fixed order
+                    hyper_parts = torch.empty(planes, mk.numel(), dtype=torch.float32, device=mk.device)
+                    fuse.masks, fuse.hyper_pstride = hyper_parts.data_ptr(), mk.numel()
             if pack_out is not None:
                 fuse.out_scale, fuse.out_k1, fuse.out_k2, fuse.pack_out = pack_out[0].data_ptr(), float(pack_out[1]), float(pack_out[2]), 1
             if stats is not None:
@@ -350,6 +355,9 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
                 fuse.ln_mean, fuse.ln_rstd, fuse.ln_c = ln_fold[0].data_ptr(), ln_fold[1].data_ptr(), ln_fold[2].data_ptr()
         _f16x3p_call((xa.data_ptr(), xa.stride(0), sa.data_ptr(), fw.packed.data_ptr(), fw.packed.stride(0), fw.scale.data_ptr(), op, ldo, _p(bias),
                       rp, ldr, rbp, ldrb, rowgroup, M, N, fw.Kp, 1.0, act, _stream()), 2.0 * M * N * K, M, N, K, fuse)
+        if hyper_parts is not None:
+            check(_lib.load().psam_sum_planes(hyper_parts.data_ptr(), hyper_parts.shape[0], hyper_parts.shape[1], hyper_parts.shape[1],
+                                              hyper[1].data_ptr(), _stream()), "psam_sum_planes")
         return out
     if fused:
         raise ValueError("fused GEMM extras exist only on the f16x3 packed-operand path")

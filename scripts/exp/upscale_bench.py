@@ -54,6 +54,14 @@ def main():
         out["fused up.3 (GELU + hyper, no store)"] = timed(lambda: ops.linear(u1, fw3, b3, act=ops.ACT_GELU, x_scale=s1, x_packed=True, hyper=(hyper, masks, N), no_store=True))
         out["row LN + GELU, fp32 out"] = timed(lambda: ops.linear(up, fw0, b0, act=ops.ACT_GELU, x_scale=s_up, x_packed=True, out=u2, row_ln=(gam, bet, 1e-5)))
         out["row LN only, fp32 out"] = timed(lambda: ops.linear(up, fw0, b0, x_scale=s_up, x_packed=True, out=u2, row_ln=(gam, bet, 1e-5)))
+        # round-2 default chain: Linear on the patch rows, interpolation + LN + GELU (packed), second Linear + GELU, hyper products
+        k1 = ops.linear(keys.view(Z * G, E), fw0, b0)
+        out["up.0 on the G patch rows (4096 x 256)"] = timed(lambda: ops.linear(keys.view(Z * G, E), fw0, b0))
+        out["interp3 + LN + GELU, packed"] = timed(lambda: ops.interp3(k1.view(Z, G, E), idx, wgt, up, rep, scale_out=s1, ln=(gam, bet, 1e-5), act=ops.ACT_GELU))
+        out["up.3 GEMM + GELU (fp32 out)"] = timed(lambda: ops.linear(up, fw3, b3, act=ops.ACT_GELU, out=u2, x_scale=s1, x_packed=True))
+        out["hyper batched GEMM (again)"] = timed(lambda: ops.gemm_batched(hyper, u2, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z))
+        out["up.3 GEMM + GELU + hyper partial planes + sum (no store)"] = timed(lambda: ops.linear(up, fw3, b3, act=ops.ACT_GELU, x_scale=s1, x_packed=True,
+                                                                                                hyper=(hyper, masks, N), no_store=True))
     for k, v in out.items():
         print(f"{k:45s} {v:8.1f} us")
 

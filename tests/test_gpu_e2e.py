@@ -120,14 +120,16 @@ def test_fused_upscaling_matches_unfused(gpu):
     sd = random_state_dict(cfg, seed=8)
     xyz, rgb, prompt, labels = O.synthetic_batch(2, 4096, seed=5)
     outs = []
-    for first, fuse, rows in ((False, False, False), (False, True, False), (False, True, True), (True, True, False)):
+    for first, fuse, rows, hyp in ((False, False, False, False), (False, True, False, False), (False, True, True, False), (True, True, False, False),
+                                   (True, True, False, True)):
         model = gpu(cfg, sd, precision="f16x3")
-        model.upscale_linear_first, model.fuse_upscale, model.fuse_upscale_rows = first, fuse, rows
+        model.upscale_linear_first, model.fuse_upscale, model.fuse_upscale_rows, model.fuse_hyper = first, fuse, rows, hyp
         st = model.encode(xyz.cuda(), rgb.cuda())
         m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
         m2, i2 = model.decode(st, prompt.cuda(), labels.cuda(), m1[:, 1].contiguous(), False)
         outs.append((m1, i1, m2, i2))
-    for tag, got in (("packed interpolation", outs[1]), ("row epilogues", outs[2]), ("Linear before interpolation + LN/GELU in the interpolation kernel", outs[3])):
+    for tag, got in (("packed interpolation", outs[1]), ("row epilogues", outs[2]), ("Linear before interpolation + LN/GELU in the interpolation kernel", outs[3]),
+                     ("... + hyper products in the GEMM epilogue", outs[4])):
         e = [_maxerr(a, b) for a, b in zip(outs[0], got)]
         print(f"\n[upscaling: {tag} vs unfused] max|diff| masks {e[0]:.2e} iou {e[1]:.2e} click-2 masks {e[2]:.2e}")
         assert max(e) < 5e-5, e
@@ -306,8 +308,10 @@ def test_batch_pipeline_matches_predict_masks(gpu, dense_streams, precision):
             pipe.submit(*batches[k + pipe.depth])
         got.append(pipe.next())
     torch.cuda.synchronize()
-    for (m1, i1), (m2, i2) in zip(want, got):
-        assert torch.equal(m1, m2) and torch.equal(i1, i2)
+    for k, ((m1, i1), (m2, i2)) in enumerate(zip(want, got)):
+        d = (m1 - m2).abs()
+        assert torch.equal(m1, m2) and torch.equal(i1, i2), (k, float(d.max()), [[float(d[z, c].max()) for c in range(d.shape[1])] for z in range(d.shape[0])],
+                                                             float((i1 - i2).abs().max()))
     model.check_coordinate_range()
 
 
