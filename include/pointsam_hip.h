@@ -213,11 +213,16 @@ int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const f
                                 int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
                                 const float* a_scale, float k1, float k2, float* o_scale, psam_stream_t stream);
 
+/* y [M, N] = act(x [M, K] W [N, K]^T + bias) + residual for M <= 64 rows (K % 16 == 0, rows 16-byte aligned; act: none / GELU / ReLU),
+ * exact fp32 products.  The decoder's token-side nn.Linear calls (7 output tokens per prompt): transformer.py:109-236. */
+int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
+                           float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
+
 /* Three-layer ReLU MLP on a few rows -- mask_decoder.py:189-211 (MLP), the hyper-networks :171-176 and the IoU head :180 in one launch
- * each.  Weights TRANSPOSED and stacked: w1t [M, din, dh], w2t [M, dh, dh], w3t [M, dh, dout]; biases [M, dh], [M, dh], [M, dout].
- * MLP m reads the row x + z*ldx + m*sx (z < Z) and writes dout values at out + z*ldo + m*so.  din, dh <= 1024. */
-int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float* w1t, const float* b1, const float* w2t, const float* b2,
-                  const float* w3t, const float* b3, float* out, int64_t ldo, int64_t so, int32_t Z, int32_t M, int32_t din, int32_t dh,
+ * each.  Weights stacked in the reference's [out, in] layout: w1 [M, dh, din], w2 [M, dh, dh], w3 [M, dout, dh]; biases [M, dh], [M, dh],
+ * [M, dout].  MLP m reads the row x + z*ldx + m*sx (z < Z) and writes dout values at out + z*ldo + m*so.  din, dh <= 1024, % 4 == 0. */
+int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float* w1, const float* b1, const float* w2, const float* b2,
+                  const float* w3, const float* b3, float* out, int64_t ldo, int64_t so, int32_t Z, int32_t M, int32_t din, int32_t dh,
                   int32_t dout, psam_stream_t stream);
 
 /* Same contraction for the decoder's token-sized problems (any hd, few queries or few keys).

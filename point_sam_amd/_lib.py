@@ -56,6 +56,7 @@ SIGNATURES = {
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
     "psam_gemm_f16x3p_hyper_planes": (i32, [i32, i32]),
     "psam_sum_planes": (i32, [ptr, i32, i64, i64, ptr, ptr]),
+    "psam_linear_skinny": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
     "psam_mlp3": (i32, [ptr, i64, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, ptr]),
     "psam_pos_l1": (i32, [ptr, ptr, ptr, ptr, i64, ptr]),
     "psam_fourier_pe": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i64, ptr, ptr]),

@@ -230,3 +230,74 @@ PSAM_API int32_t psam_linear(const float* x, int64_t ldx, const float* W, int64_
     return psam_gemm_f32(x, ldx, 0, 0, W, ldw, 0, 0, y, ldy, 0, 0, bias, residual, ldr, 0, 0, nullptr, 0, 0, M, N, K, 1, 1, 1.0f, act,
                          stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Linear layer on a handful of rows (M <= 64: the decoder's 7 output tokens per prompt -- q/k/v/out projections and the token MLP of
+// the two-way transformer, transformer.py:109-236): y = act(x W^T + b) + residual with exact fp32 products (v_mfma_f32_16x16x4_f32).
+// The general kernel above needs ~10 us for such a launch (one or two workgroups walking K in eight dependent slabs); here one
+// workgroup owns 16 output columns and all <= 64 rows (wave w: rows 16w .. 16w+15), so N / 16 workgroups run, and every lane fetches
+// float4s of its x row and its W row for 128 k at a time, double-buffered -- the whole K = 256 of a projection is two load rounds.
+// One float4 feeds four MFMAs: element e of lane group g is k-slot 16s + 4g + e for BOTH operands (a sum over k does not care about
+// the order of k).
+// ------------------------------------------------------------------------------------------------
+typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SK_CH = 8;      // float4 per operand per lane and round = 128 k
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                                                            const float* __restrict__ bias, const float* __restrict__ res, int64_t ldr,
+                                                            float* __restrict__ y, int64_t ldy, int M, int N, int K, int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int row = wave * 16 + r, col = blockIdx.x * 16 + r;
+    const float* xp = x + (int64_t)(row < M ? row : 0) * ldx + 4 * g;
+    const float* wp = W + (int64_t)(col < N ? col : 0) * ldw + 4 * g;
+    const bool rok = row < M, cok = col < N;
+    sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    sk_f32x4 xa[SK_CH], wb[SK_CH], xn[SK_CH], wn[SK_CH];
+    auto load = [&](sk_f32x4 (&xr)[SK_CH], sk_f32x4 (&wr)[SK_CH], int kc) {
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s) {
+            const int k = kc + 16 * s;
+            const bool in = k < K;      // K % 16 == 0: a 16-k slot is inside or outside as a whole
+            xr[s] = (in && rok) ? *reinterpret_cast<const sk_f32x4*>(xp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+            wr[s] = (in && cok) ? *reinterpret_cast<const sk_f32x4*>(wp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load(xa, wb, 0);
+    for (int kc = 0; kc < K; kc += 16 * SK_CH) {
+        const bool more = kc + 16 * SK_CH < K;
+        if (more) load(xn, wn, kc + 16 * SK_CH);
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s][e], wb[s][e], acc, 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < SK_CH; ++s) { xa[s] = xn[s]; wb[s] = wn[s]; }
+        }
+    }
+    // D layout: lane holds rows 4g .. 4g+3 of the wave's 16, column r
+    if (cok) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int orow = wave * 16 + 4 * g + v;
+            if (orow < M) {
+                float val = acc[v] + bv;
+                if (act == 1) val = gelu_erf(val);
+                else if (act == 2) val = fmaxf(val, 0.f);
+                if (res) val += res[(int64_t)orow * ldr + col];
+                y[(int64_t)orow * ldy + col] = val;
+            }
+        }
+    }
+}
+
+// y [M, N] = act(x [M, K] W [N, K]^T + bias) + residual for M <= 64, K % 16 == 0, 16-byte aligned rows (ld % 4 == 0).
+PSAM_API int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
+                                    float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, hipStream_t stream) {
+    PSAM_REQUIRE(x && W && y, PSAM_EINVAL, "psam_linear_skinny: null pointer");
+    PSAM_REQUIRE(M > 0 && M <= 64 && N > 0 && K > 0 && (K & 15) == 0 && act >= 0 && act <= 2, PSAM_EINVAL,
+                 "psam_linear_skinny: need 0 < M <= 64, K % 16 == 0, act in {none, gelu, relu}");
+    PSAM_REQUIRE(((ldx | ldw) & 3) == 0 && (((uintptr_t)x | (uintptr_t)W) & 15) == 0, PSAM_EALIGN, "psam_linear_skinny: rows must be 16-byte aligned");
+    hipLaunchKernelGGL(linear_skinny_kernel, dim3((unsigned)psam_cdiv(N, 16)), dim3(256), 0, stream, x, ldx, W, ldw, bias, residual, ldr, y, ldy, M, N, K, act);
+    return psam_launch_status("psam_linear_skinny: launch failed");
+}

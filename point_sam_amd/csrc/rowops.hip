@@ -645,54 +645,73 @@ PSAM_API int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, c
 // ------------------------------------------------------------------------------------------------
 // Three-layer ReLU MLP on a handful of rows: the decoder's hyper-networks and IoU head (mask_decoder.py:171-180,189-211), 256-wide
 // layers applied to one token row per prompt.  As GEMMs these were nine + three launches of a one-workgroup kernel (~10 us each, all
-// latency); here one workgroup per (prompt row, MLP) walks the three layers with the activations in LDS.  Weights are given
-// TRANSPOSED ([in][out], prepared once at model load) so that thread j, which owns output j, reads row k of W^T together with its
-// neighbours (coalesced) and needs no cross-lane reduction: y[j] = b[j] + sum_k x[k] W^T[k][j], fp32 FMAs in k order.
-// MLP m of a stack reads x + z*ldx + m*sx and uses the m-th [in][out] matrix of each stacked weight.
+// latency); here one workgroup per (prompt row, MLP) walks the three layers with the activations in LDS.  A wave takes 32 output rows
+// of W at a time: lane l multiplies its float4 of the input (k = 4l .. 4l+3 of each 256-wide chunk) with the same float4 of every
+// row -- 32 independent, fully coalesced 1 KiB loads in flight -- and the 64 per-lane partial sums of each output are added through a
+// wave-private LDS transpose (lane o sums row o: fixed order).  (A thread-per-output version over transposed weights was a chain of
+// dependent loads: 59 us per launch.)  MLP m of a stack reads x + z*ldx + m*sx and uses the m-th [out][in] matrix of each weight.
 // ------------------------------------------------------------------------------------------------
-constexpr int MLP3_MAXD = 1024;
-__global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ x, int64_t ldx, int64_t sx, const float* __restrict__ w1t,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2,
-                                                   const float* __restrict__ w3t, const float* __restrict__ b3, float* __restrict__ out, int64_t ldo,
+constexpr int MLP3_MAXD = 1024, MLP3_OB = 32;
+__global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ x, int64_t ldx, int64_t sx, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                   const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ out, int64_t ldo,
                                                    int64_t so, int din, int dh, int dout) {
-    __shared__ float s_a[MLP3_MAXD], s_b[MLP3_MAXD];
-    const int z = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_a[MLP3_MAXD], s_b[MLP3_MAXD];
+    __shared__ float s_red[4][MLP3_OB][65];
+    const int z = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xp = x + (int64_t)z * ldx + (int64_t)m * sx;
-    for (int i = tid; i < din; i += 256) s_a[i] = xp[i];
+    for (int i = tid; i < MLP3_MAXD; i += 256) s_a[i] = i < din ? xp[i] : 0.f;
     __syncthreads();
-    auto layer = [&](const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ wt, const float* __restrict__ b, int ni, int no,
-                     bool relu, bool global_out) {
-        for (int j = tid; j < no; j += 256) {
-            float a0 = b[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four partial sums: independent FMA chains, combined in a fixed order
-            int kk = 0;
-            for (; kk + 4 <= ni; kk += 4) {
-                a0 = fmaf(src[kk], wt[(int64_t)kk * no + j], a0);
-                a1 = fmaf(src[kk + 1], wt[(int64_t)(kk + 1) * no + j], a1);
-                a2 = fmaf(src[kk + 2], wt[(int64_t)(kk + 2) * no + j], a2);
-                a3 = fmaf(src[kk + 3], wt[(int64_t)(kk + 3) * no + j], a3);
+    auto layer = [&](const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ W, const float* __restrict__ b, int ni, int no,
+                     bool relu) {
+        for (int ob = wave * MLP3_OB; ob < no; ob += 4 * MLP3_OB) {
+            float part[MLP3_OB];
+#pragma unroll
+            for (int o = 0; o < MLP3_OB; ++o) part[o] = 0.f;
+            for (int kc = 0; kc < ni; kc += 256) {
+                const int k = kc + 4 * lane;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(src + (k < MLP3_MAXD ? k : 0));      // zero beyond ni (ni % 4 == 0)
+                const bool kin = k < ni;
+#pragma unroll
+                for (int o = 0; o < MLP3_OB; ++o) {
+                    const bool ok = kin && ob + o < no;
+                    const f32x4 wv = ok ? *reinterpret_cast<const f32x4*>(W + (int64_t)(ob + o) * ni + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    part[o] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+                }
             }
-            for (; kk < ni; ++kk) a0 = fmaf(src[kk], wt[(int64_t)kk * no + j], a0);
-            float y = (a0 + a1) + (a2 + a3);
-            if (relu) y = fmaxf(y, 0.f);
-            dst[global_out ? (int64_t)j : j] = y;
+#pragma unroll
+            for (int o = 0; o < MLP3_OB; ++o) s_red[wave][o][lane] = part[o];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < MLP3_OB && ob + lane < no) {
+                float y = b[ob + lane];
+                for (int l = 0; l < 64; ++l) y += s_red[wave][lane][l];
+                if (relu) y = fmaxf(y, 0.f);
+                dst[ob + lane] = y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     };
-    layer(s_a, s_b, w1t + (int64_t)m * din * dh, b1 + (int64_t)m * dh, din, dh, true, false);
+    layer(s_a, s_b, w1 + (int64_t)m * dh * din, b1 + (int64_t)m * dh, din, dh, true);
     __syncthreads();
-    layer(s_b, s_a, w2t + (int64_t)m * dh * dh, b2 + (int64_t)m * dh, dh, dh, true, false);
+    for (int i = dh + tid; i < MLP3_MAXD; i += 256) s_b[i] = 0.f;      // (the next layer reads whole float4 chunks)
     __syncthreads();
-    layer(s_a, out + (int64_t)z * ldo + (int64_t)m * so, w3t + (int64_t)m * dh * dout, b3 + (int64_t)m * dout, dh, dout, false, true);
+    layer(s_b, s_a, w2 + (int64_t)m * dh * dh, b2 + (int64_t)m * dh, dh, dh, true);
+    __syncthreads();
+    for (int i = dh + tid; i < MLP3_MAXD; i += 256) s_a[i] = 0.f;
+    __syncthreads();
+    layer(s_a, out + (int64_t)z * ldo + (int64_t)m * so, w3 + (int64_t)m * dout * dh, b3 + (int64_t)m * dout, dh, dout, false);
 }
 
-// x rows [Z] (row stride ldx; MLP m reads at + m * sx), stacked transposed weights w1t [M, din, dh], w2t [M, dh, dh], w3t [M, dh, dout],
-// biases [M, dh], [M, dh], [M, dout]; out rows [Z] (stride ldo; MLP m writes dout values at + m * so).
-PSAM_API int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float* w1t, const float* b1, const float* w2t, const float* b2,
-                           const float* w3t, const float* b3, float* out, int64_t ldo, int64_t so, int32_t Z, int32_t M, int32_t din, int32_t dh,
+// x rows [Z] (row stride ldx; MLP m reads at + m * sx), stacked weights in the reference's [out, in] layout w1 [M, dh, din], w2 [M, dh, dh],
+// w3 [M, dout, dh], biases [M, dh], [M, dh], [M, dout]; out rows [Z] (stride ldo; MLP m writes dout values at + m * so).  din, dh % 4 == 0.
+PSAM_API int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, float* out, int64_t ldo, int64_t so, int32_t Z, int32_t M, int32_t din, int32_t dh,
                            int32_t dout, hipStream_t stream) {
-    PSAM_REQUIRE(x && w1t && b1 && w2t && b2 && w3t && b3 && out, PSAM_EINVAL, "psam_mlp3: null pointer");
-    PSAM_REQUIRE(Z > 0 && M > 0 && M <= 65535 && din > 0 && dh > 0 && dout > 0 && din <= MLP3_MAXD && dh <= MLP3_MAXD, PSAM_EINVAL,
-                 "psam_mlp3: bad shape (din, dh <= 1024)");
-    hipLaunchKernelGGL(mlp3_kernel, dim3((unsigned)Z, (unsigned)M), dim3(256), 0, stream, x, ldx, sx, w1t, b1, w2t, b2, w3t, b3, out, ldo, so, din, dh, dout);
+    PSAM_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && out, PSAM_EINVAL, "psam_mlp3: null pointer");
+    PSAM_REQUIRE(Z > 0 && M > 0 && M <= 65535 && din > 0 && dh > 0 && dout > 0 && din <= MLP3_MAXD && dh <= MLP3_MAXD && (din & 3) == 0 && (dh & 3) == 0,
+                 PSAM_EINVAL, "psam_mlp3: bad shape (din, dh <= 1024 and multiples of 4)");
+    PSAM_REQUIRE((((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3) & 15) == 0, PSAM_EALIGN, "psam_mlp3: weights must be 16-byte aligned");
+    hipLaunchKernelGGL(mlp3_kernel, dim3((unsigned)Z, (unsigned)M), dim3(256), 0, stream, x, ldx, sx, w1, b1, w2, b2, w3, b3, out, ldo, so, din, dh, dout);
     return psam_launch_status("psam_mlp3: launch failed");
 }
 

@@ -126,7 +126,7 @@ class PointCloudSAM:
             blk.p = p
             self.blocks.append(blk)
         self.out_tokens = torch.cat([w["mask_decoder.iou_token.weight"], w["mask_decoder.mask_tokens.weight"]], 0).contiguous()
-        # hyper-networks and IoU head as one launch each (psam_mlp3): transposed, stacked weights; multimask uses MLPs 1.., single mask MLP 0
+        # hyper-networks and IoU head as one launch each (psam_mlp3): stacked weights; multimask uses MLPs 1.., single mask MLP 0
         mlp = lambda pfx: [(w[f"{pfx}.layers.{j}.weight"], w[f"{pfx}.layers.{j}.bias"]) for j in range(3)]
         hyp = [mlp(f"mask_decoder.output_hypernetworks_mlps.{i}") for i in range(cfg.num_mask_tokens)]
         self.hyper_mw = {True: ops.Mlp3Weights(hyp[1:]), False: ops.Mlp3Weights(hyp[:1])}

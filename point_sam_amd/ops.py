@@ -46,6 +46,7 @@ def _sampled_launch(launch, record):
 # matrix pipe with the exact 3-way operand split (fp32-accurate, see csrc/gemm_split.hip), small ones stay on "f32".
 GEMM_MODE = "f32"
 SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 128
+SKINNY_MAX_M = 64      # up to this many rows nn.Linear runs on the skinny kernel (exact fp32 products, like "f32")
 GEMM_MODES = ("f32", "bf16x6", "f16x3")
 # "f16x3" = large 2-D GEMMs against a prepared static weight (F16Weight) on the fp16 matrix pipe: power-of-two row scales + 2-way
 # fp16 split, 3 partial products (fp32-grade: same measured error vs fp64 as the f32 kernel, csrc/gemm_f16x3p.hip); batched and
@@ -363,6 +364,11 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         raise ValueError("fused GEMM extras exist only on the f16x3 packed-operand path")
     if x_packed:
         raise ValueError("x_packed activations can only feed an f16x3 GEMM with a prepared F16Weight (M above the split threshold)")
+    if (M <= SKINNY_MAX_M and K % 16 == 0 and rowbias is None and act in (ACT_NONE, ACT_GELU, ACT_RELU) and (ldx | ldw) % 4 == 0
+            and (xp | wp) % 16 == 0):
+        # a handful of rows (the decoder's output tokens): N / 16 workgroups, whole-K load rounds (csrc/gemm.hip linear_skinny_kernel)
+        check(_lib.load().psam_linear_skinny(xp, ldx, wp, ldw, _p(bias), rp, ldr, op, ldo, M, N, K, act, _stream()), "psam_linear_skinny")
+        return out
     _gemm_call((xp, ldx, 0, 0, wp, ldw, 0, 0, op, ldo, 0, 0, _p(bias), rp, ldr, 0, 0, rbp, ldrb, rowgroup, M, N, K, 1, 1, 1.0, act, _stream()),
                2.0 * M * N * K, M, N, K, "psam_gemm_f32")
     return out
@@ -430,15 +436,15 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
 
 
 class Mlp3Weights:
-    """Three Linear layers (ReLU between) of M stacked MLPs, transposed for psam_mlp3: w?t [M, in, out], b? [M, out]."""
+    """Three Linear layers (ReLU between) of M stacked MLPs for psam_mlp3: w? [M, out, in] (the reference's layout), b? [M, out]."""
 
     def __init__(self, layers):
         # layers: list over MLPs of [(W1, b1), (W2, b2), (W3, b3)] with W [out, in]
-        st = lambda i: (torch.stack([m[i][0].t().contiguous() for m in layers]).contiguous(), torch.stack([m[i][1] for m in layers]).contiguous())
-        (self.w1t, self.b1), (self.w2t, self.b2), (self.w3t, self.b3) = st(0), st(1), st(2)
-        self.M, self.din, self.dh = self.w1t.shape
-        self.dout = self.w3t.shape[2]
-        if self.w2t.shape[1:] != (self.dh, self.dh) or self.w3t.shape[1] != self.dh:
+        st = lambda i: (torch.stack([m[i][0] for m in layers]).contiguous(), torch.stack([m[i][1] for m in layers]).contiguous())
+        (self.w1, self.b1), (self.w2, self.b2), (self.w3, self.b3) = st(0), st(1), st(2)
+        self.M, self.dh, self.din = self.w1.shape
+        self.dout = self.w3.shape[1]
+        if self.w2.shape[1:] != (self.dh, self.dh) or self.w3.shape[2] != self.dh:
             raise ValueError("Mlp3Weights: layer shapes do not chain")
 
 
@@ -448,7 +454,7 @@ def mlp3(x, ldx, sx, mw: Mlp3Weights, out, ldo, so, Z):
     for t in (x, out):
         if not (t.is_cuda and t.dtype == torch.float32):
             raise _lib.PointSamHipError("mlp3: operands must be fp32 tensors on the GPU (there is no CPU fallback)")
-    check(_lib.load().psam_mlp3(x.data_ptr(), ldx, sx, mw.w1t.data_ptr(), mw.b1.data_ptr(), mw.w2t.data_ptr(), mw.b2.data_ptr(), mw.w3t.data_ptr(),
+    check(_lib.load().psam_mlp3(x.data_ptr(), ldx, sx, mw.w1.data_ptr(), mw.b1.data_ptr(), mw.w2.data_ptr(), mw.b2.data_ptr(), mw.w3.data_ptr(),
                                 mw.b3.data_ptr(), out.data_ptr(), ldo, so, Z, mw.M, mw.din, mw.dh, mw.dout, _stream()), "psam_mlp3")
     return out
 

@@ -716,6 +716,27 @@ def test_flash_attention_running_max_spike(ops):
     _close(out.view(B, L, hd), _sdpa(q, k, v, H, 1.0), 2e-5, what="flash spike")
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(56, 256, 256, 0, True), (56, 2048, 256, 2, False), (56, 256, 2048, 0, True), (7, 128, 256, 0, False),
+                                           (64, 100, 48, 1, True), (1, 16, 16, 0, False), (33, 40, 272, 2, False)])
+def test_linear_skinny(ops, M, N, K, act, res):
+    """nn.Linear on <= 64 rows (the decoder's token side) through linear_skinny_kernel, vs fp64; ops.linear routes there by itself."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    want = F.linear(x.double(), W.double(), b.double())
+    want = F.gelu(want) if act == 1 else (F.relu(want) if act == 2 else want)
+    if res:
+        want = want + r.double()
+    with ops.gemm_mode("f16x3"):
+        got = ops.linear(cu(x), cu(W), cu(b), act=act, residual=None if r is None else cu(r))
+    _close(got, want, 1e-5, rtol=1e-5, what="linear_skinny")      # fp32 accumulation over up to 2048 terms
+    # strided views (a column slice of a wider buffer, as the fused q|k|v buffers are used)
+    big = torch.randn(M, K + 32, generator=g)
+    with ops.gemm_mode("f32"):
+        got2 = ops.linear(cu(big)[:, 16:16 + K], cu(W), cu(b))
+    _close(got2, F.linear(big[:, 16:16 + K].double(), W.double(), b.double()), 3e-6, rtol=3e-6, what="linear_skinny strided")
+
+
 @pytest.mark.parametrize("Z,M,din,dh,dout,T", [(8, 3, 256, 256, 256, 7), (5, 1, 256, 256, 4, 7), (2, 2, 64, 96, 10, 3)])
 def test_mlp3_hypernetworks(ops, Z, M, din, dh, dout, T):
     """psam_mlp3 (the decoder's hyper-network MLPs / IoU head in one launch) vs fp64: MLP m reads token 1 + m of every prompt's row block."""
