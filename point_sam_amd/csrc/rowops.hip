@@ -480,6 +480,75 @@ __global__ __launch_bounds__(256) void interp3_kernel(const float* __restrict__ 
     }
 }
 
+// C == 256: R rows per wave, every load of all R rows issued before the first use.  With one row per wave the kernel is a chain of two
+// memory round trips (indices, then the three source rows) and ~10 cross-lane steps, and its time is that latency times the number
+// of occupancy rounds (262144 rows / 8192 resident waves = 32 rounds: 160 us); R independent chains per wave divide the rounds by R.
+template <int R>
+__global__ __launch_bounds__(256) void interp3_c256_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx3, const float* __restrict__ w3,
+                                                           float* __restrict__ out, int rep, int64_t Z, int N, int G, float* __restrict__ scale_out,
+                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps, int act) {
+    constexpr int C = 256;
+    const int lane = threadIdx.x & 63, c = lane * 4;
+    const int64_t total = Z * N, row0 = ((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6)) * R;
+    if (row0 >= total) return;
+    int64_t rows[R];
+    const float* p0[R]; const float* p1[R]; const float* p2[R];
+    float w0[R], w1[R], w2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        rows[r] = row0 + r < total ? row0 + r : total - 1;      // clamped duplicates are computed and not stored
+        const int64_t z = rows[r] / N, n = rows[r] % N, b = z / rep, o = (b * N + n) * 3;
+        const float* s = src + z * (int64_t)G * C + c;
+        p0[r] = s + idx3[o] * C; p1[r] = s + idx3[o + 1] * C; p2[r] = s + idx3[o + 2] * C;
+        w0[r] = w3[o]; w1[r] = w3[o + 1]; w2[r] = w3[o + 2];
+    }
+    f32x4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p0[r]), bb = *reinterpret_cast<const f32x4*>(p1[r]), cc = *reinterpret_cast<const f32x4*>(p2[r]);
+        v[r] = a * w0[r];      // same association as (x*w).sum(-2): ((a*w0) + b*w1) + c*w2
+        v[r] = v[r] + bb * w1[r];
+        v[r] = v[r] + cc * w2[r];
+    }
+    if (ln_g) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(ln_g + c), be = *reinterpret_cast<const f32x4*>(ln_b + c);
+        float mean[R], q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) mean[r] = wave_sum((v[r][0] + v[r][1]) + (v[r][2] + v[r][3])) * (1.0f / 256.0f);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { v[r] = v[r] - mean[r]; q[r] = wave_sum((v[r][0] * v[r][0] + v[r][1] * v[r][1]) + (v[r][2] * v[r][2] + v[r][3] * v[r][3])); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float rstd = 1.0f / sqrtf(q[r] * (1.0f / 256.0f) + ln_eps);
+            v[r] = v[r] * rstd * gg + be;
+            if (act == 1) v[r] = f32x4{gelu_erf(v[r][0]), gelu_erf(v[r][1]), gelu_erf(v[r][2]), gelu_erf(v[r][3])};
+            else if (act == 2) v[r] = f32x4{fmaxf(v[r][0], 0.f), fmaxf(v[r][1], 0.f), fmaxf(v[r][2], 0.f), fmaxf(v[r][3], 0.f)};
+        }
+    }
+    if (scale_out) {
+        float sc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) sc[r] = f16_row_scale(wave_max(fmaxf(fmaxf(fabsf(v[r][0]), fabsf(v[r][1])), fmaxf(fabsf(v[r][2]), fabsf(v[r][3])))));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            unsigned h0, l0, h1, l1;
+            psam_split2_f16(v[r][0], v[r][1], sc[r], h0, l0);
+            psam_split2_f16(v[r][2], v[r][3], sc[r], h1, l1);
+            const bool odd = lane & 1;
+            const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+            typedef unsigned ip_u32x4 __attribute__((ext_vector_type(4)));
+            if (row0 + r < total) {
+                if (lane == 0) scale_out[rows[r]] = sc[r];
+                *reinterpret_cast<ip_u32x4*>(out + rows[r] * C + c) = odd ? ip_u32x4{r0, r1, l0, l1} : ip_u32x4{h0, h1, r0, r1};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row0 + r < total) *reinterpret_cast<f32x4*>(out + rows[r] * C + c) = v[r];
+    }
+}
+
 // scale_out [Z*N] != NULL (C == 256 only): out receives the g8-packed rows (A operand of psam_gemm_f16x3p) and scale_out their scales.
 // ln_gamma / ln_beta != NULL (C == 256 only): LayerNorm(ln_eps) + activation `act` (PSAM_ACT_NONE / GELU / RELU) of every interpolated row.
 PSAM_API int32_t psam_interp3_ex(const float* src, const int64_t* idx3, const float* w3, float* out, int32_t rep, int64_t Z, int32_t N, int32_t G,
@@ -490,6 +559,12 @@ PSAM_API int32_t psam_interp3_ex(const float* src, const int64_t* idx3, const fl
     PSAM_REQUIRE(!scale_out || (C == 256 && ((uintptr_t)out & 31) == 0), PSAM_EINVAL, "psam_interp3: packed output needs C == 256 and 32-byte aligned rows");
     PSAM_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr) && (!ln_gamma || (C == 256 && (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0)) &&
                  act >= 0 && act <= 2 && (ln_gamma || act == 0), PSAM_EINVAL, "psam_interp3: row LayerNorm needs gamma and beta, C == 256, act in {none, gelu, relu}");
+    if (C == 256) {
+        constexpr int R = 4;
+        hipLaunchKernelGGL(interp3_c256_kernel<R>, dim3((unsigned)psam_cdiv(Z * N, 4 * R)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, scale_out,
+                           ln_gamma, ln_beta, ln_eps, act);
+        return psam_launch_status("psam_interp3: launch failed");
+    }
     hipLaunchKernelGGL(interp3_kernel, dim3((unsigned)psam_cdiv(Z * N, 4)), dim3(256), 0, stream, src, idx3, w3, out, rep, Z, N, G, C, scale_out, ln_gamma,
                        ln_beta, ln_eps, act);
     return psam_launch_status("psam_interp3: launch failed");
