@@ -702,42 +702,64 @@ __global__ __launch_bounds__(256) void patch_l1_kernel(const float* __restrict__
     for (int i = 0; i < CIN; ++i) { w0[i] = W[(2 * lane) * CIN + i]; w1[i] = W[(2 * lane + 1) * CIN + i]; }
     const float b0 = bias[2 * lane], b1 = bias[2 * lane + 1];
     const float g0 = lnw[2 * lane], g1 = lnw[2 * lane + 1], e0 = lnb[2 * lane], e1 = lnb[2 * lane + 1];
-    for (int64_t row = wave; row < rows; row += nwaves) {
-        const int k = (int)(row % K);
-        const int g = (int)((row / K) % G);
-        const int64_t bf = row / ((int64_t)K * G);
-        const int64_t b = bf / rep;
-        const int64_t n = knn_idx[(b * G + g) * K + k];
-        const float* p = xyz + (b * N + n) * 3;
-        const float* c = centers + (b * G + g) * 3;
-        float in[CIN];
-        in[0] = (p[0] - c[0]) * inv_radius; in[1] = (p[1] - c[1]) * inv_radius; in[2] = (p[2] - c[2]) * inv_radius;
-        const float* f = feats + (bf * N + n) * C;
+    // R rows per wave and iteration, the R dependent chains (index -> gather -> two reductions -> maximum) interleaved: the kernel's time
+    // is that chain's latency times the iterations per resident wave
+    constexpr int R = 2;
+    for (int64_t row0 = wave * R; row0 < rows; row0 += nwaves * R) {
+        float y0[R], y1[R];
 #pragma unroll
-        for (int i = 0; i < C; ++i) in[3 + i] = f[i];
-        if (CENTRAL) {
-            const float* fc = feats + (bf * N + center_idx[b * G + g]) * C;
+        for (int q = 0; q < R; ++q) {
+            const int64_t row = row0 + q < rows ? row0 + q : rows - 1;
+            const int k = (int)(row % K);
+            const int g = (int)((row / K) % G);
+            const int64_t bf = row / ((int64_t)K * G);
+            const int64_t b = bf / rep;
+            const int64_t n = knn_idx[(b * G + g) * K + k];
+            const float* p = xyz + (b * N + n) * 3;
+            const float* c = centers + (b * G + g) * 3;
+            float in[CIN];
+            in[0] = (p[0] - c[0]) * inv_radius; in[1] = (p[1] - c[1]) * inv_radius; in[2] = (p[2] - c[2]) * inv_radius;
+            const float* f = feats + (bf * N + n) * C;
 #pragma unroll
-            for (int i = 0; i < C; ++i) in[3 + C + i] = f[i] - fc[i];
+            for (int i = 0; i < C; ++i) in[3 + i] = f[i];
+            if (CENTRAL) {
+                const float* fc = feats + (bf * N + center_idx[b * G + g]) * C;
+#pragma unroll
+                for (int i = 0; i < C; ++i) in[3 + C + i] = f[i] - fc[i];
+            }
+            y0[q] = b0; y1[q] = b1;
+#pragma unroll
+            for (int i = 0; i < CIN; ++i) { y0[q] = fmaf(w0[i], in[i], y0[q]); y1[q] = fmaf(w1[i], in[i], y1[q]); }
         }
-        float y0 = b0, y1 = b1;
+        float mean[R], var[R];
 #pragma unroll
-        for (int i = 0; i < CIN; ++i) { y0 = fmaf(w0[i], in[i], y0); y1 = fmaf(w1[i], in[i], y1); }
-        const float mean = wave_sum(y0 + y1) * (1.0f / 128.0f);
-        const float a0 = y0 - mean, a1 = y1 - mean;
-        const float var = wave_sum(a0 * a0 + a1 * a1) * (1.0f / 128.0f);
-        const float r = 1.0f / sqrtf(var + eps);
-        const float o0 = gelu_erf(a0 * r * g0 + e0), o1 = gelu_erf(a1 * r * g1 + e1);
+        for (int q = 0; q < R; ++q) mean[q] = wave_sum(y0[q] + y1[q]) * (1.0f / 128.0f);
+#pragma unroll
+        for (int q = 0; q < R; ++q) { y0[q] -= mean[q]; y1[q] -= mean[q]; var[q] = wave_sum(y0[q] * y0[q] + y1[q] * y1[q]) * (1.0f / 128.0f); }
+        float o0[R], o1[R], sc[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const float r = 1.0f / sqrtf(var[q] + eps);
+            o0[q] = gelu_erf(y0[q] * r * g0 + e0); o1[q] = gelu_erf(y1[q] * r * g1 + e1);
+        }
         if (PACK) {
-            const float sc = f16_row_scale(wave_max(fmaxf(fabsf(o0), fabsf(o1))));
-            if (lane == 0) scale_out[row] = sc;
-            unsigned hi, lo;
-            psam_split2_f16(o0, o1, sc, hi, lo);
-            unsigned* orow = reinterpret_cast<unsigned*>(out) + row * 128 + (lane >> 2) * 8 + (lane & 3);   // group of 8 channels = 4 lanes
-            orow[0] = hi;
-            orow[4] = lo;
-        } else {
-            *reinterpret_cast<psam_f32x2*>(out + row * 128 + 2 * lane) = psam_f32x2{o0, o1};
+#pragma unroll
+            for (int q = 0; q < R; ++q) sc[q] = f16_row_scale(wave_max(fmaxf(fabsf(o0[q]), fabsf(o1[q]))));
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int64_t row = row0 + q;
+            if (row >= rows) break;
+            if (PACK) {
+                if (lane == 0) scale_out[row] = sc[q];
+                unsigned hi, lo;
+                psam_split2_f16(o0[q], o1[q], sc[q], hi, lo);
+                unsigned* orow = reinterpret_cast<unsigned*>(out) + row * 128 + (lane >> 2) * 8 + (lane & 3);   // group of 8 channels = 4 lanes
+                orow[0] = hi;
+                orow[4] = lo;
+            } else {
+                *reinterpret_cast<psam_f32x2*>(out + row * 128 + 2 * lane) = psam_f32x2{o0[q], o1[q]};
+            }
         }
     }
 }
