@@ -93,3 +93,22 @@ def test_synthetic_inputs_match_the_oracles_generator():
         assert torch.equal(a, b)
     xyz = synthetic_batch(3, 1000)[0]
     assert torch.allclose(xyz.norm(dim=2).max(dim=1).values, torch.ones(3))
+
+
+def test_mlp3_weight_stack_and_ln_bound():
+    """Host-side preparation for psam_mlp3 (stacked [M, out, in] weights, shape chaining) and the LayerNorm output bound that scales the
+    packed output of a row-LayerNorm epilogue (|LN(x) gamma + beta| <= sqrt(n - 1) max|gamma| + max|beta|)."""
+    import torch
+    from point_sam_amd import ops
+    g = torch.Generator().manual_seed(0)
+    mk = lambda i, o: (torch.randn(o, i, generator=g), torch.randn(o, generator=g))
+    mw = ops.Mlp3Weights([[mk(8, 12), mk(12, 12), mk(12, 5)] for _ in range(3)])
+    assert (mw.M, mw.din, mw.dh, mw.dout) == (3, 8, 12, 5) and mw.w1.shape == (3, 12, 8) and mw.w3.shape == (3, 5, 12) and mw.b3.shape == (3, 5)
+    with pytest.raises(ValueError):
+        ops.Mlp3Weights([[mk(8, 12), mk(10, 12), mk(12, 5)]])
+    gam, bet = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    x = torch.randn(1000, 256, generator=g) * torch.logspace(-3, 3, 1000)[:, None]
+    x[0] = 0; x[0, 7] = 1e6      # one-hot row: the extreme case of the bound
+    y = torch.nn.functional.layer_norm(x.double(), (256,), gam.double(), bet.double(), 1e-5)
+    assert y.abs().max().item() <= ops.row_ln_bound(gam, bet) * (1 + 1e-6)
+    assert y[0].abs().max().item() > 0.9 * (255 ** 0.5) * gam[7].abs().item() - bet.abs().max().item()
