@@ -8,14 +8,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from point_sam_amd import ops
 from gemm_p_bench import pack_g8, run_p
-for name, M, N, K in (("qkv", 4096, 3072, 1024), ("fc1", 4096, 5504, 1024), ("fc2", 4096, 1024, 2752)):
+CFGS = [int(c) for c in os.environ.get("GEMM_CFGS", "21").split(",")]      # with the ablation build: 100 + 32 * which + ablation bits (gemm_abl.py)
+SHAPES = (("qkv", 4096, 3072, 1024), ("fc1", 4096, 5504, 1024), ("fc2", 4096, 1024, 2752)) if len(CFGS) == 1 else (("qkv", 4096, 3072, 1024),)
+for name, M, N, K in SHAPES:
     y = torch.empty(M, N, device="cuda")
     for fill in (None, 0.0):
         x = torch.randn(M, K, device="cuda") if fill is None else torch.full((M, K), fill, device="cuda")
         W = torch.randn(N, K, device="cuda") / 32 if fill is None else torch.full((N, K), fill, device="cuda")
         sa, sw = ops.row_scale_f16(x), ops.row_scale_f16(W)
         xp, wp = pack_g8(x, sa), pack_g8(W, sw)
-        torch.cuda.synchronize()
-        for _ in range(30):
-            run_p(21, xp, sa, wp, sw, y, M, N, K)
-        torch.cuda.synchronize()
+        for cfg in CFGS:
+            torch.cuda.synchronize()
+            for _ in range(30):
+                run_p(cfg, xp, sa, wp, sw, y, M, N, K)
+            torch.cuda.synchronize()

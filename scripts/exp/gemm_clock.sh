@@ -21,6 +21,8 @@ out = ["f16x3p GEMM (128x128 tile, cfg 21), 30 back-to-back launches per (shape,
 groups = collections.defaultdict(list)
 for i, (d, (ns, name, grid), c) in enumerate(rows):
     groups[(grid, i // 30)].append((ns, c))
+import os
+ncfg = len(os.environ.get("GEMM_CFGS", "21").split(","))
 for (grid, gi), lst in sorted(groups.items(), key=lambda kv: kv[0][1]):
     lst = lst[10:]
     n = len(lst)
@@ -28,7 +30,7 @@ for (grid, gi), lst in sorted(groups.items(), key=lambda kv: kv[0][1]):
     g = lambda k: sum(x[1].get(k, 0.0) for x in lst) / n
     cyc = g("GRBM_GUI_ACTIVE") / 8
     wc = g("SQ_WAVE_CYCLES")
-    out.append(f"{grid:8d} {('random' if gi % 2 == 0 else 'zeros'):>6} {ns / 1e3:8.1f} {cyc:9.0f} {cyc / ns * 1e3:10.0f} {g('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * cyc):10.3f} "
+    out.append(f"{grid:8d} {('random' if (gi // ncfg) % 2 == 0 else 'zeros') + ('' if ncfg == 1 else '/' + os.environ['GEMM_CFGS'].split(',')[gi % ncfg]):>6} {ns / 1e3:8.1f} {cyc:9.0f} {cyc / ns * 1e3:10.0f} {g('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * cyc):10.3f} "
                f"{g('SQ_ACTIVE_INST_ANY') / wc:7.2f} {g('SQ_WAIT_INST_ANY') / wc:7.2f} {g('SQ_WAIT_ANY') / wc:7.2f}")
 open("gpurun_out/gemm_clock.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
