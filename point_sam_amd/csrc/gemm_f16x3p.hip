@@ -595,6 +595,10 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         case 21: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 4 waves, mid-slab stage release
         case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);     // 256x192, mid-slab stage release
         case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 8 waves of 32x64, 2 stages, mid-slab release (70 KiB): 2 per CU
+        // 30 / 31: three workgroups per CU.  Alone they win on the short launches (proj 38.4 -> 32.3 us, up.3 233 -> 205 us), in the pipelined
+        // bench (two batches' kernels co-scheduled) they lose 1.5 % (profiles/r02_gemm_tri_tile.txt): reachable through force_config only
+        case 30: return launch_f16x3p<2, 2, 2, 1, 2, 0, 0, 2>(p, stream);     // 128x64, 4 waves of 64x32, 48 KiB (no SwiGLU / fused extras)
+        case 31: return launch_f16x3p<2, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 64x128, 4 waves of 32x64, 48 KiB: 3 workgroups per CU
         case 40: return launch_f16x3p<4, 1, 1, 8, 2, 0, 0, 2>(p, stream);     // 128x256, 4 waves of 32x256 (whole rows per wave: row epilogues), 133 KiB
         default: break;
     }

@@ -12,7 +12,7 @@ NAMES = {0: "128x128 4w S2", 1: "128x128 4w S3", 2: "128x128 4w S3 LA", 3: "128x
          12: "256x192 8w S2", 13: "128x192 4w S2", 14: "256x256 8w(64x128) S2", 15: "256x256 8w(128x64) S2", 16: "256x128 4w(128x64) S2",
          20: "128x128 4w S2 PF1", 21: "128x128 4w S2 PF2", 22: "256x192 PF1", 23: "256x192 PF2", 24: "256x256 PF1", 25: "256x256 PF2", 26: "256x128 S3 PF1",
          27: "256x128 S2 PF2", 28: "128x128 8w S2 PF2", 29: "128x128 8w S4 LA PF1"}
-ODD_TN = (12, 23)
+ODD_TN = (12, 23, 30)
 # per-shape configuration maps for the two-stream layer loop (qkv, proj, fc1, fc2)
 COMBOS = {"all c0": (0, 0, 0, 0), "all c4": (4, 4, 4, 4), "all c14": (14, 14, 14, 14), "c12 c4 c14 c4": (12, 4, 14, 4), "c12 c9 c14 c9": (12, 9, 14, 9),
           "c14 c4 c14 c4": (14, 4, 14, 4), "c12 c4 c4 c4": (12, 4, 4, 4), "c13 c0 c13 c0": (13, 0, 13, 0), "c12 c16 c14 c16": (12, 16, 14, 16),
