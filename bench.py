@@ -7,12 +7,19 @@
 One step = one full pass (FPS -> kNN grouping -> mini-PointNet -> ViT-L -> two-way decoder -> per-point mask logits)
 over one batch of synthetic clouds resident in HBM: BASELINE.json configs[1] = ViT-L, N=32768, group_number=512,
 group_size=64, batch=8 per GPU, 1 point prompt, multimask output.  With N>1 every rank processes its own batch
-(weak scaling, clouds are independent) and the per-cloud logits are all-gathered over RCCL each step.
+(weak scaling, clouds are independent) and the per-cloud logits are all-gathered over RCCL each step, on a side stream.
+`python bench.py --gpus N` without a launcher spawns the N ranks itself (one process per GPU, 127.0.0.1 rendezvous).
 Prints ONE JSON line on rank 0.
+
+Besides the contract fields the line carries: `roofline` (dominant GEMM kernel, live HIP-event durations), `cpu_baseline` (the oracle on
+cloud 0 of the SAME batch, host cores), `parity` (the timed configuration's own output for cloud 0 against that oracle run), `sustained`
+(a second, much longer timed region), `tokenizer` (FPS us/iteration, distance evaluations per second against the VALU peak), `rccl`
+(N > 1: ranks seen and the time of the per-step all_gather).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -23,32 +30,11 @@ sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md, dense peaks at 256 CUs x 2.4 GHz
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16
+TRAFFIC_FILES = {"f16x3": ("r03_traffic.json", "r02_traffic.json"), "bf16x6": ("r01_v6_traffic.json",), "f32": ("r01_v6_traffic.json",)}
 
 
-def cpu_baseline(cfg, sd, N, seed, iters=3):
-    """The oracle (CPU restatement of the reference, PyTorch fp32 + C tokenizer) on a bounded sample: ONE cloud of the same workload,
-    one warm-up run + `iters` timed runs (median).  Reported next to the GPU number; never the thing measured above."""
-    from oracle import pointsam_oracle as O
-    xyz, rgb, prompt, labels = O.synthetic_batch(1, N, seed=seed)
-    cores = torch.get_num_threads()
-    O.fps(xyz[:, :4096], 16)  # build/load the C library outside the timed region
-    run = lambda: O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="reference")
-    run()
-    ts = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        run()
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    dt = ts[len(ts) // 2]
-    return {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port", "iterations": iters,
-            "seconds_per_cloud": {"median": round(dt, 3), "min": round(ts[0], 3), "max": round(ts[-1], 3)},
-            "sample": f"1 cloud of the workload (ViT-L, N={N}, 512x64, 1 prompt), oracle mode='reference' (torch.cdist+topk), 1 warm-up + {iters} timed runs, "
-                      f"median {dt:.1f} s; torch {torch.__version__}, {cores} threads"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -60,7 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clouds per GPU per step")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3"],
                     help="arithmetic of the large GEMMs; all three are fp32-grade and pass the same parity tests (DESIGN.md section 4)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle run (drops cpu_baseline and parity)")
     ap.add_argument("--streams", type=int, default=2, help="dense-stage HIP streams: batches in flight (1 = only the tokenizer of the next batch overlaps)")
     ap.add_argument("--no-pipeline", action="store_true", help="run FPS/kNN of each batch inline instead of one batch ahead on a side stream")
     ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")
@@ -69,208 +55,420 @@ def main():
     ap.add_argument("--no-graphs", dest="graphs", action="store_false", help="issue every kernel launch from Python (BatchPipeline)")
     ap.add_argument("--slots", type=int, default=3, help="batches in flight with --graphs (static buffer sets)")
     ap.add_argument("--no-stage-times", action="store_true", help="skip the per-stage timing pass after the timed region")
-    args = ap.parse_args()
+    ap.add_argument("--sustained-steps", type=int, default=400, help="steps of the second, long timed region (0 = skip); reported under `sustained`")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo run of this file's control flow with a stand-in pipeline (tests)
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------ launching the ranks
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_entry(rank, world, port, argv, cores):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if cores:      # one slice of the host cores per rank: the ranks' launch threads do not migrate onto each other
+        try:
+            os.sched_setaffinity(0, cores)
+        except OSError:
+            pass
+    worker(parse_args(argv))
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher: start N ranks (torch.multiprocessing spawn context), rank r on GPU r."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    per = len(avail) // args.gpus
+    procs = []
+    for r in range(args.gpus):
+        cores = set(avail[r * per:(r + 1) * per]) if per >= 1 else None
+        p = ctx.Process(target=_rank_entry, args=(r, args.gpus, port, argv, cores))
+        p.start()
+        procs.append(p)
+    code = 0
+    for p in procs:
+        p.join()
+        code = code or (p.exitcode or 0)
+    return code
+
+
+# ------------------------------------------------------------------------------------------ what runs a step
+class HipHarness:
+    """The product pipeline: GraphPipeline (default) / BatchPipeline / inline predict_masks on this rank's GPU."""
+
+    def __init__(self, args, rank, local):
+        from point_sam_amd.synthetic import synthetic_batch   # (oracle/ is only imported by the cpu_baseline leg)
+        from point_sam_amd import get_config, ops
+        from point_sam_amd.model import PointCloudSAM, BatchPipeline, GraphPipeline
+        from point_sam_amd.weights import random_state_dict
+        torch.cuda.set_device(local)
+        self.args, self.ops = args, ops
+        self.dev = torch.device("cuda", local)
+        self.cfg = get_config(args.config, args.groups, args.group_size)
+        self.sd = random_state_dict(self.cfg, seed=42)
+        self.model = PointCloudSAM(self.cfg, self.sd, self.dev, precision=args.precision)
+        self.seed = 42 + rank
+        self.batch = tuple(t.to(self.dev) for t in synthetic_batch(args.batch, args.points, seed=self.seed))
+        self.use_graphs = args.graphs and not args.no_pipeline
+        self.pipe = BatchPipeline(self.model, dense_streams=args.streams) if not args.no_pipeline else None
+        self.gpipe = GraphPipeline(self.model, *self.batch, None, True, slots=args.slots, dense_streams=args.streams) if self.use_graphs else None
+        self.main_stream = torch.cuda.current_stream(self.dev)
+        self.depth = self.gpipe.depth if self.use_graphs else (self.pipe.depth if self.pipe is not None else 1)
+        self.inline = self.pipe is None
+        self.prof = None
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(self.main_stream)
+        return e
+
+    def submit(self):
+        xyz, rgb, prompt, labels = self.batch
+        (self.gpipe if self.use_graphs else self.pipe).submit(xyz, rgb, prompt, labels, None, True)
+
+    def next(self):
+        if self.inline:
+            return self.model.predict_masks(*self.batch, None, True, validate=False)
+        return (self.gpipe if self.use_graphs else self.pipe).next()
+
+    def before_resubmit(self, gather):
+        # the slot's static outputs are still being read by the gather just started
+        if self.use_graphs and gather.stream is not None:
+            self.main_stream.wait_stream(gather.stream)
+
+    def finalize(self):
+        self.model.check_coordinate_range()
+
+    # ---- measurement legs after the timed region
+    def gemm_profile(self):
+        """Per-launch durations of the dominant kernel: every 3rd large-GEMM launch of one eager (un-graphed) pass, HIP events on the launch
+        stream, second half of the pass with the other dense stream held off (the duration is the kernel's own)."""
+        ops, prof = self.ops, []
+        pipe = self.pipe
+        if pipe is None:
+            from point_sam_amd.model import BatchPipeline
+            pipe = BatchPipeline(self.model, dense_streams=1)
+        xyz, rgb, prompt, labels = self.batch
+        n = 2
+        for k in range(n):
+            last = k == n - 1
+            if last:
+                others = [s for i, s in enumerate(pipe.dense) if i != pipe.count % len(pipe.dense)] if pipe.dense else []
+                ops._gemm_counter = 0
+                ops.GEMM_PROFILE, ops.GEMM_PROFILE_EVERY, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER = prof, 3, tuple(others), 70 if others else 0
+            try:
+                pipe.submit(xyz, rgb, prompt, labels, None, True)
+                if not pipe.dense:
+                    pipe.next()
+            finally:
+                if last:
+                    ops.GEMM_PROFILE, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER, ops.GEMM_PROFILE_EVERY = None, (), 0, 29
+        while len(pipe):
+            pipe.next()
+        torch.cuda.synchronize()
+        return prof
+
+    def stage_times(self):
+        from point_sam_amd.profiling import stage_times, tokenizer_metrics
+        a = self.args
+        st = stage_times(self.model, *self.batch, passes=3, warmup=1)
+        return st, tokenizer_metrics(st, a.batch, a.points, a.groups, a.group_size)
+
+    def cpu_baseline(self, out, iters=3):
+        """The oracle (CPU restatement of the reference, PyTorch fp32 + C tokenizer) on a bounded sample: cloud 0 of this very batch, one
+        warm-up run + `iters` timed runs (median).  Its logits are then the checker of the timed configuration's own output for that cloud
+        (`parity`).  Reported next to the GPU number; never the thing measured above."""
+        from oracle import pointsam_oracle as O
+        a = self.args
+        xyz, rgb, prompt, labels = (t[:1] for t in O.synthetic_batch(a.batch, a.points, seed=self.seed))
+        cores = torch.get_num_threads()
+        O.fps(xyz[:, :4096], 16)  # build/load the C library outside the timed region
+        run = lambda: O.predict_masks(self.sd, self.cfg, xyz, rgb, prompt, labels, None, True, mode="reference")
+        want = run()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        dt = ts[len(ts) // 2]
+        base = {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port", "iterations": iters,
+                "seconds_per_cloud": {"median": round(dt, 3), "min": round(ts[0], 3), "max": round(ts[-1], 3)},
+                "sample": f"cloud 0 of the timed batch (ViT-{a.config}, N={a.points}, {a.groups}x{a.group_size}, 1 prompt), oracle mode='reference' (torch.cdist+topk), "
+                          f"1 warm-up + {iters} timed runs, median {dt:.1f} s; torch {torch.__version__}, {cores} threads"}
+        masks, iou = out
+        em = float((masks[:1].float().cpu() - want[0]).abs().max())
+        ei = float((iou[:1].float().cpu() - want[1]).abs().max())
+        parity = {"checked": "cloud 0 of the last timed step's output (the graph/stream pipeline's own result) vs the oracle on the same inputs and weights",
+                  "max_abs_err_mask_logits": em, "max_abs_err_iou": ei, "tolerance": 1e-3, "ok": bool(em < 1e-3 and ei < 1e-3),
+                  "logit_scale": float(want[0].abs().max())}
+        return base, parity
+
+
+class StubHarness:
+    """CPU stand-in with the same interface (tests/test_bench_cpu.py): `depth` batches in flight, each step's "logits" are a known
+    function of (rank, step), so that the gathered results of every step can be checked for content and order."""
+
+    def __init__(self, args, rank, local):
+        self.args, self.rank, self.depth = args, rank, max(1, args.slots)
+        self.submitted, self.taken, self.queue = 0, 0, []
+        self.dev = torch.device("cpu")
+        self.use_graphs, self.prof = True, None
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return time.perf_counter()
+
+    def submit(self):
+        if len(self.queue) >= self.depth:
+            raise RuntimeError("stub: more batches in flight than slots")
+        self.queue.append(self.submitted)
+        self.submitted += 1
+
+    def next(self):
+        k = self.queue.pop(0)
+        self.taken += 1
+        B = self.args.batch
+        base = torch.arange(B, dtype=torch.float32).view(B, 1, 1) + 100.0 * self.rank + 10000.0 * k
+        return base.expand(B, 3, 16).contiguous(), base.view(B, 1).expand(B, 3).contiguous()
+
+    def before_resubmit(self, gather):
+        pass
+
+    def finalize(self):
+        pass
+
+    @staticmethod
+    def expected(world, B, k):
+        return torch.cat([torch.arange(B, dtype=torch.float32) + 100.0 * r + 10000.0 * k for r in range(world)])
+
+
+# ------------------------------------------------------------------------------------------ one rank
+def worker(args):
     from point_sam_amd import dist as psdist
-    rank, world, local = psdist.init_from_env()
+    rank, world, local = psdist.init_from_env(backend="gloo" if args.stub else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a launcher")
+    H = (StubHarness if args.stub else HipHarness)(args, rank, local)
+    B, total = args.batch, args.batch * world
+    side_gather = psdist.SideStreamGather(None if args.stub else H.dev)       # N > 1: the all_gather of a step's logits runs on its own stream
+    pending, checks = [], {"steps_checked": 0, "bad": 0}
 
-    from point_sam_amd.synthetic import synthetic_batch   # (oracle/ is only imported by the cpu_baseline leg below)
-    from point_sam_amd import get_config, ops
-    from point_sam_amd.model import PointCloudSAM
-    from point_sam_amd.weights import random_state_dict
+    def verify(out, k):
+        if args.stub and world > 1 and out is not None:
+            checks["steps_checked"] += 1
+            want = StubHarness.expected(world, B, k)
+            if out[0].shape[0] != total or not torch.equal(out[0][:, 0, 0], want) or not torch.equal(out[1][:, 0], want):
+                checks["bad"] += 1
 
-    cfg = get_config(args.config, args.groups, args.group_size)
-    sd = random_state_dict(cfg, seed=42)
-    model = PointCloudSAM(cfg, sd, dev, precision=args.precision)
-    B, N = args.batch, args.points
-    xyz, rgb, prompt, labels = synthetic_batch(B, N, seed=42 + rank)
-    xyz, rgb, prompt, labels = xyz.to(dev), rgb.to(dev), prompt.to(dev), labels.to(dev)
-    total = B * world
-
-    from point_sam_amd.model import BatchPipeline, GraphPipeline
-    use_graphs = args.graphs and not args.no_pipeline
-    pipe = BatchPipeline(model, dense_streams=args.streams) if not args.no_pipeline else None
-    gpipe = GraphPipeline(model, xyz, rgb, prompt, labels, None, True, slots=args.slots, dense_streams=args.streams) if use_graphs else None
-
-    side_gather = psdist.SideStreamGather(dev)       # N > 1: the all_gather of a step's logits runs on its own stream
-    pending = []
-
-    def finish(masks, iou):
+    def finish(masks, iou, k):
         """Starts the gather of this step's results (side stream) and completes the previous step's: the collective of step k overlaps
         the dense stage of the batches behind it.  Returns the newest COMPLETED (gathered) results."""
         if world == 1:
             return masks, iou
-        pending.append(side_gather.start((masks, iou), total))
-        return side_gather.finish(pending.pop(0)) if len(pending) > 1 else (masks, iou)
+        pending.append((side_gather.start((masks, iou), total), k))
+        if len(pending) > 1:
+            h, kk = pending.pop(0)
+            out = side_gather.finish(h)
+            verify(out, kk)
+            return out
+        return masks, iou
 
     def drain():
         out = None
         while pending:
-            out = side_gather.finish(pending.pop(0))
+            h, kk = pending.pop(0)
+            out = side_gather.finish(h)
+            verify(out, kk)
         return out
 
-    main_stream = torch.cuda.current_stream(dev)
+    counter = {"k": 0}
 
-    def mark(events):
+    def run_steps(n, events=None):
+        """n full passes, `depth` batches in flight: next() before the slot is submitted again."""
+        out = None
         if events is not None:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(main_stream)
-            events.append(e)
-
-    def run_graph_steps(n, events=None):
-        """n full passes through the captured graphs: `slots` batches in flight, next() before the slot is submitted again."""
-        out = None
-        mark(events)
-        for k in range(min(gpipe.depth, n)):
-            gpipe.submit(xyz, rgb, prompt, labels, None, True)
-        for k in range(n):
-            out = finish(*gpipe.next())
-            mark(events)
-            if k + gpipe.depth < n:
-                if side_gather.stream is not None:      # the slot's static outputs are still being read by the gather just started
-                    main_stream.wait_stream(side_gather.stream)
-                gpipe.submit(xyz, rgb, prompt, labels, None, True)
-        return out
-
-    def run_steps(n, prof=None, events=None):
-        """n full passes (every batch is tokenized, encoded and decoded inside this call), every launch issued from Python.  With the
-        pipeline the tokenizer stage of a step runs on its own stream ahead of the dense stage, and `pipe.depth` batches are in flight.
-        prof: sample the GEMM launches of the LAST step (every 3rd one, HIP events on the launch stream, the other dense stream held
-        off during a sampled launch)."""
-        def dense_call(k, fn):   # fn enqueues the dense stage of step k
-            if prof is None or k != n - 1:
-                return fn()
-            others = [s for i, s in enumerate(pipe.dense) if i != pipe.count % len(pipe.dense)] if (pipe is not None and pipe.dense) else []
-            # sampling starts in the second half of the step (the ~150 GEMM launches of a step: the encoder's 96 large ones come in
-            # block order): by then the previous batch has drained, so holding the other stream off costs no overlap
-            ops._gemm_counter = 0
-            ops.GEMM_PROFILE, ops.GEMM_PROFILE_EVERY, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER = prof, 3, tuple(others), 70 if others else 0
-            try:
-                return fn()
-            finally:
-                ops.GEMM_PROFILE, ops.GEMM_PROFILE_OTHERS, ops.GEMM_PROFILE_AFTER, ops.GEMM_PROFILE_EVERY = None, (), 0, 29
-        out = None
-        mark(events)
-        if pipe is None:
-            for k in range(n):
-                out = finish(*dense_call(k, lambda: model.predict_masks(xyz, rgb, prompt, labels, None, True, validate=False)))
-                mark(events)
+            events.append(H.event())
+        if getattr(H, "inline", False):
+            for _ in range(n):
+                out = finish(*H.next(), counter["k"]); counter["k"] += 1
+                if events is not None:
+                    events.append(H.event())
             return out
-        sub = lambda: pipe.submit(xyz, rgb, prompt, labels, None, True)
-        for k in range(min(pipe.depth, n)):
-            dense_call(k, sub) if pipe.dense else sub()
+        for _ in range(min(H.depth, n)):
+            H.submit()
         for k in range(n):
-            if k + pipe.depth < n:
-                dense_call(k + pipe.depth, sub) if pipe.dense else sub()
-            out = finish(*(pipe.next() if pipe.dense else dense_call(k, pipe.next)))
-            mark(events)
+            out = finish(*H.next(), counter["k"]); counter["k"] += 1
+            if events is not None:
+                events.append(H.event())
+            if k + H.depth < n:
+                H.before_resubmit(side_gather)
+                H.submit()
         return out
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        H.sync()
+
+    def timed(n, events=None):
+        fence()
+        t0 = time.perf_counter()
+        out = run_steps(n, events)
+        out = drain() or out                       # N > 1: the last step's gather completes inside the timed region
+        t_enq = time.perf_counter() - t0           # host time to issue every launch of the region (no sync inside)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=H.dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return out, el, t_enq
 
     if args.warmup:
-        run_graph_steps(args.warmup) if use_graphs else run_steps(args.warmup)
+        run_steps(args.warmup)
         drain()
-    prof = None if args.no_gemm_profile else []
     step_events = []
-    fence()
-    t0 = time.perf_counter()
-    # timed region: exactly --steps passes.  With graphs the per-launch GEMM sampling cannot sit inside a replay: it runs in one
-    # extra eager pass AFTER the timed region (same process, same workload, same kernels); without graphs it samples the last timed step.
-    out = run_graph_steps(args.steps, step_events) if use_graphs else run_steps(args.steps, prof, step_events)
-    out = drain() or out                       # N > 1: the last step's gather completes inside the timed region
-    t_enqueued = time.perf_counter() - t0      # host time to issue every launch of the timed region (no sync inside)
-    fence()
-    elapsed = time.perf_counter() - t0
-    model.check_coordinate_range()
+    # timed region: exactly --steps passes
+    out, elapsed, t_enqueued = timed(args.steps, step_events)
+    H.finalize()
     assert torch.isfinite(out[0]).all()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    gaps = sorted(a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:]))
+    keep = (out[0][:B].clone(), out[1][:B].clone()) if world == 1 else (out[0][rank * B:(rank + 1) * B].clone(), out[1][rank * B:(rank + 1) * B].clone())
+
+    if args.stub:
+        gaps = sorted(b - a for a, b in zip(step_events[:-1], step_events[1:]))
+        gaps = [g * 1e3 for g in gaps]
+    else:
+        gaps = sorted(a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:]))
     step_stats = {"median": round(gaps[len(gaps) // 2], 3), "min": round(gaps[0], 3), "max": round(gaps[-1], 3),
                   "note": "ms between consecutive step completions on the caller's stream (HIP events); the first steps of the region fill the pipeline"} if gaps else None
-    if use_graphs and prof is not None:
-        run_steps(2, prof)       # untimed eager pass for the per-launch GEMM durations (see above)
-        torch.cuda.synchronize()
-    stage_ms = tok_roof = None
-    if rank == 0 and not args.no_stage_times:
-        from point_sam_amd.profiling import stage_times, tokenizer_roofline
-        stage_ms = stage_times(model, xyz, rgb, prompt, labels, passes=3, warmup=1)
-        tok_roof = tokenizer_roofline(stage_ms, B, N, args.groups, args.group_size)
 
-    roofline = None
-    if prof:
-        # dominant kernel = the large-GEMM kernel of the selected precision: ALGORITHMIC flops (2*M*N*K) per launch divided
-        # by the measured launch duration (HIP events on the launch stream, sampled launches of the timed region)
-        kind = args.precision
-        sel = [(s.elapsed_time(e), f) for s, e, f, _, _, _, k in prof if k == kind and f >= 1e9]
-        if sel:
-            tot_ms, tot_fl = sum(m for m, _ in sel), sum(f for _, f in sel)
-            ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            if kind == "f32":
-                peak, kernel, note = F32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "f32-input MFMA dense peak"
-            elif kind == "f16x3":
-                peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-                kernel = "gemm_f16x3p_kernel (v_mfma_f32_32x32x16_f16; operands pre-packed as row-scaled hi|lo fp16, LDS-DMA ring; 3 partial products per fp32-grade product)"
-                note = ("fp32-equivalent peak of the scheme = fp16 dense MFMA peak 2500 TFLOP/s / 3 executed products; "
-                        f"executed matrix-pipe rate = {ach * 3:.0f} TFLOP/s = {ach * 3 / BF16_MFMA_PEAK_TFLOPS:.3f} of the fp16 peak")
-            else:
-                peak = BF16_MFMA_PEAK_TFLOPS / 6.0
-                kernel = "gemm_bf16x6_kernel (v_mfma_f32_32x32x16_bf16, 6 partial products per fp32-accurate product)"
-                note = ("fp32-equivalent peak of the scheme = bf16 dense MFMA peak 2500 TFLOP/s / 6 executed products; "
-                        f"executed matrix-pipe rate = {ach * 6:.0f} TFLOP/s = {ach * 6 / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak")
-            traffic = None
-            tfile = "r02_traffic.json" if kind == "f16x3" else "r01_v6_traffic.json"
-            try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
-                tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
-                key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "gemm_f16x3p_kernel"}.get(kind)
-                if key and key in tj:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                traffic = None
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "traffic_note": f"bytes/launch (launch-weighted mean over the kernel's tile configurations), rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
-                        "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
-                        "sampling": (("every 3rd GEMM launch of one eager (un-graphed) pass right after the timed region, HIP events on the launch stream" if use_graphs else
-                                      "every 3rd GEMM launch of the last step of the timed region, HIP events on the launch stream") +
-                                     ("; second half of that step only, when the previous batch has drained, and the other dense stream is held off during a sampled launch: the duration is the kernel's own" if (pipe is not None and pipe.depth > 1) else "")),
-                        "avg_launch_ms": round(tot_ms / len(sel), 4), "avg_launch_gflop": round(tot_fl / len(sel) / 1e9, 3)}
-            # whole-path figure of SURVEY.md 8(d): algorithmic flops of the path (3.72e11 per cloud at this workload) / step time
-            if args.config == "large" and N == 32768 and args.groups == 512 and args.group_size == 64:
-                roofline["whole_path_achieved"] = round(3.72e11 * total / world / (elapsed / args.steps) / 1e12, 2)
-                roofline["whole_path_frac"] = round(roofline["whole_path_achieved"] / peak, 4)
-            roofline["tokenizer"] = tok_roof
+    # second, long timed region: the same passes, enough of them that clock / power state is the sustained one
+    sustained = None
+    if args.sustained_steps > 0:
+        clocks = []
+        _, el2, _ = timed(args.sustained_steps)
+        if not args.stub:
+            from point_sam_amd.profiling import read_sclk_mhz
+            clocks = read_sclk_mhz()
+        sustained = {"steps": args.sustained_steps, "seconds": round(el2, 3), "value": round(total * args.sustained_steps / el2, 3), "unit": "point-clouds/s",
+                     "ms_per_step": round(el2 / args.sustained_steps * 1e3, 3), "vs_timed_region": round((total * args.sustained_steps / el2) / (total * args.steps / elapsed), 4),
+                     "sclk_mhz_after": clocks or None,
+                     "note": "same passes, run right after the contract's timed region with the same fences; `value` above stays the contract's K-step figure"}
+
+    # the collective on its own: ranks seen + time of the per-step gather of the logits
+    rccl = None
+    if world > 1:
+        ids = psdist.gather_results(torch.full((1,), float(rank), device=H.dev), world)
+        fence()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            h = side_gather.start(keep, total)
+            side_gather.finish(h)
+        fence()
+        rccl = {"ranks_seen": int(torch.unique(ids.cpu()).numel()), "gather_ms": round((time.perf_counter() - t0) / reps * 1e3, 4),
+                "gather_bytes_per_rank": int(keep[0].numel() * 4 + keep[1].numel() * 4), "backend": torch.distributed.get_backend(),
+                "note": "all_gather_into_tensor of one step's [B,3,N] logits + [B,3] IoU on the side stream, 10 back-to-back, host-timed between barriers"}
+
+    prof = stage_ms = tok = None
+    if not args.stub:
+        if not args.no_gemm_profile:
+            prof = H.gemm_profile()
+        if rank == 0 and not args.no_stage_times:
+            stage_ms, tok = H.stage_times()
+    roofline = build_roofline(args, prof, total, world, elapsed) if prof else None
 
     if rank == 0:
+        a = args
         res = {
-            "metric": "point-clouds/sec (encode+1-prompt decode)", "value": round(total * args.steps / elapsed, 3), "unit": "point-clouds/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "metric": "point-clouds/sec (encode+1-prompt decode)", "value": round(total * a.steps / elapsed, 3), "unit": "point-clouds/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (fp32 in/out/accumulate; large GEMMs as exact 3-way bf16 split x 6 MFMA products)",
-                      "f16x3": "f32 (fp32 in/out/accumulate; large GEMMs as row-scaled 2-way fp16 split x 3 MFMA products, fp32-grade error)"}[args.precision],
+                      "f16x3": "f32 (fp32 in/out/accumulate; large GEMMs as row-scaled 2-way fp16 split x 3 MFMA products, fp32-grade error)"}[a.precision],
             "data": "synthetic",
-            "config": {"workload": f"ViT-{args.config} N={N} g={args.groups}x{args.group_size} batch={B}/GPU 1 point prompt multimask",
-                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": pipe is not None,
-                       "batches_in_flight": (gpipe.depth if use_graphs else (pipe.depth if pipe is not None else 1)), "dense_streams": args.streams, "hip_graphs": use_graphs,
-                       "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3), "gemm_precision": args.precision, "weights": "seeded random init (no checkpoint offline)"},
-            "roofline": roofline,
-            "step_ms": step_stats,
-            "stage_ms": stage_ms,
+            "config": {"workload": f"ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={B}/GPU 1 point prompt multimask",
+                       "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": not a.no_pipeline,
+                       "batches_in_flight": H.depth, "dense_streams": a.streams, "hip_graphs": bool(H.use_graphs),
+                       "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "gemm_precision": a.precision, "weights": "seeded random init (no checkpoint offline)"},
+            "roofline": roofline, "step_ms": step_stats, "stage_ms": stage_ms, "tokenizer": tok, "sustained": sustained, "rccl": rccl,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, N, 42)
+        if args.stub:
+            res["config"]["stub"] = dict(checks, taken=H.taken)
+            res["data"] = "stub"
+        elif world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"], res["parity"] = H.cpu_baseline(keep)
         print(json.dumps(res), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def build_roofline(args, prof, total, world, elapsed):
+    # dominant kernel = the large-GEMM kernel of the selected precision: ALGORITHMIC flops (2*M*N*K) per launch divided
+    # by the measured launch duration (HIP events on the launch stream, sampled launches)
+    kind = args.precision
+    sel = [(s.elapsed_time(e), f) for s, e, f, _, _, _, k in prof if k == kind and f >= 1e9]
+    if not sel:
+        return None
+    tot_ms, tot_fl = sum(m for m, _ in sel), sum(f for _, f in sel)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    if kind == "f32":
+        peak, kernel, note = F32_MFMA_PEAK_TFLOPS, "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "f32-input MFMA dense peak"
+    elif kind == "f16x3":
+        peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+        kernel = "gemm_f16x3p / gemm_f16x3pp kernels (v_mfma_f32_32x32x16_f16; operands pre-packed as row-scaled hi|lo fp16, LDS-DMA ring; 3 partial products per fp32-grade product)"
+        note = ("fp32-equivalent peak of the scheme = fp16 dense MFMA peak 2500 TFLOP/s / 3 executed products; "
+                f"executed matrix-pipe rate = {ach * 3:.0f} TFLOP/s = {ach * 3 / BF16_MFMA_PEAK_TFLOPS:.3f} of the fp16 peak")
+    else:
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+        kernel = "gemm_bf16x6_kernel (v_mfma_f32_32x32x16_bf16, 6 partial products per fp32-accurate product)"
+        note = ("fp32-equivalent peak of the scheme = bf16 dense MFMA peak 2500 TFLOP/s / 6 executed products; "
+                f"executed matrix-pipe rate = {ach * 6:.0f} TFLOP/s = {ach * 6 / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak")
+    traffic = tfile = None
+    for cand in TRAFFIC_FILES[kind]:   # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (profiles/, see its _note)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            key = {"bf16x6": "void gemm_bf16x6_kernel<2, 2, 2, 2, true>", "f16x3": "gemm_f16x3p_kernel"}.get(kind)
+            if key and key in tj:
+                traffic, tfile = tj[key]["hbm_bytes_per_launch"], cand
+                break
+        except (OSError, ValueError, KeyError):
+            continue
+    roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": traffic, "traffic_note": f"bytes/launch (launch-weighted mean over the kernel's tile configurations), rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE (fabric requests, Infinity-Cache hits included), profiles/{tfile}" if traffic else None,
+                "kernel": kernel, "peak_note": note, "sampled_launches": len(sel),
+                "sampling": "every 3rd GEMM launch of one eager (un-graphed) pass right after the timed regions, HIP events on the launch stream; second half of that pass only, "
+                            "when the previous batch has drained, and the other dense stream is held off during a sampled launch: the duration is the kernel's own",
+                "avg_launch_ms": round(tot_ms / len(sel), 4), "avg_launch_gflop": round(tot_fl / len(sel) / 1e9, 3)}
+    # whole-path figure of SURVEY.md 8(d): algorithmic flops of the path (3.72e11 per cloud at this workload) / step time
+    if args.config == "large" and args.points == 32768 and args.groups == 512 and args.group_size == 64:
+        roofline["whole_path_achieved"] = round(3.72e11 * total / world / (elapsed / args.steps) / 1e12, 2)
+        roofline["whole_path_frac"] = round(roofline["whole_path_achieved"] / peak, 4)
+    return roofline
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":

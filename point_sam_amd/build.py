@@ -21,6 +21,7 @@ SOURCES = [
     ("gemm.hip", []),
     ("gemm_split.hip", []),
     ("gemm_f16x3p.hip", []),
+    ("gemm_f16x3pp.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("error.cpp", ["-x", "hip"]),

@@ -11,6 +11,7 @@
 //   * edge tiles: a compact rolled loop, one column per lane, every element bounds-checked.
 // C/D layout of v_mfma_f32_32x32x*: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 typedef float ep_f32x16 __attribute__((ext_vector_type(16)));
@@ -27,6 +28,84 @@ __device__ __forceinline__ void ep_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-row scalars of a wave tile (TM*32 rows), held lane -> row (row_base + 64 t + lane): the inverse A-row scale and, with a folded
+// LayerNorm, the row's mean and rstd.  Loaded ONCE per wave tile with coalesced loads and fetched per pass with a lane shuffle; together
+// with the lane's column constants (bias, inverse weight-row scales, folded-LayerNorm c) they form the epilogue's PREFETCH, which a
+// kernel issues BEFORE its K loop: the epilogue then starts with every operand it needs except the accumulators (and the residual rows)
+// already in registers.  (Measured on the 256x256 ping-pong tile, profiles/r03_epi_pmc.txt: 2 500 instructions per wave took 52 k cycles,
+// 33 k of them parked at s_waitcnt -- dependent 4-byte global loads inside every pass and one LDS round trip at a time.)
+template <int TM>
+struct EpRows {
+    static constexpr int NR = (TM * 32 + 63) / 64;
+    float rs[NR], mean[NR], rstd[NR];
+};
+template <int TM, bool SCALED, bool EXT, typename ArgsT>
+__device__ __forceinline__ EpRows<TM> gemm_epilogue_rows(const ArgsT& p, int row_base, int lane) {
+    EpRows<TM> o;
+#pragma unroll
+    for (int t = 0; t < EpRows<TM>::NR; ++t) {
+        int row = row_base + t * 64 + lane;
+        row = row < p.M ? row : p.M - 1;
+        o.rs[t] = 1.f; o.mean[t] = 0.f; o.rstd[t] = 1.f;
+        if (row >= 0) {
+            if constexpr (SCALED) o.rs[t] = inv_pow2(p.scaleA[row]);
+            if constexpr (EXT) { if (p.ln_c) { o.mean[t] = p.ln_mean[row]; o.rstd[t] = p.ln_rstd[row]; } }
+        }
+    }
+    return o;
+}
+
+// lane -> (row inside a pass, float4 column) mapping of the interior path: non-gated TN*8 float4 per row, gated TN*4 float4 of output per row
+template <int TN>
+struct EpLane {
+    bool swiglu, lane_on;
+    float alpha;
+    int c4n, rpp, np, rl0, c4, scol, pcol, ocol;
+    template <typename ArgsT>
+    __device__ __forceinline__ EpLane(const ArgsT& p, int col_base, int lane) {
+        swiglu = (TN % 2 == 0) && p.act == 3;
+        alpha = swiglu ? 1.f : p.alpha;
+        c4n = swiglu ? TN * 4 : TN * 8; rpp = 64 / c4n; np = 32 / rpp;          // rows per pass (1, 2, 4 or 8), np = 4 .. 32 passes per stripe
+        rl0 = lane / c4n; c4 = lane % c4n;
+        lane_on = rl0 < rpp;                                                    // TN = 3: 48 of the 64 lanes carry a float4
+        scol = swiglu ? ((c4 * 4) >> 5) * 64 + ((c4 * 4) & 31) : c4 * 4;       // staged column of the lane's (first) float4
+        pcol = col_base + scol;                                                // its column in N (packed, for the gate)
+        ocol = swiglu ? (col_base >> 1) + c4 * 4 : pcol;                       // output column
+    }
+};
+template <int TM, int TN, typename ArgsT>
+__device__ __forceinline__ bool gemm_epilogue_interior(const ArgsT& p, int row_base, int col_base, const float* C, const float* R) {
+    const bool vec_ok = ((p.ldc & 3) == 0) && (((uintptr_t)C & 15) == 0) && (!R || (((p.ldr & 3) == 0) && (((uintptr_t)R & 15) == 0))) &&
+                        (!p.rowbias || (((p.ldrb & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0))) && (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+    return vec_ok && row_base + TM * 32 <= p.M && col_base + TN * 32 <= p.N;   // wave-uniform
+}
+// option bits of a specialised pass loop (gemm_store_tile)
+enum : int { EP_SWIGLU = 1, EP_STATS = 2, EP_PACK = 4, EP_LNC = 8, EP_RES = 16, EP_ROWBIAS = 32, EP_GELU = 64, EP_RELU = 128, EP_GMAX = 256, EP_HYPER = 512,
+              EP_NOSTORE = 1024 };
+
+template <int TM>
+struct EpPre {
+    EpRows<TM> rows;
+    ep_f32x4 b0, b1, m0, m1, lnc;
+};
+template <int TM, int TN, bool SCALED, bool EXT, typename ArgsT>
+__device__ __forceinline__ EpPre<TM> gemm_epilogue_prefetch(const ArgsT& p, int row_base, int col_base, int lane, const float* C, const float* R) {
+    EpPre<TM> o;
+    const EpLane<TN> L(p, col_base, lane);
+    o.b0 = ep_f32x4{0.f, 0.f, 0.f, 0.f}; o.b1 = o.b0; o.lnc = o.b0;
+    o.m0 = ep_f32x4{L.alpha, L.alpha, L.alpha, L.alpha}; o.m1 = o.m0;
+    o.rows = gemm_epilogue_rows<TM, SCALED, EXT>(p, row_base, lane);
+    if (gemm_epilogue_interior<TM, TN>(p, row_base, col_base, C, R) && L.lane_on) {
+        if constexpr (EXT) { if (p.ln_c) o.lnc = ep_load4(p.ln_c + L.pcol); }
+        if (p.bias) { o.b0 = ep_load4(p.bias + L.pcol); if (L.swiglu) o.b1 = ep_load4(p.bias + L.pcol + 32); }
+        if constexpr (SCALED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o.m0[e] *= inv_pow2(p.scaleW[L.pcol + e]); if (L.swiglu) o.m1[e] *= inv_pow2(p.scaleW[L.pcol + 32 + e]); }
+        }
+    }
+    return o;
 }
 
 // ArgsT needs: M, N, act, alpha, bias, rowbias, ldrb, rowgroup, ldc, ldr.   C / R already offset for the batch.
@@ -54,46 +133,59 @@ __device__ __forceinline__ void ep_wave_sync() {
 //    with W' = W * gamma (columns), c = W' 1, bias = W beta + b.
 template <int TM, int TN, bool SCALED = false, bool EXT = false, typename ArgsT>
 __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], float* __restrict__ lw, int row_base, int col_base,
-                                                int lane, float* __restrict__ C, const float* __restrict__ R) {
+                                                int lane, float* __restrict__ C, const float* __restrict__ R, const EpPre<TM>* pre = nullptr) {
     const int r32 = lane & 31, h = lane >> 5;
     constexpr int LD = TN * 32 + 4;
-    const bool swiglu = (TN % 2 == 0) && p.act == 3;
-    const float alpha = swiglu ? 1.f : p.alpha;
-    const bool vec_ok = ((p.ldc & 3) == 0) && (((uintptr_t)C & 15) == 0) && (!R || (((p.ldr & 3) == 0) && (((uintptr_t)R & 15) == 0))) &&
-                        (!p.rowbias || (((p.ldrb & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0))) && (!p.bias || (((uintptr_t)p.bias & 15) == 0));
-    const bool interior = vec_ok && row_base + TM * 32 <= p.M && col_base + TN * 32 <= p.N;   // wave-uniform
-
-    // ---- per-lane constants of the interior path: non-gated TN*8 float4 per row, gated TN*4 float4 of output per row
-    const int c4n = swiglu ? TN * 4 : TN * 8, rpp = 64 / c4n, np = 32 / rpp;      // rows per pass (1, 2, 4 or 8), np = 4 .. 32 passes per stripe
-    const int rl0 = lane / c4n, c4 = lane % c4n;
-    const bool lane_on = rl0 < rpp;                                               // TN = 3: 48 of the 64 lanes carry a float4
-    const int scol = swiglu ? ((c4 * 4) >> 5) * 64 + ((c4 * 4) & 31) : c4 * 4;   // staged column of the lane's (first) float4
-    const int pcol = col_base + scol;                                            // its column in N (packed, for the gate)
-    const int ocol = swiglu ? (col_base >> 1) + c4 * 4 : pcol;                   // output column
-    ep_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, m0 = {alpha, alpha, alpha, alpha}, m1 = m0;
-    ep_f32x4 lnc = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EXT) { if (interior && lane_on && p.ln_c) lnc = ep_load4(p.ln_c + pcol); }
+    const bool interior = gemm_epilogue_interior<TM, TN>(p, row_base, col_base, C, R);   // wave-uniform
+    const EpLane<TN> L(p, col_base, lane);
+    const bool swiglu = L.swiglu, lane_on = L.lane_on;
+    const float alpha = L.alpha;
+    const int rpp = L.rpp, np = L.np, rl0 = L.rl0, c4 = L.c4, scol = L.scol, pcol = L.pcol, ocol = L.ocol;
+    [[maybe_unused]] const int c4n = L.c4n;
+    const EpPre<TM> own = pre ? *pre : gemm_epilogue_prefetch<TM, TN, SCALED, EXT>(p, row_base, col_base, lane, C, R);
+    const ep_f32x4 b0 = own.b0, b1 = own.b1, m0 = own.m0, m1 = own.m1, lnc = own.lnc;
+    const EpRows<TM>& rows = own.rows;
     constexpr bool FULLROW = EXT && TN == 8;
+    constexpr bool ALL_ON = TN != 3;       // 64 % (float4 per row) == 0: every lane carries a float4 of every pass
     constexpr bool HYPER = EXT && (TN == 8 || TN == 2);      // hyper products: full rows (one plane) or 64-column wave tiles (N / 64 partial planes)
     [[maybe_unused]] ep_f32x4 rg = {1.f, 1.f, 1.f, 1.f}, rbt = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FULLROW) { if (interior && p.row_ln_g) { rg = ep_load4(p.row_ln_g + pcol); rbt = ep_load4(p.row_ln_b + pcol); } }
-    if (interior && lane_on) {
-        if (p.bias) { b0 = ep_load4(p.bias + pcol); if (swiglu) b1 = ep_load4(p.bias + pcol + 32); }
-        if constexpr (SCALED) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { m0[e] *= inv_pow2(p.scaleW[pcol + e]); if (swiglu) m1[e] *= inv_pow2(p.scaleW[pcol + 32 + e]); }
-        }
-    }
     [[maybe_unused]] ep_f32x4 gm = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // running group maximum of this lane's 4 columns (EXT)
-    constexpr int NPMAX = TN * 8 > 32 ? 32 : (TN * 8 > 16 ? 16 : 8), NB = 2;   // NB = 4 doubles the epilogue register footprint (190 VGPRs) and costs a wave of occupancy
+    constexpr int NPMAX = TN * 8 > 32 ? 32 : (TN * 8 > 16 ? 16 : 8);
 
+    // one 32-row stripe of the wave tile; instantiated per stripe index (a rolled loop would index the accumulator array at run time and
+    // send all of it through scratch memory: seen with TM = 4)
+    auto stripe = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        // residual rows of the whole stripe and (when one row-bias row covers the stripe: rowgroup % 32 == 0) the row bias: in flight while the
+        // stripe is staged and its passes run
+        // (the small wave tiles run at three or four waves per SIMD and must stay inside 128 / 168 registers: they prefetch four passes' worth and
+        // fetch the rest, chunk by chunk, in the tail -- their co-resident waves cover that latency)
+        constexpr int RP = TM * TN <= 2 ? 4 : NPMAX;
+        ep_f32x4 res[RP];
+        ep_f32x4 rb_s = {0.f, 0.f, 0.f, 0.f};
+        const bool rb_uniform = p.rowbias && (p.rowgroup & 31) == 0;
+        auto load_res = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+            for (int q = 0; q < RP; ++q)
+                if (c0 + q < np) res[q] = ep_load4(R + (int64_t)(row_base + i * 32 + (c0 + q) * rpp + rl0) * p.ldr + ocol);
+        };
+        if (interior && lane_on) {
+            if (R) load_res(0);
+            if (rb_uniform) rb_s = ep_load4(p.rowbias + (int64_t)((row_base + i * 32) / p.rowgroup) * p.ldrb + pcol);
+        }
         // ---- stage this 32-row stripe (pure transposition)
+#ifdef PSAM_GEMM_ABLATE
+        if constexpr (EXT) { if (p.epi_abl & 2) goto staged; }
+#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) lw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + j * 32 + r32] = acc[i][j][r];
+#ifdef PSAM_GEMM_ABLATE
+    staged:
+        if constexpr (EXT) { if (p.epi_abl & 2) { float sum = 0.f; for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r]; if (sum == 123.456f) C[0] = sum; } }
+#endif
         ep_wave_sync();
         [[maybe_unused]] float row_mean = 0.f, row_rstd = 1.f;      // of row (lane & 31) of this stripe (FULLROW, row_ln)
         [[maybe_unused]] bool finalized = false;
@@ -136,36 +228,99 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
             }
         }
         if (interior) {
-#pragma unroll
-            for (int q0 = 0; q0 < NPMAX; q0 += NB) {     // batches of NB passes: loads first, then arithmetic and stores
-                if (q0 < np && lane_on) {
-                    ep_f32x4 res[NB], rb[NB];
-                    float rs[NB];
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        const int row = row_base + i * 32 + (q0 + q) * rpp + rl0;
-                        if (R) res[q] = ep_load4(R + (int64_t)row * p.ldr + ocol);
-                        if (p.rowbias) rb[q] = ep_load4(p.rowbias + (int64_t)(row / p.rowgroup) * p.ldrb + pcol);
-                        if constexpr (SCALED) rs[q] = inv_pow2(p.scaleA[row]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        const int rl = (q0 + q) * rpp + rl0;
-                        const int row = row_base + i * 32 + rl;
-                        ep_f32x4 v = ep_load4(lw + rl * LD + scol);
-                        if (!finalized) {
-                            if constexpr (SCALED) v *= rs[q];
-                            if constexpr (EXT) {
-                                if (p.ln_c) { v = (v * m0 - lnc * p.ln_mean[row]) * p.ln_rstd[row] + b0; } else v = v * m0 + b0;
-                            } else v = v * m0 + b0;
+            // ---- the passes of the stripe, as a ROLLED loop (one copy of the code per stripe, resident in the instruction cache after its first
+            // pass) that is SPECIALISED on what the launch asks of the epilogue.  History (256x256 ping-pong tile, qkv shape, 32 passes per wave;
+            // profiles/r03_epi_*.txt): fully unrolled with every option a run-time branch, 31 us of an 95 us kernel (each pass a separate cold copy
+            // of the code); rolled, 20 us -- of which 12 us were the ~110 instructions and ~15 scalar branches of ONE generic pass body and 5 us
+            // the stores.  The option set of a launch is fixed, so the loop is instantiated for the combinations the model's GEMMs use (F >= 0:
+            // every option test folds at compile time) and once generically (F < 0).
+            auto passes = [&](auto f_c) {
+                constexpr int F = decltype(f_c)::value;
+                const bool o_swiglu = F < 0 ? swiglu : bool(F & EP_SWIGLU);
+                const bool o_res = F < 0 ? (R != nullptr) : bool(F & EP_RES);
+                const bool o_rowbias = F < 0 ? (p.rowbias != nullptr) : bool(F & EP_ROWBIAS);
+                const bool o_rb_uniform = F < 0 ? rb_uniform : true;
+                const int o_act = F < 0 ? p.act : ((F & EP_GELU) ? 1 : ((F & EP_RELU) ? 2 : 0));
+                bool o_stats = false, o_pack = false, o_lnc = false, o_gmax = false, o_hyper = false, o_nostore = false;
+                if constexpr (EXT) {
+                    o_stats = F < 0 ? (p.stats != nullptr) : bool(F & EP_STATS);
+                    o_pack = F < 0 ? (p.pack_out != 0) : bool(F & EP_PACK);
+                    o_lnc = F < 0 ? (p.ln_c != nullptr) : bool(F & EP_LNC);
+                    o_gmax = F < 0 ? (p.gmax_out != nullptr) : bool(F & EP_GMAX);
+                    o_hyper = HYPER && (F < 0 ? (p.hyper != nullptr) : bool(F & EP_HYPER));
+                    o_nostore = F < 0 ? (p.no_store != 0) : bool(F & EP_NOSTORE);
+                }
+                // what happens to a finished value (after the residual): group maximum, write-back for the hyper row pass, packed or plain store
+                auto finish = [&](ep_f32x4 v, int rl, int row, float rsq) {
+                    if (!o_swiglu) {
+                        if constexpr (EXT) {
+                            if (o_gmax) gm = ep_f32x4{fmaxf(gm[0], v[0]), fmaxf(gm[1], v[1]), fmaxf(gm[2], v[2]), fmaxf(gm[3], v[3])};
                         }
-                        if (swiglu) {
-                            ep_f32x4 x = ep_load4(lw + rl * LD + scol + 32);
-                            if constexpr (SCALED) x *= rs[q];
+                        if constexpr (HYPER) {
+                            if (o_hyper) *reinterpret_cast<ep_f32x4*>(lw + rl * LD + scol) = v;      // finished value back in place for the row pass below
+                        }
+                    }
+                    bool stored = false;
+                    if constexpr (EXT) {
+                        if (o_pack) {      // g8-packed output with the bound-derived row scale (see the header of this function)
+                            const float bnd = p.out_k1 * rsq + p.out_k2;          // rsq = 1 / scaleA[row]
+                            const float so = f16_row_scale(o_swiglu ? bnd * bnd : bnd);
+                            if (c4 == 0 && col_base == 0) p.out_scale[row] = so;
+                            unsigned h0, l0, h1, l1;
+                            psam_split2_f16(v[0], v[1], so, h0, l0);
+                            psam_split2_f16(v[2], v[3], so, h1, l1);
+                            const bool odd = lane & 1;
+                            const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+                            typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+                            *reinterpret_cast<ep_u32x4*>(C + (int64_t)row * p.ldc + ocol) = odd ? ep_u32x4{r0, r1, l0, l1} : ep_u32x4{h0, h1, r0, r1};
+                            stored = true;
+                        }
+                    }
+                    if (o_nostore) stored = true;
+                    if (!stored) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
+                };
+                // operands of a pass that come through LDS (staged float4s, row scalars by lane shuffle: every lane takes part): fetched one pass
+                // AHEAD, so that their round trip runs under the arithmetic of the current pass
+                struct PassIn { ep_f32x4 v, x; float rsq, lmean, lrstd; };
+                auto fetch = [&](int q) {
+                    PassIn o;
+                    const int rl = q * rpp + rl0;
+                    const int srcl = ((i & 1) * 32 + rl) & 63;
+                    o.rsq = __shfl(rows.rs[i >> 1], srcl, 64);
+                    o.lmean = 0.f; o.lrstd = 1.f;
+                    if (o_lnc) { o.lmean = __shfl(rows.mean[i >> 1], srcl, 64); o.lrstd = __shfl(rows.rstd[i >> 1], srcl, 64); }
+                    o.v = ep_f32x4{0.f, 0.f, 0.f, 0.f}; o.x = o.v;
+                    if (ALL_ON || lane_on) {
+                        o.v = ep_load4(lw + rl * LD + scol);
+                        if (o_swiglu) o.x = ep_load4(lw + rl * LD + scol + 32);
+                    }
+                    return o;
+                };
+                PassIn nxt = fetch(0);
+                int np_run = np;
+#ifdef PSAM_GEMM_ABLATE
+                if constexpr (EXT) { if (p.epi_abl & 1) np_run = 0; }
+#endif
+#pragma unroll 1
+                for (int q = 0; q < np_run; ++q) {
+                    const PassIn cur = nxt;
+                    if (q + 1 < np) nxt = fetch(q + 1);
+                    const int rl = q * rpp + rl0;
+                    const int row = row_base + i * 32 + rl;
+                    const float rsq = cur.rsq;
+                    if (ALL_ON || lane_on) {
+                        ep_f32x4 v = cur.v;
+                        if (!finalized) {
+                            if constexpr (SCALED) v *= rsq;
+                            if (o_lnc) { v = (v * m0 - lnc * cur.lmean) * cur.lrstd + b0; } else v = v * m0 + b0;
+                        }
+                        if (o_swiglu) {
+                            ep_f32x4 x = cur.x;
+                            if constexpr (SCALED) x *= rsq;
                             x = x * m1 + b1;
                             v = ep_f32x4{silu(v[0]) * x[0], silu(v[1]) * x[1], silu(v[2]) * x[2], silu(v[3]) * x[3]};
                             if constexpr (EXT) {
-                                if (p.stats) {     // LayerNorm partials of this row over the wave's TN*16 gated columns (valid ones: < stat_cols)
+                                if (o_stats) {     // LayerNorm partials of this row over the wave's TN*16 gated columns (valid ones: < stat_cols)
                                     const int seg0 = col_base >> 1, nv = p.stat_cols - seg0 < TN * 16 ? (p.stat_cols - seg0 > 0 ? p.stat_cols - seg0 : 0) : TN * 16;
                                     float sm = 0.f;
 #pragma unroll
@@ -185,44 +340,64 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                                 }
                             }
                         } else {
-                            if (p.rowbias) v += rb[q];
+                            if (o_rowbias) v += o_rb_uniform ? rb_s : ep_load4(p.rowbias + (int64_t)(row / p.rowgroup) * p.ldrb + pcol);
                             if constexpr (FULLROW) {
                                 if (finalized) {      // LayerNorm over the 256 columns of this row (rpp == 1: row rl is wave-uniform)
                                     const float mean = __shfl(row_mean, rl, 64), rr = __shfl(row_rstd, rl, 64);
                                     v = (v - mean) * rr * rg + rbt;
                                 }
                             }
-                            if (p.act == 1) v = ep_f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
-                            else if (p.act == 2) v = ep_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                            if (R) v += res[q];
-                            if constexpr (EXT) {
-                                if (p.gmax_out) gm = ep_f32x4{fmaxf(gm[0], v[0]), fmaxf(gm[1], v[1]), fmaxf(gm[2], v[2]), fmaxf(gm[3], v[3])};
-                            }
-                            if constexpr (HYPER) {
-                                if (p.hyper) *reinterpret_cast<ep_f32x4*>(lw + rl * LD + scol) = v;      // finished value back in place for the row pass below
-                            }
+                            if (o_act == 1) v = ep_f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+                            else if (o_act == 2) v = ep_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                         }
-                        bool stored = false;
-                        if constexpr (EXT) {
-                            if (p.pack_out) {      // g8-packed output with the bound-derived row scale (see the header of this function)
-                                const float bnd = p.out_k1 * rs[q] + p.out_k2;          // rs = 1 / scaleA[row]
-                                const float so = f16_row_scale(p.act == 3 ? bnd * bnd : bnd);
-                                if (c4 == 0 && col_base == 0) p.out_scale[row] = so;
-                                unsigned h0, l0, h1, l1;
-                                psam_split2_f16(v[0], v[1], so, h0, l0);
-                                psam_split2_f16(v[2], v[3], so, h1, l1);
-                                const bool odd = lane & 1;
-                                const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
-                                typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
-                                *reinterpret_cast<ep_u32x4*>(C + (int64_t)row * p.ldc + ocol) = odd ? ep_u32x4{r0, r1, l0, l1} : ep_u32x4{h0, h1, r0, r1};
-                                stored = true;
-                            }
-                        }
-                        if constexpr (EXT) { if (p.no_store) stored = true; }
-                        if (!stored) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
+#ifdef PSAM_GEMM_ABLATE
+                        if constexpr (EXT) { if (p.epi_abl & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.456f) C[0] = v[0]; continue; } }
+#endif
+                        if (o_res) *reinterpret_cast<ep_f32x4*>(lw + rl * LD + scol) = v;      // parked: the residual rows (in flight since before the staging) are added below
+                        else finish(v, rl, row, rsq);
                     }
                 }
+                if (o_res) {     // residual add + store, unrolled over the prefetched rows (a handful of instructions per pass; each lane re-reads its own float4)
+#pragma unroll
+                    for (int c0 = 0; c0 < NPMAX; c0 += RP) {
+                        if (c0 > 0 && c0 < np && lane_on) load_res(c0);
+#pragma unroll
+                        for (int q = 0; q < RP; ++q) {
+                            if (c0 + q < np) {
+                                const int rl = (c0 + q) * rpp + rl0;
+                                const int srcl = ((i & 1) * 32 + rl) & 63;
+                                const float rsq = __shfl(rows.rs[i >> 1], srcl, 64);
+                                if (ALL_ON || lane_on) {
+                                    ep_f32x4 v = ep_load4(lw + rl * LD + scol);
+                                    v += res[q];
+                                    finish(v, rl, row_base + i * 32 + rl, rsq);
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            // option set of this launch -> its specialised instance (the FULLROW row-LayerNorm path and per-row row biases stay generic)
+            int opt = -1;
+            if (!finalized && (!p.rowbias || rb_uniform)) {
+                opt = (swiglu ? EP_SWIGLU : 0) | (R ? EP_RES : 0) | (p.rowbias ? EP_ROWBIAS : 0) | (!swiglu && p.act == 1 ? EP_GELU : 0) | (!swiglu && p.act == 2 ? EP_RELU : 0);
+                if constexpr (EXT) {
+                    opt |= (p.stats ? EP_STATS : 0) | (p.pack_out ? EP_PACK : 0) | (p.ln_c ? EP_LNC : 0) | (p.gmax_out ? EP_GMAX : 0) | ((HYPER && p.hyper) ? EP_HYPER : 0) |
+                           (p.no_store ? EP_NOSTORE : 0);
+                }
             }
+            using std::integral_constant;
+            if (opt == 0) passes(integral_constant<int, 0>{});                                                  // qkv, patch_proj, ...: bias only
+            else if (opt == EP_RES) passes(integral_constant<int, EP_RES>{});                                   // attention projection
+            else if (EXT && opt == (EP_SWIGLU | EP_STATS | EP_PACK)) passes(integral_constant<int, EP_SWIGLU | EP_STATS | EP_PACK>{});   // fc1 of the fused EVA02 MLP
+            else if (EXT && opt == (EP_LNC | EP_RES)) passes(integral_constant<int, EP_LNC | EP_RES>{});         // fc2 with the folded LayerNorm
+            else if (EXT && opt == (EP_PACK | EP_GMAX)) passes(integral_constant<int, EP_PACK | EP_GMAX>{});     // PatchEncoder conv1.3
+            else if (opt == EP_ROWBIAS) passes(integral_constant<int, EP_ROWBIAS>{});                           // PatchEncoder conv2.0 (x half)
+            else if (EXT && opt == (EP_GMAX | EP_NOSTORE)) passes(integral_constant<int, EP_GMAX | EP_NOSTORE>{});   // PatchEncoder conv2.3
+            else if (EXT && HYPER && opt == (EP_GELU | EP_HYPER | EP_NOSTORE)) passes(integral_constant<int, EP_GELU | EP_HYPER | EP_NOSTORE>{});   // upscaling MLP
+            else if (opt == EP_GELU) passes(integral_constant<int, EP_GELU>{});
+            else if (opt == EP_SWIGLU) passes(integral_constant<int, EP_SWIGLU>{});
+            else passes(integral_constant<int, -1>{});
             if constexpr (HYPER) {
                 if (p.hyper && !swiglu) {      // hyper-network dot products of the stripe's finished rows (hyper_rows % 32 == 0: one z per stripe)
                     // over this wave's TN*32 columns: the whole row (TN == 8), or plane col_base / 64 of N / 64 partial sums (psam_sum_planes adds them)
@@ -293,5 +468,10 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
             }
         }
         ep_wave_sync();   // the stripe is consumed before the next one overwrites it
-    }
+    };
+    stripe(std::integral_constant<int, 0>{});
+    if constexpr (TM > 1) stripe(std::integral_constant<int, 1>{});
+    if constexpr (TM > 2) stripe(std::integral_constant<int, 2>{});
+    if constexpr (TM > 3) stripe(std::integral_constant<int, 3>{});
+    static_assert(TM <= 4, "stripes instantiated for TM <= 4");
 }

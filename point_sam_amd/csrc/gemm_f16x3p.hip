@@ -24,37 +24,8 @@
 #include <type_traits>
 #include <cstdlib>
 #include "common.h"
+#include "gemm_f16x3p_args.h"
 #include "gemm_epilogue.h"
-
-typedef float pf32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
-
-struct F16PArgs {
-    const unsigned char* A; const unsigned char* W; float* C;
-    const float* bias; const float* residual; const float* rowbias;
-    const float* scaleA; const float* scaleW;
-    int64_t lda, ldw, ldc, ldr, ldrb;     // lda / ldw in 32-bit containers
-    int M, N, K, rowgroup, act;
-    float alpha;
-    int tiles_m, tiles_n, panel;      // panel: width (in column tiles) of the column panels the tile order walks row-major (f16x3p_panel)
-    // fused extras (psam_gemm_fuse_t, see gemm_epilogue.h): all null / 0 for the plain GEMM
-    float* out_scale; float out_k1, out_k2; int pack_out;
-    float* stats; int stat_cols, stat_segs;
-    const float* ln_mean; const float* ln_rstd; const float* ln_c;
-    float* gmax_out; int64_t gmax_ld; int gmax_k, no_store;
-    const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
-    const float* hyper; float* masks; int hyper_c, hyper_rows; int64_t hyper_pstride;
-};
-
-#define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
-// LDS-DMA of 16 bytes per lane: LDS[dst + lane * 16] = buffer[voff(lane) + soff].  The builtin exists only in the device compilation
-// (the host pass of this translation unit must still parse the kernel template to emit its launch stub).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define P_DMA16(rsrc, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, P_LDS(dst), 16, voff, soff, 0, 0)
-#else
-#define P_DMA16(rsrc, dst, voff, soff) ((void)(rsrc), (void)(dst), (void)(voff), (void)(soff))
-#endif
 
 // ABL (measurement builds only, -DPSAM_GEMM_ABLATE): 1 = no epilogue, 2 = no DMA after the prologue, 4 = no MFMA, 8 = every tile loads the
 // operand panels of tile (0, 0) (perfect L2 sharing), 16 = no fragment reads after the first slab.
@@ -430,31 +401,6 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
     return best;
 }
 
-// Column-panel width of the tile order (see the kernel).  Fabric-side traffic model per XCD, which owns ntiles / 8 consecutive tiles and
-// keeps about 2.5 MiB of operands in its L2: with panels of P column tiles the XCD's W panel (P * BN * K * 4 B) is fetched once per panel
-// it touches if it fits, once per group of concurrently running row bands if it does not; every A row band (BM * K * 4 B) of the panel
-// is fetched once.  The P with the least modelled traffic wins (ties: the widest).  PSAM_GEMM_PANEL overrides (0: plain row-major).
-// Measured (profiles/r02_gemm_panel_sweep.log): qkv 81.7 -> 79.6 us, fc1 143.4 -> 138.2 us, two-stream layer 303.9 -> 292 us.
-static int f16x3p_panel(int tiles_m, int tiles_n, int BM, int BN, int K) {
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("PSAM_GEMM_PANEL"); forced = e ? atoi(e) : -1; }
-    if (forced == 0) return tiles_n;
-    if (forced > 0) return forced < tiles_n ? forced : tiles_n;
-    const double l2 = 2.5 * 1048576.0, a_band = (double)BM * K * 4, w_col = (double)BN * K * 4;
-    const double chunk = (double)tiles_m * tiles_n / 8.0;
-    int best = tiles_n;
-    double best_cost = 1e300;
-    for (int P = tiles_n; P >= 1; P = P > 1 ? (P + 1) / 2 : 0) {
-        const double rows = chunk / P < tiles_m ? chunk / P : tiles_m;                 // row bands an XCD walks inside a panel
-        const double panels = chunk / ((double)tiles_m * P) > 1.0 ? chunk / ((double)tiles_m * P) : 1.0;   // panels it touches
-        const double wp = P * w_col, conc = 64.0 / P > 1.0 ? 64.0 / P : 1.0;           // ~64 tiles of an XCD in flight: conc row bands share a panel pass
-        const double w_cost = (wp <= l2 || rows <= conc) ? wp * panels : wp * (rows / conc) * panels;
-        const double cost = 8.0 * (w_cost + rows * a_band * panels);
-        if (cost < best_cost * 0.999) { best_cost = cost; best = P; }
-    }
-    return best;
-}
-
 template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
 static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
@@ -468,13 +414,10 @@ static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     p.tiles_m = (int)psam_cdiv(p.M, BM);
     p.tiles_n = (int)psam_cdiv(p.N, BN);
     p.panel = f16x3p_panel(p.tiles_m, p.tiles_n, BM, BN, p.K);
-    static bool attr_done = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
-            return PSAM_EINVAL;
-        }
-        attr_done = true;
+    static unsigned long long attr_done = 0;   // per device (bit = device id)
+    if (!f16x3p_reserve_lds(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>, lds, attr_done)) {
+        psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
+        return PSAM_EINVAL;
     }
     hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * NW), lds, stream, p);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
@@ -520,7 +463,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
-    p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0;
+    p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0; p.epi_abl = 0;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
     if (fuse && fuse->hyper && !fuse->row_ln_g) {
@@ -573,6 +516,18 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         if (fuse->gmax_out) { if (cfg != 4 && cfg != 14 && cfg != 21) cfg = (N % 256 == 0 && !fuse->stats) ? 14 : 4; }
         else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
     }
+    {   // ping-pong kernel (gemm_f16x3pp.hip) where it measured faster (f16x3pp_pick), or where a forced configuration names it
+        const bool w_stats = p.stats != nullptr, w_gmax = p.gmax_out != nullptr, w_hyper = p.hyper != nullptr;
+        const bool fused_any = w_stats || w_gmax || w_hyper || p.pack_out || p.ln_c;
+        const bool shape_ok = !fused_any || ((M & 255) == 0 && (N & 127) == 0);
+        const int forced = g_f16x3p_cfg;
+        if (forced >= 50 && forced < 100) { if (shape_ok && f16x3pp_supports(forced, act, w_stats, w_gmax, w_hyper)) cfg = forced; }
+        else if (forced < 0) {
+            const int pp = f16x3pp_pick(M, N, K, act);
+            if (pp >= 0 && shape_ok && f16x3pp_supports(pp, act, w_stats, w_gmax, w_hyper)) cfg = pp;
+        }
+    }
+    if (cfg >= 50 && (cfg < 100 || cfg >= 200)) return launch_f16x3pp(cfg, p, stream);
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2
         const int which = (cfg - 100) / 32, abl = (cfg - 100) % 32;

@@ -72,11 +72,15 @@ class SideStreamGather:
     With one process (no process group) start/finish pass the tensors through."""
 
     def __init__(self, device=None):
-        self.stream = torch.cuda.Stream(device=device) if (torch.cuda.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.enabled = dist.is_initialized() and dist.get_world_size() > 1
+        # GPU tensors: the collective gets its own HIP stream.  CPU tensors (gloo, tests): the gather runs in place, synchronously.
+        self.stream = torch.cuda.Stream(device=device) if (self.enabled and device is not None and torch.cuda.is_available()) else None
 
     def start(self, tensors, total: int):
-        if self.stream is None:
+        if not self.enabled:
             return tuple(tensors), None
+        if self.stream is None:
+            return tuple(gather_results(t, total) for t in tensors), None
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):

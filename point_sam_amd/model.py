@@ -684,13 +684,27 @@ class GraphPipeline:
                 st.out = model.decode(model.encode(st.coords, st.features, st.tok), st.pc, st.pl, st.pm, multimask_output)
             st.tok_done, st.done = torch.cuda.Event(), torch.cuda.Event()
             self.slots.append(st)
+        # what the graphs were captured for: submit() refuses anything else (a replay would silently compute on stale or mis-shaped buffers)
+        g = model.pc_encoder.patch_embed.grouper
+        self.captured = dict(num_groups=int(g.num_groups), group_size=int(g.group_size), precision=model.precision)
         torch.cuda.synchronize(dev)
 
     @torch.no_grad()
     def submit(self, coords, features, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True):
         if multimask_output != self.multimask:
             raise ValueError("GraphPipeline was captured for a fixed multimask_output")
+        g = self.model.pc_encoder.patch_embed.grouper
+        now = dict(num_groups=int(g.num_groups), group_size=int(g.group_size), precision=self.model.precision)
+        if now != self.captured:
+            raise ValueError(f"GraphPipeline was captured for {self.captured}, the model is now set to {now}: build a new pipeline")
         st = self.slots[self.count % self.depth]
+        for name, dst, src in (("coords", st.coords, coords), ("features", st.features, features), ("prompt_coords", st.pc, prompt_coords),
+                               ("prompt_labels", st.pl, prompt_labels), ("prompt_masks", st.pm, prompt_masks)):
+            if (dst is None) != (src is None):
+                raise ValueError(f"GraphPipeline: {name} was {'absent' if dst is None else 'present'} at capture and is {'absent' if src is None else 'present'} now "
+                                 "(the captured graph has a fixed set of inputs)")
+            if dst is not None and tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"GraphPipeline: {name} has shape {tuple(src.shape)}, the graphs were captured for {tuple(dst.shape)}")
         if st.busy:
             raise RuntimeError("GraphPipeline: the slot's previous batch has not been taken with next() yet (at most `slots` batches in flight)")
         ds = self.dense[self.count % len(self.dense)]

@@ -1,10 +1,9 @@
 """Measurement helpers shared by bench.py and scripts/stage_times.py: per-stage GPU times (HIP events) of the path, and the
-streaming-model byte counts of the tokenizer stages.  Not on the product path."""
+tokenizer stages' work rates against the VALU peak.  Not on the product path."""
 import torch
 
 from . import ops
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
 class StageTimer:
@@ -68,15 +67,55 @@ def stage_times(model, coords, features, prompt_coords, prompt_labels, passes: i
     return out
 
 
-def tokenizer_roofline(stage_ms: dict, B: int, N: int, G: int, K: int) -> dict:
-    """Streaming-model bytes of SURVEY.md 8(d) per batch / measured stage time, as a fraction of the HBM peak.  (The FPS kernel keeps
-    the cloud on chip -- registers + LDS -- so it does NOT move these bytes; the figure is the rate a streaming implementation would
-    need to match it.  kNN and 3-NN do stream the coordinates, through L2.)"""
-    model_bytes = {"fps": float(G) * N * 20, "knn": float(G) * N * 12 + float(G) * K * 8, "three_nn": float(N) * G * 12}
+# VALU peak for the distance work of the tokenizer kernels: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6e12 lane-operations per second
+# (MI355X_MICROARCH.md: fp32 vector peak 157.3 TFLOP/s = that many FMAs).  One squared distance with the oracle's operation order costs
+# 8 individually rounded operations (3 subtractions, 3 multiplications, 2 additions; no FMA: bit-exactness), so the chip can evaluate at
+# most 9.83e12 distances per second and one CU 3.84e10.
+CHIP_CUS = 256
+VALU_LANE_OPS_PER_CU = 4 * 32 * 2.4e9
+DIST_OPS = 8
+
+
+def tokenizer_metrics(stage_ms: dict, B: int, N: int, G: int, K: int) -> dict:
+    """What bounds the tokenizer kernels, per stage: distance evaluations per second against the VALU peak of the CUs the kernel occupies
+    (FPS: one workgroup = one CU per cloud for N <= 32768, N / 4096 per cloud above; kNN and 3-NN: the whole chip), and for FPS the time
+    per dependent iteration (the kernel is a chain of G iterations, each ending in a workgroup-wide arg-max: latency-bound).
+    These kernels keep their working set on chip, so HBM bytes are not their measure (the round-1/2 streaming-model figures were not
+    evidence: a kernel that does not move those bytes can "exceed" the HBM peak)."""
     out = {}
-    for k, per_cloud in model_bytes.items():
-        ms = stage_ms.get(k)
-        if ms:
-            gbs = per_cloud * B / (ms * 1e-3) / 1e9
-            out[k] = {"ms": ms, "streaming_model_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    peak_cu = VALU_LANE_OPS_PER_CU / DIST_OPS
+    def entry(ms, evals, cus, extra=None):
+        rate = evals / (ms * 1e-3)
+        e = {"ms": ms, "distance_evals": evals, "distance_evals_per_s": round(rate, 1), "cus_occupied": cus,
+             "valu_peak_evals_per_s": round(peak_cu * cus, 1), "frac_of_valu_peak": round(rate / (peak_cu * cus), 4)}
+        if extra:
+            e.update(extra)
+        return e
+    if stage_ms.get("fps"):
+        cus = B * max(1, N // 32768 * 8 if N > 32768 else 1)
+        out["fps"] = entry(stage_ms["fps"], float(B) * G * N, min(cus, CHIP_CUS),
+                           {"us_per_iteration": round(stage_ms["fps"] * 1e3 / G, 3), "iterations": G,
+                            "bound": "dependent iterations: distance update (VALU) + workgroup arg-max (DPP / LDS / barrier latency) per iteration"})
+    if stage_ms.get("knn"):
+        out["knn"] = entry(stage_ms["knn"], float(B) * G * N * 4, CHIP_CUS,
+                           {"bound": "VALU + L2 stream: 3 radix-select passes + 1 collect pass over the cloud per center (4 distance evaluations per point-center pair)"})
+    if stage_ms.get("three_nn"):
+        out["three_nn"] = entry(stage_ms["three_nn"], float(B) * N * G, CHIP_CUS, {"bound": "VALU: one distance + top-3 insertion per point-center pair"})
+    return out
+
+
+def read_sclk_mhz():
+    """Current shader clock of every GPU the kernel driver exposes (sysfs pp_dpm_sclk, the starred level), best effort: [] if unreadable."""
+    import glob
+    import re
+    out = []
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(f):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                    if m:
+                        out.append(int(m.group(1)))
+        except OSError:
+            pass
     return out

@@ -11,14 +11,20 @@ NAMES = {0: "128x128 4w S2", 1: "128x128 4w S3", 2: "128x128 4w S3 LA", 3: "128x
          6: "128x256 8w S3 LA", 7: "256x128 8w S2", 8: "128x128 8w(32x64) S2", 9: "128x128 8w(32x64) S4 LA", 10: "128x64 4w S2", 11: "128x64 4w S3 LA",
          12: "256x192 8w S2", 13: "128x192 4w S2", 14: "256x256 8w(64x128) S2", 15: "256x256 8w(128x64) S2", 16: "256x128 4w(128x64) S2",
          20: "128x128 4w S2 PF1", 21: "128x128 4w S2 PF2", 22: "256x192 PF1", 23: "256x192 PF2", 24: "256x256 PF1", 25: "256x256 PF2", 26: "256x128 S3 PF1",
-         27: "256x128 S2 PF2", 28: "128x128 8w S2 PF2", 29: "128x128 8w S4 LA PF1"}
+         27: "256x128 S2 PF2", 28: "128x128 8w S2 PF2", 29: "128x128 8w S4 LA PF1",
+         # ping-pong kernel (gemm_f16x3pp.hip): one 8-wave workgroup per CU, two wave groups one barrier interval apart
+         50: "pp 256x256 (128x64) S5 prio", 51: "pp 256x256 no prio", 52: "pp 256x256 static prio", 53: "pp 256x256 (64x128)", 59: "pp 256x256 S4", 60: "pp 256x256 S5 P2", 61: "pp 256x256 S4 P2",
+         55: "pp 256x128 S6 P2", 56: "pp 256x128 S6 P1", 57: "pp 128x128 S8 P2", 58: "pp 128x128 S4 P2"}
 ODD_TN = (12, 23, 30)
 # per-shape configuration maps for the two-stream layer loop (qkv, proj, fc1, fc2)
 COMBOS = {"all c0": (0, 0, 0, 0), "all c4": (4, 4, 4, 4), "all c14": (14, 14, 14, 14), "c12 c4 c14 c4": (12, 4, 14, 4), "c12 c9 c14 c9": (12, 9, 14, 9),
           "c14 c4 c14 c4": (14, 4, 14, 4), "c12 c4 c4 c4": (12, 4, 4, 4), "c13 c0 c13 c0": (13, 0, 13, 0), "c12 c16 c14 c16": (12, 16, 14, 16),
           "c14 c14 c14 c14": (14, 14, 14, 14), "c15 c4 c15 c4": (15, 4, 15, 4), "c12 c9 c4 c9": (12, 9, 4, 9), "c12 c0 c14 c0": (12, 0, 14, 0),
           "c23 c9 c25 c9": (23, 9, 25, 9), "c23 c28 c25 c28": (23, 28, 25, 28), "c23 c29 c27 c29": (23, 29, 27, 29), "c22 c29 c24 c29": (22, 29, 24, 29),
-          "c23 c9 c27 c9": (23, 9, 27, 9), "c23 c9 c4 c9": (23, 9, 4, 9)}
+          "c23 c9 c27 c9": (23, 9, 27, 9), "c23 c9 c4 c9": (23, 9, 4, 9), "all c21": (21, 21, 21, 21),
+          "c50 c57 c50 c57": (50, 57, 50, 57), "c50 c55 c50 c55": (50, 55, 50, 55), "c55 c57 c55 c57": (55, 57, 55, 57), "c50 c58 c50 c58": (50, 58, 50, 58),
+          "c50 c21 c50 c21": (50, 21, 50, 21), "c55 c57 c50 c57": (55, 57, 50, 57), "all c55": (55, 55, 55, 55), "all c50": (50, 50, 50, 50),
+          "c21 c57 c21 c57": (21, 57, 21, 57), "all c60": (60, 60, 60, 60), "c60 c57 c60 c57": (60, 57, 60, 57), "c60 c57 c55 c57": (60, 57, 55, 57), "c60 c21 c60 c21": (60, 21, 60, 21), "c21 c57 c55 c57": (21, 57, 55, 57)}
 
 
 def half_chip_streams():
@@ -139,6 +145,7 @@ def main():
     # one encoder layer's four GEMMs back to back, on one stream and on two streams at once (the bench keeps two batches in flight)
     layer = ["qkv", "proj", "fc1", "fc2"]
     s2 = torch.cuda.Stream()
+    s3 = torch.cuda.Stream()
     def layer_run(cfgmap):
         for nm in layer:
             xp, sa, wp, sw, y, M, N, K, bias, res, act = data[nm]
@@ -172,12 +179,23 @@ def main():
                         layer_run(cm)
             for hs in HALF:
                 cur.wait_stream(hs)
-        fns = {"one": one, "two": two}
+        def three():
+            cur = torch.cuda.current_stream()
+            for sx in (s2, s3):
+                sx.wait_stream(cur)
+                with torch.cuda.stream(sx):
+                    for _ in range(24):
+                        layer_run(cm)
+            for _ in range(24):
+                layer_run(cm)
+            cur.wait_stream(s2); cur.wait_stream(s3)
+        fns = {"one": one, "two": two, "three": three}
         if HALF:
             fns["halves"] = halves
         r = timeit(fns, rounds=3, iters=2)
         line = (f"  {cname:18s}: 1 stream {r['one'][0] / 24:7.1f} us/layer ({103.7e3 / (r['one'][0] / 24):4.0f} TF) | 2 streams {r['two'][0] / 48:7.1f} us/layer "
                 f"({103.7e3 / (r['two'][0] / 48):4.0f} TF)")
+        line += f" | 3 streams {r['three'][0] / 72:7.1f} us/layer ({103.7e3 / (r['three'][0] / 72):4.0f} TF)"
         if HALF:
             line += f" | 2 half-chip streams {r['halves'][0] / 48:7.1f} us/layer ({103.7e3 / (r['halves'][0] / 48):4.0f} TF)"
         print(line, flush=True)

@@ -525,6 +525,20 @@ def test_graph_pipeline_matches_eager(gpu):
     for (m1, i1), (m2, i2) in zip(want, got):
         assert torch.equal(m1, m2) and torch.equal(i1, i2)
     model.check_coordinate_range()
+    # a replay computes on the captured buffers only: anything the graphs were not captured for is refused, not silently ignored
+    xyz, rgb, prompt, labels = batches[0]
+    with pytest.raises(ValueError):
+        pipe.submit(xyz[:1], rgb[:1], prompt[:1], labels[:1])                                  # smaller batch (copy_ would broadcast it)
+    with pytest.raises(ValueError):
+        pipe.submit(xyz, rgb, prompt, labels, torch.zeros(2, 3000, device="cuda"))            # captured without a mask prompt
+    g = model.pc_encoder.patch_embed.grouper
+    g.num_groups = 32
+    with pytest.raises(ValueError):
+        pipe.submit(xyz, rgb, prompt, labels)                                                  # grouper changed after capture
+    g.num_groups = 64
+    pipe.submit(xyz, rgb, prompt, labels)
+    m, i = pipe.next()
+    assert torch.equal(m, want[0][0]) and torch.equal(i, want[0][1])
 
 
 def _nccl_worker(rank, world, port, q):
