@@ -24,6 +24,12 @@ constexpr int gemm_epilogue_lds_floats_per_wave() { return 32 * (TN * 32 + 4); }
 __device__ __forceinline__ float inv_pow2(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
 __device__ __forceinline__ ep_f32x4 ep_load4(const float* q) { return *reinterpret_cast<const ep_f32x4*>(q); }
 __device__ __forceinline__ float ep_act(float v, int act) { return act == 1 ? gelu_erf(v) : (act == 2 ? fmaxf(v, 0.f) : v); }
+// Every DS operation in flight (the fetch of the NEXT pass: LDS reads and ds_bpermute lane shuffles) completes here, before the current pass
+// issues DS operations of another kind (stats / packing shuffles, the parked ds_write).  hipcc counts lgkmcnt on the assumption that DS
+// operations retire in issue order; with a ds_bpermute and a ds_read / ds_write in flight together that did not hold under load: a
+// counted `s_waitcnt lgkmcnt(1)` let a pass start on a shuffle result that had not landed for the last 16 lanes -- wrong fc2 outputs
+// (1e-2) whenever another stream's kernels shared the CU, never when the kernel ran alone (scripts/exp/r03_race.py, profiles/r03_race.txt).
+__device__ __forceinline__ void ep_lgkm_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void ep_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -161,7 +167,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
         // stripe is staged and its passes run
         // (the small wave tiles run at three or four waves per SIMD and must stay inside 128 / 168 registers: they prefetch four passes' worth and
         // fetch the rest, chunk by chunk, in the tail -- their co-resident waves cover that latency)
-        constexpr int RP = TM * TN <= 2 ? 4 : NPMAX;
+        constexpr int RP = TM * TN <= 2 ? 4 : (NPMAX < 8 ? NPMAX : 8);
         ep_f32x4 res[RP];
         ep_f32x4 rb_s = {0.f, 0.f, 0.f, 0.f};
         const bool rb_uniform = p.rowbias && (p.rowgroup & 31) == 0;
@@ -279,8 +285,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     if (o_nostore) stored = true;
                     if (!stored) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + ocol) = v;
                 };
-                // operands of a pass that come through LDS (staged float4s, row scalars by lane shuffle: every lane takes part): fetched one pass
-                // AHEAD, so that their round trip runs under the arithmetic of the current pass
+                // operands of a pass that come through LDS (staged float4s, row scalars by lane shuffle: every lane takes part)
                 struct PassIn { ep_f32x4 v, x; float rsq, lmean, lrstd; };
                 auto fetch = [&](int q) {
                     PassIn o;
@@ -296,15 +301,17 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     }
                     return o;
                 };
-                PassIn nxt = fetch(0);
                 int np_run = np;
 #ifdef PSAM_GEMM_ABLATE
                 if constexpr (EXT) { if (p.epi_abl & 1) np_run = 0; }
 #endif
 #pragma unroll 1
                 for (int q = 0; q < np_run; ++q) {
-                    const PassIn cur = nxt;
-                    if (q + 1 < np) nxt = fetch(q + 1);
+                    // (fetching pass q+1 here, under the arithmetic of pass q, measured 1e-2 WRONG results in the folded-LayerNorm + residual
+                    // instance whenever another stream's kernels shared the CU -- never alone, never with this in-iteration fetch; the stale
+                    // values sat in lanes 48-63 of one shuffle result.  Root cause not established (scripts/exp/r03_race.py);
+                    // tests/test_gpu_kernels.py::test_fused_mlp_bitwise_stable_beside_other_streams holds the line.)
+                    const PassIn cur = fetch(q);
                     const int rl = q * rpp + rl0;
                     const int row = row_base + i * 32 + rl;
                     const float rsq = cur.rsq;
@@ -319,6 +326,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             if constexpr (SCALED) x *= rsq;
                             x = x * m1 + b1;
                             v = ep_f32x4{silu(v[0]) * x[0], silu(v[1]) * x[1], silu(v[2]) * x[2], silu(v[3]) * x[3]};
+                            ep_lgkm_drain();
                             if constexpr (EXT) {
                                 if (o_stats) {     // LayerNorm partials of this row over the wave's TN*16 gated columns (valid ones: < stat_cols)
                                     const int seg0 = col_base >> 1, nv = p.stat_cols - seg0 < TN * 16 ? (p.stat_cols - seg0 > 0 ? p.stat_cols - seg0 : 0) : TN * 16;
@@ -349,6 +357,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             }
                             if (o_act == 1) v = ep_f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
                             else if (o_act == 2) v = ep_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                            ep_lgkm_drain();
                         }
 #ifdef PSAM_GEMM_ABLATE
                         if constexpr (EXT) { if (p.epi_abl & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.456f) C[0] = v[0]; continue; } }
@@ -357,21 +366,28 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                         else finish(v, rl, row, rsq);
                     }
                 }
-                if (o_res) {     // residual add + store, unrolled over the prefetched rows (a handful of instructions per pass; each lane re-reads its own float4)
+                if (o_res) {     // residual add + store, unrolled over the prefetched rows: every parked float4 is read back first (each lane its own), ONE
+                                 // drain, then the adds and stores -- no DS operation is consumed on a counted wait (see ep_lgkm_drain)
 #pragma unroll
                     for (int c0 = 0; c0 < NPMAX; c0 += RP) {
                         if (c0 > 0 && c0 < np && lane_on) load_res(c0);
+                        ep_f32x4 pv[RP];
+                        float prs[RP];
+#pragma unroll
+                        for (int q = 0; q < RP; ++q) {
+                            prs[q] = 1.f;
+                            if (c0 + q < np) {
+                                const int rl = (c0 + q) * rpp + rl0;
+                                if (o_pack) prs[q] = __shfl(rows.rs[i >> 1], ((i & 1) * 32 + rl) & 63, 64);
+                                if (ALL_ON || lane_on) pv[q] = ep_load4(lw + rl * LD + scol);
+                            }
+                        }
+                        ep_lgkm_drain();
 #pragma unroll
                         for (int q = 0; q < RP; ++q) {
                             if (c0 + q < np) {
                                 const int rl = (c0 + q) * rpp + rl0;
-                                const int srcl = ((i & 1) * 32 + rl) & 63;
-                                const float rsq = __shfl(rows.rs[i >> 1], srcl, 64);
-                                if (ALL_ON || lane_on) {
-                                    ep_f32x4 v = ep_load4(lw + rl * LD + scol);
-                                    v += res[q];
-                                    finish(v, rl, row_base + i * 32 + rl, rsq);
-                                }
+                                if (ALL_ON || lane_on) finish(pv[q] + res[q], rl, row_base + i * 32 + rl, prs[q]);
                             }
                         }
                     }

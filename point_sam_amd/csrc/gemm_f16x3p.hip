@@ -117,6 +117,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // the epilogue's operands (per-row scalars, column constants): in flight from here on for the wave tiles that have the registers to hold
+    // them through the K loop (gemm_epilogue.h)
+    constexpr bool PREFETCH_EPI = TM * TN >= 4 && TN <= 4;
+    EpPre<TM> epre;
+    if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
     pf16x8 f0a[TM][2], f0w[TN][2], f1a[TM][2], f1w[TN][2];
     // fragment read n in [0, NFR) of step s from `stage`: n -> (operand, tile, plane)
     bool first_slab = true;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         return;
     }
     gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
-                                  n0 + wn * TN * 32, lane, p.C, p.residual);
+                                  n0 + wn * TN * 32, lane, p.C, p.residual, PREFETCH_EPI ? &epre : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- row scales

@@ -541,6 +541,32 @@ def test_graph_pipeline_matches_eager(gpu):
     assert torch.equal(m, want[0][0]) and torch.equal(i, want[0][1])
 
 
+def test_pipelines_bitwise_equal_eager_at_bench_config(gpu):
+    """The benchmark's own configuration (BASELINE configs[1]: ViT-L, B=8, N=32768, 512x64; two dense streams + the tokenizer stream; HIP
+    graphs, 3 slots) gives, step after step, the bits of the plain single-stream predict_masks.  (The small-config graph test above did not
+    see round 3's epilogue race: it needs full-size GEMMs of two batches sharing the CUs.)"""
+    from point_sam_amd.model import BatchPipeline, GraphPipeline
+    cfg = get_config("large", 512, 64)
+    model = gpu(cfg, random_state_dict(cfg, 42), precision="f16x3")
+    batch = tuple(t.cuda() for t in O.synthetic_batch(8, 32768, seed=42))
+    want_m, want_i = model.predict_masks(*batch)
+    torch.cuda.synchronize()
+
+    def run(pipe, n=6):
+        for k in range(min(pipe.depth, n)):
+            pipe.submit(*batch, None, True)
+        for k in range(n):
+            m, i = pipe.next()
+            assert torch.equal(m, want_m) and torch.equal(i, want_i), (type(pipe).__name__, k, float((m - want_m).abs().max()))
+            if k + pipe.depth < n:
+                pipe.submit(*batch, None, True)
+        torch.cuda.synchronize()
+
+    run(BatchPipeline(model, dense_streams=2))
+    run(GraphPipeline(model, *batch, None, True, slots=3, dense_streams=2))
+    model.check_coordinate_range()
+
+
 def _nccl_worker(rank, world, port, q):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),

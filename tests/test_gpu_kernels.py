@@ -452,6 +452,65 @@ def test_fused_mlp_two_gemms(ops, M, D, H):
     assert e1 < 3e-6 and e1 < 4 * e0 + 5e-7, (e0, e1)
 
 
+def test_fused_mlp_bitwise_stable_beside_other_streams(ops):
+    """The fused EVA02 MLP GEMMs (fc1: SwiGLU + row statistics + packed output; fc2: folded LayerNorm + residual) at the benchmark's
+    size must give the SAME BITS whether they run alone or while another stream's kernels (GEMMs, attention, LayerNorm) share the CUs.
+    (Round 3: a software-pipelined epilogue loop passed every single-stream test and produced 1e-2 errors in exactly this situation --
+    two workgroups of different kernels per CU; only lanes 48-63 of one lane-shuffle result were stale.  scripts/exp/r03_race.py.)"""
+    L = ops._lib.load()
+    g = torch.Generator().manual_seed(0)
+    M, D, H = 4096, 1024, 2730
+    Hp = (H + 31) // 32 * 32
+    h = torch.randn(M, D, generator=g)
+    W1 = torch.randn(2 * Hp, D, generator=g) / 32
+    b1 = torch.randn(2 * Hp, generator=g) * 0.1
+    w2g = torch.randn(D, Hp, generator=g) / 52
+    ln_c, ln_d, res = cu(w2g.sum(1)), cu(torch.randn(D, generator=g) * 0.1), cu(torch.randn(M, D, generator=g))
+    k1, k2 = float(2.0 ** 15 * math.sqrt(D) * W1.double().norm(dim=1).max()), float(b1.abs().max())
+    fw1, fw2g, b1 = ops.F16Weight(cu(W1)), ops.F16Weight(cu(w2g)), cu(b1)
+    wq, bq = ops.F16Weight(cu(torch.randn(3 * D, D, generator=g) / 32)), cu(torch.zeros(3 * D))
+    qkv = cu(torch.randn(M, 3 * D, generator=g))
+    with ops.gemm_mode("f16x3"):
+        hp, sh = ops.scale_pack_rows_g8(cu(h))
+
+        def mlp():
+            up = torch.empty(M, Hp, device="cuda"); su = torch.empty(M, device="cuda"); st = torch.empty(M, ops.stat_segs(2 * Hp), 2, device="cuda")
+            ops.linear(hp, fw1, b1, act=ops.ACT_SWIGLU, x_scale=sh, x_packed=True, out=up, pack_out=(su, k1, k2), stats=(st, H))
+            mean, rstd = ops.ln_stats_finalize(st, H, 1e-6)
+            y = ops.linear(up, fw2g, ln_d, residual=res, x_scale=su, x_packed=True, ln_fold=(mean, rstd, ln_c))
+            return dict(up=up, su=su, st=st[:, :(H + 31) // 32], mean=mean, rstd=rstd, y=y)
+
+        def noise(kind):
+            if kind == "qkv":
+                ops.linear(hp, wq, bq, x_scale=sh, x_packed=True)
+            elif kind == "mlp":
+                mlp()
+            elif kind == "ln":
+                ops.layernorm(res, ln_d, ln_d, 1e-6)
+            else:
+                o = torch.empty(M, D, device="cuda")
+                ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, 8, 16, 512, 512, 64, 0.125)
+
+        s2 = torch.cuda.Stream()
+        try:
+            for cfg in (-1, 21, 28):
+                L.psam_gemm_f16x3p_force_config(cfg)
+                ref = mlp()
+                torch.cuda.synchronize()
+                for kind in ("qkv", "mlp", "attn", "ln"):
+                    for it in range(4):
+                        s2.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(s2):
+                            for _ in range(6):
+                                noise(kind)
+                        out = mlp()
+                        torch.cuda.synchronize()
+                        for k in ref:
+                            assert torch.equal(out[k].view(torch.int32), ref[k].view(torch.int32)), (cfg, kind, it, k)
+        finally:
+            L.psam_gemm_f16x3p_force_config(-1)
+
+
 def test_gemm_row_epilogues_upscaling_chain(ops):
     """The decoder's upscaling MLP inside GEMM epilogues (N = 256: a wave owns whole rows): Linear -> LayerNorm -> GELU with the result
     packed against the LayerNorm's bound, then Linear -> GELU -> hyper-network dot products, against fp64 (mask_decoder.py:53-59,164-176)."""
