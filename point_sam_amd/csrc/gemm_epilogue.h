@@ -56,7 +56,7 @@ __device__ __forceinline__ EpRows<TM> gemm_epilogue_rows(const ArgsT& p, int row
         row = row < p.M ? row : p.M - 1;
         o.rs[t] = 1.f; o.mean[t] = 0.f; o.rstd[t] = 1.f;
         if (row >= 0) {
-            if constexpr (SCALED) o.rs[t] = inv_pow2(p.scaleA[row]);
+            if constexpr (SCALED) o.rs[t] = p.scaleA[row];      // RAW scale (a power of two): inverted where it is used, so that nothing waits for this load early
             if constexpr (EXT) { if (p.ln_c) { o.mean[t] = p.ln_mean[row]; o.rstd[t] = p.ln_rstd[row]; } }
         }
     }
@@ -101,14 +101,14 @@ __device__ __forceinline__ EpPre<TM> gemm_epilogue_prefetch(const ArgsT& p, int 
     EpPre<TM> o;
     const EpLane<TN> L(p, col_base, lane);
     o.b0 = ep_f32x4{0.f, 0.f, 0.f, 0.f}; o.b1 = o.b0; o.lnc = o.b0;
-    o.m0 = ep_f32x4{L.alpha, L.alpha, L.alpha, L.alpha}; o.m1 = o.m0;
+    o.m0 = ep_f32x4{1.f, 1.f, 1.f, 1.f}; o.m1 = o.m0;      // RAW weight-row scales (1 when not SCALED): alpha / scale is formed in gemm_store_tile
     o.rows = gemm_epilogue_rows<TM, SCALED, EXT>(p, row_base, lane);
     if (gemm_epilogue_interior<TM, TN>(p, row_base, col_base, C, R) && L.lane_on) {
         if constexpr (EXT) { if (p.ln_c) o.lnc = ep_load4(p.ln_c + L.pcol); }
         if (p.bias) { o.b0 = ep_load4(p.bias + L.pcol); if (L.swiglu) o.b1 = ep_load4(p.bias + L.pcol + 32); }
         if constexpr (SCALED) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o.m0[e] *= inv_pow2(p.scaleW[L.pcol + e]); if (L.swiglu) o.m1[e] *= inv_pow2(p.scaleW[L.pcol + 32 + e]); }
+            for (int e = 0; e < 4; ++e) { o.m0[e] = p.scaleW[L.pcol + e]; if (L.swiglu) o.m1[e] = p.scaleW[L.pcol + 32 + e]; }
         }
     }
     return o;
@@ -149,7 +149,10 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     const int rpp = L.rpp, np = L.np, rl0 = L.rl0, c4 = L.c4, scol = L.scol, pcol = L.pcol, ocol = L.ocol;
     [[maybe_unused]] const int c4n = L.c4n;
     const EpPre<TM> own = pre ? *pre : gemm_epilogue_prefetch<TM, TN, SCALED, EXT>(p, row_base, col_base, lane, C, R);
-    const ep_f32x4 b0 = own.b0, b1 = own.b1, m0 = own.m0, m1 = own.m1, lnc = own.lnc;
+    const ep_f32x4 b0 = own.b0, b1 = own.b1, lnc = own.lnc;
+    ep_f32x4 m0, m1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m0[e] = alpha * inv_pow2(own.m0[e]); m1[e] = alpha * inv_pow2(own.m1[e]); }
     const EpRows<TM>& rows = own.rows;
     constexpr bool FULLROW = EXT && TN == 8;
     constexpr bool ALL_ON = TN != 3;       // 64 % (float4 per row) == 0: every lane carries a float4 of every pass
@@ -291,7 +294,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     PassIn o;
                     const int rl = q * rpp + rl0;
                     const int srcl = ((i & 1) * 32 + rl) & 63;
-                    o.rsq = __shfl(rows.rs[i >> 1], srcl, 64);
+                    o.rsq = inv_pow2(__shfl(rows.rs[i >> 1], srcl, 64));
                     o.lmean = 0.f; o.lrstd = 1.f;
                     if (o_lnc) { o.lmean = __shfl(rows.mean[i >> 1], srcl, 64); o.lrstd = __shfl(rows.rstd[i >> 1], srcl, 64); }
                     o.v = ep_f32x4{0.f, 0.f, 0.f, 0.f}; o.x = o.v;
@@ -378,7 +381,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             prs[q] = 1.f;
                             if (c0 + q < np) {
                                 const int rl = (c0 + q) * rpp + rl0;
-                                if (o_pack) prs[q] = __shfl(rows.rs[i >> 1], ((i & 1) * 32 + rl) & 63, 64);
+                                if (o_pack) prs[q] = inv_pow2(__shfl(rows.rs[i >> 1], ((i & 1) * 32 + rl) & 63, 64));
                                 if (ALL_ON || lane_on) pv[q] = ep_load4(lw + rl * LD + scol);
                             }
                         }
