@@ -213,6 +213,15 @@ int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const f
                                 int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
                                 const float* a_scale, float k1, float k2, float* o_scale, psam_stream_t stream);
 
+/* Self-attention on PRE-PACKED operands (head dim 64): qkv [B*L, ld] holds every row's q | k | v (column blocks of D = H*64 containers) in
+ * the g8-packed hi|lo fp16 form of psam_gemm_f16x3p, all rows with ONE power-of-two scale (sc[b*L] is read) -- what the qkv GEMM writes with
+ * psam_gemm_fuse_t {pack_out = 1, out_k1 = 0, out_k2 = an a-priori bound of |q|, |k|, |v|}.  Replaces the SDPA call of timm's EvaAttention
+ * (pc_sam/model/pc_encoder.py:138-139) together with the conversions the fp32-input kernels above do per tile: K / V tiles move global -> LDS
+ * by LDS-DMA, V is transposed on read (ds_read_b64_tr_b16), nothing is scaled or split in the kernel except the probabilities.
+ * o [B*L, ldo]: g8-packed output for the projection GEMM, o_scale [B*L] = f16_row_scale(v_bound) for every row (v_bound >= max |v|). */
+int32_t psam_attention_packed(const void* qkv, int64_t ld, const float* sc, float* o, int64_t ldo, float* o_scale, int32_t B, int32_t H, int32_t L,
+                              int32_t hd, float scale, float v_bound, psam_stream_t stream);
+
 /* y [M, N] = act(x [M, K] W [N, K]^T + bias) + residual for M <= 64 rows (K % 16 == 0, rows 16-byte aligned; act: none / GELU / ReLU),
  * exact fp32 products.  The decoder's token-side nn.Linear calls (7 output tokens per prompt): transformer.py:109-236. */
 int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,

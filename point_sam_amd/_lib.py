@@ -53,6 +53,7 @@ SIGNATURES = {
     "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3_ex": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, ptr]),
+    "psam_attention_packed": (i32, [ptr, i64, ptr, ptr, i64, ptr, i32, i32, i32, i32, f32, f32, ptr]),
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
     "psam_gemm_f16x3p_hyper_planes": (i32, [i32, i32]),
     "psam_sum_planes": (i32, [ptr, i32, i64, i64, ptr, ptr]),

@@ -590,3 +590,289 @@ PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, c
                                       float scale, hipStream_t stream) {
     return psam_attention_f16x3_ex(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, B, H, Lq, Lk, hd, scale, nullptr, 0.f, 0.f, nullptr, stream);
 }
+
+// ================================================================================================================
+// Attention on PRE-PACKED operands ("f16x3", head dim 64): the qkv GEMM's epilogue has already written every row of q | k | v in the
+// g8-packed hi|lo fp16 form of gemm_f16x3p.hip ([hi d0..7 : 16 B][lo d0..7 : 16 B] per 8 channels) with ONE power-of-two scale for
+// the whole tensor (psam_gemm_fuse_t pack_out with k1 = 0: the scale comes from an a-priori bound of |q|, |k|, |v| -- Cauchy-Schwarz on
+// the LayerNorm output and the weight row norms; a loose bound costs nothing here: the lo plane resolves 2^-24 of the scaled domain
+// whatever the magnitude).  So nothing is converted, scaled or reduced per tile any more:
+//   * Q fragments: eight 16-byte global loads per lane, straight from the packed rows (B operand of S^T = K Q^T);
+//   * K and V tiles (64 keys x 256 B each): global -> LDS by LDS-DMA, double buffered, chunk-swizzled on the source address;
+//   * K fragments: ds_read_b128 of one chunk (A operand: lane = key, 8 consecutive channels);
+//   * V^T fragments (A operand of O^T = V^T P^T: lane = channel, 8 consecutive KEYS): V stays row-major in LDS and is transposed on
+//     the way out by ds_read_b64_tr_b16 -- within a 16-lane group, lane i receives element i%4 of the 8 bytes that lanes i/4, 4+i/4,
+//     8+i/4, 12+i/4 point at (probed on gfx950, scripts/exp/tr_probe.hip); source lane s therefore points at key s/4, channels
+//     4(s%4)..+3 of the group's 16 channels, and two such reads fill the 8 k-slots {0-3, 8-11} (+4 for the upper half wave) that the
+//     S^T accumulator layout dictates for P;
+//   * one workgroup = 8 waves = 256 query rows of one (cloud, head): a K/V tile is fetched once for all of them;
+//   * online softmax in the log2 domain per lane (= per query row), P produced scaled by 2^14 and split in registers.
+// The output leaves g8-packed for the projection GEMM with the constant scale f16_row_scale(v_bound) (attention outputs are convex
+// combinations of V rows).  47 -> see profiles/r03_attention.txt.
+struct PackedAttnArgs {
+    const unsigned char* qkv;      // packed rows: [B * L][ld containers]; q at column 0, k at column D, v at column 2 D (containers)
+    const float* sc;               // the rows' (common) scale: sc[b * L] is read
+    float* o; float* o_scale;
+    int64_t ld, ldo;               // containers (4 bytes) per row
+    int H, L, B, D;
+    float scale_log2e, v_bound;
+#ifdef PSAM_ATTN_ABLATE
+    int abl;      // 1 no DMA after the prologue, 2 no barriers, 4 no softmax arithmetic, 8 no S MFMAs, 16 no PV MFMAs, 32 no V reads, 64 no K reads
+#endif
+};
+
+typedef short fa_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short fa_s16x8 __attribute__((ext_vector_type(8)));
+// ds_read_b64_tr_b16 through the compiler's builtin: the read is counted and scheduled like any other LDS load
+__device__ __forceinline__ fa_s16x4 fa_ds_read_tr16(const unsigned char* lds_ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4*)(lds_ptr));
+#else
+    (void)lds_ptr; return fa_s16x4{0, 0, 0, 0};
+#endif
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FA_DMA16(rsrc, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst), 16, voff, soff, 0, 0)
+#else
+#define FA_DMA16(rsrc, dst, voff, soff) ((void)(rsrc), (void)(dst), (void)(voff), (void)(soff))
+#endif
+
+constexpr int PA_BQ = 256;     // query rows per workgroup (8 waves x 32)
+#ifndef PA_PRIO
+#define PA_PRIO 1
+#endif
+constexpr int PA_TILE = FA_BKV * 256;      // bytes of one K (or V) tile: 64 keys x 64 channels x 4 B
+
+__global__ __launch_bounds__(512) void flash_attn_packed_kernel(const PackedAttnArgs p) {
+    constexpr int HD = 64, KS = 4, DT = 2, ROWB = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [3][K tile | V tile]: ring of three tiles, ONE barrier per tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int nq = (p.L + PA_BQ - 1) / PA_BQ, HB = p.H * p.B;
+    int qb, hb;        // consecutive workgroup ids go to different XCDs: the query blocks of one (cloud, head) share an XCD's L2
+    if ((HB & 7) == 0) { const int id = blockIdx.x, grp = id / (8 * nq), r = id - grp * 8 * nq; hb = grp * 8 + (r & 7); qb = r >> 3; }
+    else { qb = blockIdx.x % nq; hb = blockIdx.x / nq; }
+    const int head = hb % p.H, b = hb / p.H;
+    const int64_t rowb = p.ld * 4;                               // bytes per packed row
+    const unsigned char* base = p.qkv + (int64_t)b * p.L * rowb + (int64_t)head * HD * 4;
+    const float s_u = p.sc[(int64_t)b * p.L];                   // the tensor's scale (a power of two)
+
+    // ---- K / V tiles by LDS-DMA: piece pc (1 KiB) = rows 4 pc .. 4 pc + 3; lane -> (row 4 pc + lane / 16, slot lane % 16) receives chunk
+    // slot ^ f(row): f = row & 15 for K (16 different keys of a ds_read_b128 lane group on 16 different slots), (row & 1) | (row & 2) << 2
+    // for V (the 4 keys x 4 channel quads of a transposing read on 16 different slots).  8 waves x 4 pieces = K tile + V tile.
+    const int nt = (p.L + FA_BKV - 1) / FA_BKV;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    int dvoff[4];        // byte offset of this lane's chunk inside a tile's rows (row * rowb + column block + chunk * 16), tile base in soffset
+    int dkey[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pc = wave * 4 + i;                             // 0..15: K pieces, 16..31: V pieces
+        const bool isv = pc >= 16;
+        const int row = (pc & 15) * 4 + (lane >> 4), slot = lane & 15;
+        const int chunk = slot ^ (isv ? ((row & 1) | ((row & 2) << 2)) : (row & 15));
+        dkey[i] = row;
+        dvoff[i] = (isv ? 2 : 1) * p.D * 4 + chunk * 16;
+    }
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave * 4 + i;
+            int key = t * FA_BKV + dkey[i];
+            key = key < p.L ? key : p.L - 1;                     // rows past the end are clamped (their scores are masked)
+            unsigned char* dst = smem + buf * 2 * PA_TILE + (pc >= 16 ? PA_TILE : 0) + (pc & 15) * 1024;
+            FA_DMA16(rs, dst, (int)((int64_t)key * rowb) + dvoff[i], 0);
+        }
+    };
+    issue_tile(0, 0);
+    if (nt > 1) issue_tile(1, 1);
+
+    // ---- this lane's query row: the hi / lo chunks of channels 16 s + 8 h .. + 7, as stored
+    const int q0 = qb * PA_BQ + wave * 32;
+    const int qrow = q0 + r32;
+    fa_f16x8 qh[KS], ql[KS];
+    {
+        const unsigned char* qp = base + (int64_t)(qrow < p.L ? qrow : p.L - 1) * rowb;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qh[s] = *reinterpret_cast<const fa_f16x8*>(qp + (2 * s + h) * 32);
+            ql[s] = *reinterpret_cast<const fa_f16x8*>(qp + (2 * s + h) * 32 + 16);
+        }
+    }
+    const float inv_su = fa_inv_pow2(s_u);
+    const float c_s = p.scale_log2e * inv_su * inv_su;          // scaled-domain S -> log2-domain logits
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // l_run sums the 2^14-scaled probabilities
+
+    // transposing V reads: this lane as SOURCE lane s = lane & 15 of its group g = lane >> 4: key (s >> 2) of the quad of keys, channels
+    // (g & 1) * 16 + 4 (s & 3) .. + 3 of the 32-channel tile; as RESULT lane it is channel (g & 1) * 16 + s = r32, half h = g >> 1
+    const int tr_key = (lane & 15) >> 2, tr_d = ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    const int tr_sw = (tr_key & 1) | ((tr_key & 2) << 2);       // f(row) of key rows kbase + tr_key, kbase % 4 == 0
+
+    // the two waves of a SIMD run the same S^T -> softmax -> PV sequence: with equal priority they take the matrix pipe at the same time and
+    // leave it idle at the same time; a standing priority for one of them lets it run unimpeded while the other fills its softmax gaps
+    if (PA_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    int buf = 0;
+    for (int t = 0; t < (FA_ABL(128) ? 0 : nt); ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's pieces of tile t landed (tile t+1's may fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!FA_ABL(2)) __builtin_amdgcn_s_barrier();                          // tile t visible to every wave; every wave is done with tile t-1
+        if (t + 2 < nt && !FA_ABL(1)) issue_tile(t + 2, buf == 0 ? 2 : buf - 1);      // ... whose buffer takes tile t+2
+        const unsigned char* kt0 = smem + buf * 2 * PA_TILE;
+        const unsigned char* vt0 = kt0 + PA_TILE;
+        // ---- the tile's two 32-key sub-tiles as ONE straight-line block (the second sub-tile of a ragged last tile may lie wholly past the
+        // end: its scores are masked to -inf, which the running maximum of the first sub-tile absorbs), every LDS read a compiler-visible
+        // operation: the scheduler is free to put the S^T products of sub-tile 1 under the softmax arithmetic of sub-tile 0, and the PV
+        // products of sub-tile 0 under the softmax of sub-tile 1 -- an in-order wave overlaps matrix and vector work only instruction by
+        // instruction.
+        f32x16 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sa, sb;        // two accumulation chains (k16 steps 0,1 and 2,3): consecutive MFMAs never wait for one another's result
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+            const int krow = kt * 32 + r32;
+            const unsigned char* kb = kt0 + krow * ROWB;
+#pragma unroll
+            for (int sp = 0; sp < KS / 2; ++sp) {
+                fa_f16x8 kh[2], kl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = 2 * (2 * (sp + 2 * u) + h);
+                    kh[u] = *reinterpret_cast<const fa_f16x8*>(kb + (((c) ^ (krow & 15)) << 4));
+                    kl[u] = *reinterpret_cast<const fa_f16x8*>(kb + (((c + 1) ^ (krow & 15)) << 4));
+                }
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0], ql[sp], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1], ql[sp + 2], sb, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[0], qh[sp], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[1], qh[sp + 2], sb, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0], qh[sp], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1], qh[sp + 2], sb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = sa[r] + sb[r];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key_base = t * FA_BKV + kt * 32;
+            // ---- V^T fragments: transposing reads (see the header of this kernel)
+            fa_f16x8 vh[2][DT], vl[2][DT];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    // keys kbase + (0..3) [k-slots 0-3] and kbase + 8 + (0..3) [k-slots 4-7], kbase = kt*32 + 16*s2 + 4*h; channels d*32 + tr_d ..
+                    const int kbase = kt * 32 + 16 * s2 + 4 * h;
+                    const int ch = d * 32 + tr_d;                                   // first of this source lane's 4 channels
+                    const int chunk = 2 * (ch >> 3), inb = (ch & 7) * 2;
+                    // f(row): kbase % 4 == 0, so the low two bits of the row are tr_key's; rows kbase + 8 + tr_key have the same low bits
+                    const unsigned char* a0 = vt0 + (kbase + tr_key) * ROWB + inb;
+                    const unsigned char* a1 = a0 + 8 * ROWB;
+                    const fa_s16x4 h0 = fa_ds_read_tr16(a0 + (((chunk) ^ tr_sw) << 4)), h1 = fa_ds_read_tr16(a1 + (((chunk) ^ tr_sw) << 4));
+                    const fa_s16x4 l0 = fa_ds_read_tr16(a0 + (((chunk + 1) ^ tr_sw) << 4)), l1 = fa_ds_read_tr16(a1 + (((chunk + 1) ^ tr_sw) << 4));
+                    vh[s2][d] = __builtin_bit_cast(fa_f16x8, fa_s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
+                    vl[s2][d] = __builtin_bit_cast(fa_f16x8, fa_s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+                }
+            // ---- online softmax for this lane's query row (keys (r&3)+8*(r>>2)+4*h of the sub-tile)
+            if (key_base + 32 > p.L) {   // uniform: only a ragged last tile masks
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key_base + (r & 3) + 8 * (r >> 2) + 4 * h >= p.L) st[kt][r] = -INFINITY;
+            }
+            float mxa = fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])), mxb = fmaxf(fmaxf(st[kt][4], st[kt][5]), fmaxf(st[kt][6], st[kt][7]));
+            float mxc = fmaxf(fmaxf(st[kt][8], st[kt][9]), fmaxf(st[kt][10], st[kt][11])), mxd = fmaxf(fmaxf(st[kt][12], st[kt][13]), fmaxf(st[kt][14], st[kt][15]));
+            float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c_s;        // c_s > 0: max commutes with the scaling
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float m14 = m_new - 14.f;
+            float psum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c_s, -m14));   // probability * 2^14, in [0, 2^14]
+                psum[r & 3] += st[kt][r];
+            }
+            l_run = l_run * alpha + ((psum[0] + psum[1]) + (psum[2] + psum[3]));
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            }
+            // ---- split P (registers 0-7 = k-slots of step 0, 8-15 = step 1) and O^T += V_sub^T P^T
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa_split2(fa_f32x2{st[kt][8 * s2 + 2 * e], st[kt][8 * s2 + 2 * e + 1]}, hi[e], lo[e]);
+                const fa_f16x8 ph = __builtin_bit_cast(fa_f16x8, fa_u32x4{hi[0], hi[1], hi[2], hi[3]});
+                const fa_f16x8 pl = __builtin_bit_cast(fa_f16x8, fa_u32x4{lo[0], lo[1], lo[2], lo[3]});
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], pl, oacc[d], 0, 0, 0);      // the two channel tiles alternate
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[s2][d], ph, oacc[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], ph, oacc[d], 0, 0, 0);
+            }
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    if (FA_ABL(256)) { if (l_run == 123.f) p.o_scale[0] = oacc[0][0] + oacc[1][5]; return; }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);          // 2^14 * sum of probabilities
+    const float inv = inv_su / l_tot;                               // (oacc / (2^14 s_u)) / (l_tot / 2^14)
+    const float out_scale = f16_row_scale(p.v_bound);
+    if (head == 0 && h == 0 && qrow < p.L) p.o_scale[(int64_t)b * p.L + qrow] = out_scale;
+    float* op = p.o + ((int64_t)b * p.L + (qrow < p.L ? qrow : 0)) * p.ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = d * 32 + 8 * g + 4 * h;
+            unsigned h0, l0, h1, l1;
+            fa_split2(fa_f32x2{oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv} * out_scale, h0, l0);
+            fa_split2(fa_f32x2{oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv} * out_scale, h1, l1);
+            const unsigned r0 = __shfl_xor(h ? h0 : l0, 32, 64), r1 = __shfl_xor(h ? h1 : l1, 32, 64);
+            if (qrow < p.L) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
+        }
+}
+
+// qkv: g8-packed rows [B * L, ld] (containers of 4 bytes: q | k | v column blocks of D = H * 64 each, one scale for all rows in
+// sc[...]); o [B * L, ldo]: g8-packed attention output for the projection GEMM, o_scale [B * L] its (constant) row scales
+// f16_row_scale(v_bound), v_bound >= max |v| (an a-priori bound; attention outputs are convex combinations of V rows).
+PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float* sc, float* o, int64_t ldo, float* o_scale, int32_t B, int32_t H,
+                                       int32_t L, int32_t hd, float scale, float v_bound, hipStream_t stream) {
+    PSAM_REQUIRE(qkv && sc && o && o_scale, PSAM_EINVAL, "psam_attention_packed: null pointer");
+    PSAM_REQUIRE(B > 0 && H > 0 && L > 0 && hd == 64, PSAM_EINVAL, "psam_attention_packed: bad shape (head_dim 64)");
+    PSAM_REQUIRE(ld >= 3 * (int64_t)H * hd && (ld & 7) == 0 && (ldo & 7) == 0 && ldo >= (int64_t)H * hd && (((uintptr_t)qkv | (uintptr_t)o) & 31) == 0, PSAM_EALIGN,
+                 "psam_attention_packed: packed rows must be 32-byte aligned, ld >= 3 H hd");
+    PSAM_REQUIRE((int64_t)L * ld * 4 < ((int64_t)1 << 31), PSAM_EINVAL, "psam_attention_packed: one cloud's qkv slice must span < 2 GiB (32-bit buffer offsets)");
+    PSAM_REQUIRE(v_bound > 0.f && (int64_t)psam_cdiv(L, PA_BQ) * H * B < ((int64_t)1 << 31), PSAM_EINVAL, "psam_attention_packed: bad bound / too many workgroups");
+    PackedAttnArgs p;
+    p.qkv = (const unsigned char*)qkv; p.sc = sc; p.o = o; p.o_scale = o_scale; p.ld = ld; p.ldo = ldo; p.H = H; p.L = L; p.B = B; p.D = H * hd;
+    p.scale_log2e = scale * 1.4426950408889634f; p.v_bound = v_bound;
+#ifdef PSAM_ATTN_ABLATE
+    p.abl = g_attn_abl;
+#endif
+    constexpr int lds = 3 * 2 * PA_TILE;        // 96 KiB
+    static unsigned long long attr_done = 0;      // > 64 KiB of dynamic LDS: opt in per device
+    {
+        int dev = 0;
+        PSAM_REQUIRE(hipGetDevice(&dev) == hipSuccess, PSAM_EINVAL, "psam_attention_packed: no device");
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(__atomic_load_n(&attr_done, __ATOMIC_ACQUIRE) & bit)) {
+            PSAM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                         PSAM_EINVAL, "psam_attention_packed: cannot reserve LDS");
+            __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
+        }
+    }
+    hipLaunchKernelGGL(flash_attn_packed_kernel, dim3((unsigned)(psam_cdiv(L, PA_BQ) * H * B)), dim3(512), lds, stream, p);
+    return psam_launch_status("psam_attention_packed: launch failed");
+}

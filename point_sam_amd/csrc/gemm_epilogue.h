@@ -30,6 +30,21 @@ __device__ __forceinline__ float ep_act(float v, int act) { return act == 1 ? ge
 // counted `s_waitcnt lgkmcnt(1)` let a pass start on a shuffle result that had not landed for the last 16 lanes -- wrong fc2 outputs
 // (1e-2) whenever another stream's kernels shared the CU, never when the kernel ran alone (scripts/exp/r03_race.py, profiles/r03_race.txt).
 __device__ __forceinline__ void ep_lgkm_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Sum over aligned groups of W = 4, 8 or 16 consecutive lanes, every lane ending with the group's sum, in the order of the xor butterfly
+// (1, 2, 4, 8) it replaces -- on the DPP path (quad_perm, quad_perm, row_half_mirror, row_mirror: each partner already holds its sub-group's
+// sum, so mirror and xor meet the same value) instead of ds_bpermute.  Whole wave active.
+template <int W>
+__device__ __forceinline__ float ep_group_sum(float v) {
+    if constexpr (W == 4 || W == 8 || W == 16) {
+        v += dpp_f32<DPP_XOR1>(v); v += dpp_f32<DPP_XOR2>(v);
+        if constexpr (W >= 8) v += dpp_f32<DPP_HALF_MIRROR>(v);
+        if constexpr (W >= 16) v += dpp_f32<DPP_MIRROR>(v);
+    } else {        // widths no gated epilogue is instantiated for at run time (odd tile counts, the 256-column row tiles)
+#pragma unroll
+        for (int o = 1; o < W; o <<= 1) v += __shfl_xor(v, o, 64);
+    }
+    return v;
+}
 __device__ __forceinline__ void ep_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -279,7 +294,9 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                             psam_split2_f16(v[0], v[1], so, h0, l0);
                             psam_split2_f16(v[2], v[3], so, h1, l1);
                             const bool odd = lane & 1;
-                            const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+                            // lane ^ 1 exchange on the VALU's DPP path (quad_perm), not through the LDS crossbar (ds_bpermute): every lane is active
+                            // here (packing exists for the two-tile-wide wave tiles only)
+                            const unsigned r0 = (unsigned)dpp_i32<DPP_XOR1>((int)(odd ? h0 : l0)), r1 = (unsigned)dpp_i32<DPP_XOR1>((int)(odd ? h1 : l1));
                             typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
                             *reinterpret_cast<ep_u32x4*>(C + (int64_t)row * p.ldc + ocol) = odd ? ep_u32x4{r0, r1, l0, l1} : ep_u32x4{h0, h1, r0, r1};
                             stored = true;
@@ -336,14 +353,12 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                                     float sm = 0.f;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) sm += (ocol + e < p.stat_cols) ? v[e] : 0.f;
-#pragma unroll
-                                    for (int o = 1; o < TN * 4; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                                    sm = ep_group_sum<TN * 4>(sm);
                                     const float mean = nv > 0 ? sm / (float)nv : 0.f;
                                     float m2 = 0.f;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) { const float d = (ocol + e < p.stat_cols) ? v[e] - mean : 0.f; m2 += d * d; }
-#pragma unroll
-                                    for (int o = 1; o < TN * 4; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+                                    m2 = ep_group_sum<TN * 4>(m2);
                                     if (c4 == 0) {
                                         float* st = p.stats + ((int64_t)row * p.stat_segs + seg0 / (TN * 16)) * 2;
                                         st[0] = mean; st[1] = m2;

@@ -71,6 +71,9 @@ class PointCloudSAM:
         self.precision = precision
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
         self.fuse_attn_pack = True  # "f16x3": the attention kernel writes its output packed for the output projection (bound-derived scale)
+        # "f16x3", head dim 64: the qkv GEMM writes q | k | v already packed (one a-priori power-of-two scale) and the attention kernel consumes
+        # them as they are -- K / V tiles by LDS-DMA, V transposed on read; no per-tile conversion, scaling or maximum (csrc/attention.hip)
+        self.fuse_attn_operands = True
         # upscaling MLP: the first Linear runs on the G patch rows BEFORE the 3-NN interpolation (an affine combination: it commutes with a
         # Linear layer) and the LayerNorm + GELU after it ride on the interpolation kernel -- the [N, 256] GEMM and LayerNorm pass are gone
         self.upscale_linear_first = True
@@ -164,6 +167,13 @@ class PointCloudSAM:
                     blk.w2g = ops.F16Weight(w2g.float().contiguous())
                     blk.k1 = float(2.0 ** 15 * math.sqrt(D) * blk.w1.double().norm(dim=1).max().item())
                     blk.k2 = float(blk.b1.abs().max().item())
+                # a-priori bounds of |q|, |k|, |v| (packed qkv for the operand-packed attention) and of |v| alone (its packed output):
+                # |W_n . h + b_n| <= ||W_n||_2 ||h||_2 + |b_n|, and a LayerNorm output h = z * gamma + beta has ||h||_2 <= max|gamma| sqrt(D) + ||beta||_2
+                g1, b1n = w[blk.p + ".norm1.weight"].double(), w[blk.p + ".norm1.bias"].double()
+                hnorm = float(g1.abs().max() * math.sqrt(D) + b1n.norm())
+                wq_all = blk.wqkv.double()
+                blk.qkv_bound = 1.001 * (float(wq_all.norm(dim=1).max()) * hnorm + float(blk.bqkv.abs().max())) + 1e-30
+                blk.v_bound = 1.001 * (float(wq_all[2 * D:].norm(dim=1).max()) * hnorm + float(blk.bqkv[2 * D:].abs().max())) + 1e-30
                 # bound of |V| from the scale of the (LayerNorm) row that produced it: the attention kernel packs its output with it
                 wv = blk.wqkv[2 * D:].double()
                 blk.vk1 = float(2.0 ** 15 * math.sqrt(D) * wv.norm(dim=1).max().item())
@@ -246,9 +256,21 @@ class PointCloudSAM:
         pk = f16 and x.shape[0] >= ops.SPLIT_MIN_M and isinstance(blk.wqkv, ops.F16Weight) and ops.layernorm_can_pack(D)
         rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if pk else None
         h = self._ln(p + ".norm1", x, vit.ln_eps, scale_out=rs, pack=pk)
-        qkv = ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs, x_packed=pk)
         o = torch.empty_like(x)
-        if pk and self.fuse_attn_pack and ops.attention_can_pack(hd) and D % 32 == 0 and (p + ".attn.proj.weight") in self.fw:
+        if (pk and self.fuse_attn_operands and self.fuse_attn_pack and ops.attention_packed_supported(hd, x.shape[0], D) and D % 32 == 0
+                and (p + ".attn.proj.weight") in self.fw):
+            qkvp = torch.empty(x.shape[0], 3 * D, dtype=torch.float32, device=x.device)      # g8-packed containers
+            sq = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+            ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs, x_packed=True, out=qkvp, pack_out=(sq, 0.0, blk.qkv_bound))
+            so = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+            ops.attention_packed(qkvp, sq, o, so, B, H, L, hd, hd ** -0.5, blk.v_bound)
+            self._lin(p + ".attn.proj", o, residual=x, out=x, x_scale=so, x_packed=True)
+            qkv = None
+        else:
+            qkv = ops.linear(h, blk.wqkv, blk.bqkv, x_scale=rs, x_packed=pk)
+        if qkv is None:
+            pass
+        elif pk and self.fuse_attn_pack and ops.attention_can_pack(hd) and D % 32 == 0 and (p + ".attn.proj.weight") in self.fw:
             so = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)      # the attention kernel leaves its rows packed for proj
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5, pack=(rs, blk.vk1, blk.vk2, so))
             self._lin(p + ".attn.proj", o, residual=x, out=x, x_scale=so, x_packed=True)

@@ -435,6 +435,22 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
     return out
 
 
+def attention_packed_supported(hd: int, rows: int, width: int) -> bool:
+    """Self-attention straight from the qkv GEMM's packed output: head dim 64, and the qkv GEMM must be able to pack ([rows, 3 * width])."""
+    return GEMM_MODE == "f16x3" and hd == 64 and fuse_supported(rows, 3 * width)
+
+
+def attention_packed(qkv_packed, scale_rows, out, out_scale, B, H, L, hd, scale, v_bound):
+    """qkv_packed [B*L, >= 3*H*hd] g8-packed q | k | v with one common power-of-two scale (scale_rows [B*L], all equal): the output of
+    linear(..., pack_out=(scale_rows, 0.0, bound)).  out [B*L, >= H*hd] receives the g8-packed attention output, out_scale [B*L] its
+    (constant) scale f16_row_scale(v_bound): linear(out, W_proj, x_scale=out_scale, x_packed=True)."""
+    qp, ld = _row_view(qkv_packed, "qkv_packed")
+    op, ldo = _row_view(out, "out")
+    check(_lib.load().psam_attention_packed(qp, ld, scale_rows.data_ptr(), op, ldo, out_scale.data_ptr(), B, H, L, hd, float(scale), float(v_bound), _stream()),
+          "psam_attention_packed")
+    return out
+
+
 class Mlp3Weights:
     """Three Linear layers (ReLU between) of M stacked MLPs for psam_mlp3: w? [M, out, in] (the reference's layout), b? [M, out]."""
 

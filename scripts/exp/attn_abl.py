@@ -45,3 +45,19 @@ with ops.gemm_mode("f16x3"):
         L.psam_attention_set_ablation(0)
     md, mn = timed(lambda: run(True))
     print(f"packed output, full                                        median {md:6.1f} us  min {mn:6.1f} us")
+    # ---- the packed-operand kernel
+    sq = torch.full((B * Lq,), 2.0 ** 11, device="cuda")
+    qkvp = ops.pack_rows_g8(qkv, sq)
+    so = torch.empty(B * Lq, device="cuda")
+    PN = {0: "full", 1: "no DMA after the prologue", 2: "no barriers", 4: "no exp / P split", 8: "no S MFMAs", 16: "no PV MFMAs", 24: "no MFMAs", 32: "no V reads", 64: "no K reads",
+          96: "no fragment reads", 28: "no MFMAs, no exp/split", 124: "skeleton: DMA + barriers + max/sum", 127: "skeleton, no DMA, no barriers", 120: "softmax arithmetic only (+DMA, barriers)",
+          100: "MFMAs only (+DMA, barriers)", 128: "no tile loop at all (prologue + epilogue)", 384: "prologue only", 256: "no epilogue"}
+    for a, name in PN.items():
+        if a and not HAVE:
+            continue
+        if HAVE:
+            L.psam_attention_set_ablation(a)
+        md, mn = timed(lambda: ops.attention_packed(qkvp, sq, o, so, B, H, Lq, hd, hd ** -0.5, 8.0))
+        print(f"packed operands: abl {a:3d} {name:44s} median {md:6.1f} us  min {mn:6.1f} us", flush=True)
+    if HAVE:
+        L.psam_attention_set_ablation(0)

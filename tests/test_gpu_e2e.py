@@ -113,6 +113,23 @@ def test_attention_packed_output_is_transparent(gpu):
     assert e_m < 5e-5 and e_i < 5e-5
 
 
+def test_attention_packed_operands_is_transparent(gpu):
+    """The qkv GEMM writing q | k | v packed with an a-priori scale + the packed-operand attention kernel, against the fp32 qkv buffer + the
+    kernel that converts per tile: the model outputs agree to fp32 round-off (ViT-B: 12 blocks; ViT-L at cfg #2 is covered by
+    test_against_oracle, which runs the default = packed path)."""
+    cfg = get_config("base", 128, 32)
+    sd = random_state_dict(cfg, seed=2)
+    xyz, rgb, prompt, labels = O.synthetic_batch(2, 4096, seed=6)
+    outs = []
+    for fuse in (True, False):
+        model = gpu(cfg, sd, precision="f16x3")
+        model.fuse_attn_operands = fuse
+        outs.append(model.predict_masks(xyz.cuda(), rgb.cuda(), prompt.cuda(), labels.cuda()))
+    e_m, e_i = _maxerr(outs[0][0], outs[1][0]), _maxerr(outs[0][1], outs[1][1])
+    print(f"\n[packed-operand attention vs per-tile conversion, ViT-B x12] max|diff| masks {e_m:.2e} iou {e_i:.2e}")
+    assert e_m < 5e-5 and e_i < 5e-5
+
+
 def test_fused_upscaling_matches_unfused(gpu):
     """Decoder upscaling chain with the packed interpolation hand-over, and in three kernels (+ row LayerNorm + GELU + re-pack and the
     hyper-network products in GEMM epilogues), vs the six-kernel sequence; multimask and single-mask outputs."""

@@ -487,26 +487,39 @@ def test_fused_mlp_bitwise_stable_beside_other_streams(ops):
                 mlp()
             elif kind == "ln":
                 ops.layernorm(res, ln_d, ln_d, 1e-6)
-            else:
+            elif kind == "attn":
                 o = torch.empty(M, D, device="cuda")
                 ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, 8, 16, 512, 512, 64, 0.125)
+            else:
+                attn_packed()
+
+        sq = torch.full((M,), 2.0 ** 11, device="cuda")
+        qkvp = ops.pack_rows_g8(qkv, sq)
+
+        def attn_packed():
+            o = torch.empty(M, D, device="cuda"); so = torch.empty(M, device="cuda")
+            ops.attention_packed(qkvp, sq, o, so, 8, 16, 512, 64, 0.125, 8.0)
+            return o
 
         s2 = torch.cuda.Stream()
         try:
+            ref_attn = attn_packed()
             for cfg in (-1, 21, 28):
                 L.psam_gemm_f16x3p_force_config(cfg)
                 ref = mlp()
                 torch.cuda.synchronize()
-                for kind in ("qkv", "mlp", "attn", "ln"):
+                for kind in ("qkv", "mlp", "attn", "ln", "attn_packed"):
                     for it in range(4):
                         s2.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(s2):
                             for _ in range(6):
                                 noise(kind)
                         out = mlp()
+                        oa = attn_packed()
                         torch.cuda.synchronize()
                         for k in ref:
                             assert torch.equal(out[k].view(torch.int32), ref[k].view(torch.int32)), (cfg, kind, it, k)
+                        assert torch.equal(oa.view(torch.int32), ref_attn.view(torch.int32)), (cfg, kind, it, "packed-operand attention")
         finally:
             L.psam_gemm_f16x3p_force_config(-1)
 
@@ -749,6 +762,39 @@ def test_flash_attention_f16x3_packed_output(ops, hd, H, L):
     # identical bits to packing the fp32 output with the same scales
     ref = ops.pack_rows_g8(want, so)
     assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+
+
+@pytest.mark.parametrize("H,L,B,spike", [(4, 512, 2, False), (2, 130, 3, False), (1, 64, 1, False), (3, 1000, 1, False), (2, 2048, 1, False), (1, 256, 1, True),
+                                          (16, 512, 8, False)])
+def test_attention_packed_operands(ops, H, L, B, spike):
+    """Attention straight from g8-packed q | k | v rows with one common power-of-two scale (what the qkv GEMM's packing epilogue writes):
+    K / V tiles by LDS-DMA, V transposed on read.  Against an fp64 SDPA of the same values, at the tolerance of the other attention
+    kernels; ragged sequence lengths; a key that dominates late in the sequence (forces the online-softmax rescale); the scale taken from a
+    bound 8x and 1000x above the largest value (a loose a-priori bound must not cost accuracy); output = the packing of the fp32 result."""
+    hd, D = 64, H * 64
+    g = torch.Generator().manual_seed(H * 1000 + L)
+    qkv = torch.randn(B * L, 3 * D, generator=g)
+    qkv[:, :D] *= 1.7; qkv[:, D:2 * D] *= 0.6; qkv[:, 2 * D:] *= torch.exp(torch.randn(B * L, 1, generator=g))
+    if spike:
+        qkv[200, D:2 * D] = qkv[7, :D] * 2.0
+    scale = hd ** -0.5
+    want = _sdpa(qkv[:, :D].view(B, L, D), qkv[:, D:2 * D].view(B, L, D), qkv[:, 2 * D:].view(B, L, D), H, scale)
+    x = cu(qkv)
+    vmax = float(qkv[:, 2 * D:].abs().max())
+    for slack in (8.0, 1000.0):
+        bound = float(qkv.abs().max()) * slack
+        e = math.floor(math.log2(bound))
+        sc = torch.full((B * L,), 2.0 ** (14 - e), device="cuda")
+        assert float(qkv.abs().max()) * float(sc[0]) < 2.0 ** 15
+        xp = ops.pack_rows_g8(x, sc)
+        out = torch.empty(B * L, D, device="cuda"); so = torch.empty(B * L, device="cuda")
+        with ops.gemm_mode("f16x3"):
+            ops.attention_packed(xp, sc, out, so, B, H, L, hd, scale, vmax * 1.01)
+        assert (so == so[0]).all() and float(torch.log2(so[0])) == round(float(torch.log2(so[0]))) and vmax * float(so[0]) < 2.0 ** 15
+        got = _unpack_g8(out, so, D).cpu().view(B, L, D)
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        print(f"\n[packed-operand attention H={H} L={L} B={B} bound x{slack:g}] rel err {err:.2e}")
+        assert err < 2e-6, err
 
 
 def test_flash_attention_f16x3_spike(ops):
