@@ -61,6 +61,7 @@ def run(tag, cfg_name, G, K, B, N, clicks, precision="f16x3"):
     return res
 
 
-out = {"cfg2": run("cfg2", "large", 512, 64, 8, 32768, 1), "cfg3": run("cfg3", "large", 2048, 256, 1, 131072, 1), "cfg5": run("cfg5", "giant", 512, 64, 1, 32768, 5)}
+ALL = {"cfg2": ("large", 512, 64, 8, 32768, 1), "cfg3": ("large", 2048, 256, 1, 131072, 1), "cfg5": ("giant", 512, 64, 1, 32768, 5)}
+out = {k: run(k, *v) for k, v in ALL.items() if k in os.environ.get("STAGE_CFGS", "cfg2,cfg3,cfg5").split(",")}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/stage_times.json", "w"), indent=1)
