@@ -49,7 +49,7 @@ const char* psam_last_error_string(void);
 size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G);
 int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws, size_t ws_bytes,
                  psam_stream_t stream);
-void psam_fps_set_cooperative(int32_t on); /* test hook: 0 = never use the multi-workgroup kernel for N > 32768 */
+void psam_fps_set_cooperative(int32_t on); /* test hook: 0 = never use the multi-workgroup kernel for N > 32768, 2 = use it without the one-XCD placement */
 
 /* K nearest points of each center, ascending by (squared distance, index); the [G,N] distance matrix is never
  * materialised.  Replaces knn_points(centers, xyz, K) = torch.cdist + torch.topk: pc_sam/model/common.py:27-56,97.
@@ -159,7 +159,12 @@ typedef struct {
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
     const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
     int64_t hyper_pstride;
+    /* split-K: splitk > 1 workgroups per output tile share the K loop; partial products go to splitk planes of splitk_ws (splitk_plane >=
+     * M * N floats apart), added in a fixed order with bias / activation / residual applied afterwards.  No other extras, act != SwiGLU,
+     * no rowbias, N % 4 == 0, splitk <= K / 128.  psam_gemm_f16x3p_splitk() suggests the factor for a shape (1: none). */
+    float* splitk_ws; int64_t splitk_plane; int32_t splitk;
 } psam_gemm_fuse_t;
+int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_t act);
 /* hyper without row_ln_*: any N % 128 == 0, M % 256 == 0; every 64-column wave tile contributes the partial products of its columns:
  * masks then holds psam_gemm_f16x3p_hyper_planes(N, 0) = N / 64 planes of [Z, C, hyper_rows], hyper_pstride elements apart, and
  * psam_sum_planes adds them in a fixed order.  With row_ln_* (full-row tile, N == 256) there is one plane. */
@@ -201,7 +206,7 @@ int32_t psam_attention_f32(const float* q, int64_t ldq, int64_t sq, const float*
                            int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
                            float scale, psam_stream_t stream);
 /* Same contract on the fp16 matrix pipe with fp32-grade products (power-of-two scaling + hi/lo fp16 split of Q, K, V and of the
- * probabilities, 3 MFMA products each; csrc/attention.hip).  head_dim in {64, 128}. */
+ * probabilities, 3 MFMA products each; csrc/attention.hip).  head_dim 64, or a multiple of 8 in (64, 128] (computed zero-padded to 128). */
 int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                            int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
                            float scale, psam_stream_t stream);

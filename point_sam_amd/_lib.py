@@ -43,6 +43,7 @@ SIGNATURES = {
     "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
+    "psam_gemm_f16x3p_splitk": (i32, [i32, i32, i32, i32]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
     "psam_ln_stats_finalize": (i32, [ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_scale_pack_rows_g8": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, ptr]),
@@ -72,7 +73,8 @@ class GemmFuse(ctypes.Structure):
     """psam_gemm_fuse_t (include/pointsam_hip.h)."""
     _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
                 ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
-                ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64)]
+                ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64),
+                ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32)]
 
 
 _lib = None

@@ -30,6 +30,7 @@ struct FlashArgs {
     // into [2^14, 2^15) -- attention outputs are convex combinations of V rows, so the bound holds for them; a_scale = the row scales
     // of the qkv GEMM's A operand (LayerNorm output), k1 = 2^15 sqrt(D) max_n ||W_v[n]||, k2 = max |b_v|.
     const float* a_scale; float* o_scale; float k1, k2;
+    int hd;       // flash_attn_f16x3_kernel: real head dim <= the kernel's HD (% 8 == 0); channels hd .. HD-1 are read as zeros, never written
 #ifdef PSAM_ATTN_ABLATE
     int abl;      // scripts/exp/attn_abl.*: 1 no per-tile convert+store, 2 no tile loads, 4 no exp/split, 8 no S MFMAs, 16 no PV MFMAs
 #endif
@@ -283,9 +284,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     else { qb = blockIdx.x % nq; hb = blockIdx.x / nq; }
     const int head = hb % p.H, b = hb / p.H;
     const int q0 = qb * FA_BQ + wave * 32;
-    const float* Q = p.q + b * p.sq + head * HD;
-    const float* K = p.k + b * p.sk + head * HD;
-    const float* V = p.v + b * p.sv + head * HD;
+    const int hd = p.hd;      // == HD, or smaller (88 under HD = 128): the missing channels are zeros
+    const float* Q = p.q + b * p.sq + head * hd;
+    const float* K = p.k + b * p.sk + head * hd;
+    const float* V = p.v + b * p.sv + head * hd;
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -304,8 +306,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     constexpr int VJ = 256 / ROW4;                       // key groups covered per pass (16 for HD = 64)
     const int vc4 = tid % ROW4, vj = tid / ROW4;
     constexpr int OOB = 0x7ffffff0;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)((((int64_t)p.Lk - 1) * p.ldk + HD) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (int)((((int64_t)p.Lk - 1) * p.ldv + HD) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)((((int64_t)p.Lk - 1) * p.ldk + hd) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (int)((((int64_t)p.Lk - 1) * p.ldv + hd) * 4), 0x00020000);
     int koffs[NF4], voffs[NF4];                          // byte offsets inside a tile; the tile base goes in the scalar offset
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
@@ -318,12 +320,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 #pragma unroll
         for (int i = 0; i < NF4; ++i) {
             const int key = kv0 + (i * 256 + tid) / ROW4;
-            rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, key < p.Lk ? koffs[i] : OOB, kbase, 0));
+            rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, (key < p.Lk && ((i * 256 + tid) % ROW4) * 4 < hd) ? koffs[i] : OOB, kbase, 0));
         }
 #pragma unroll
         for (int i = 0; i < NF4; ++i) {                  // i = (pass, e): key = 4 * (vj + VJ * pass) + e
             const int key = kv0 + 4 * (vj + VJ * (i >> 2)) + (i & 3);
-            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, key < p.Lk ? voffs[i] : OOB, vbase, 0));
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (key < p.Lk && vc4 * 4 < hd) ? voffs[i] : OOB, vbase, 0));
         }
     };
     auto publish_max = [&](int buf) {
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                t[s][e] = ok ? *reinterpret_cast<const f32x4*>(qp + s * 16 + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                t[s][e] = (ok && s * 16 + h * 8 + e * 4 < hd) ? *reinterpret_cast<const f32x4*>(qp + s * 16 + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 amax = fmaxf(fmaxf(amax, fmaxf(fabsf(t[s][e][0]), fabsf(t[s][e][1]))), fmaxf(fabsf(t[s][e][2]), fabsf(t[s][e][3])));
             }
         amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         // g8-packed rows: this lane holds channels d0..d0+3 of its query row, lane ^ 32 the other four of the same group of 8: the
         // lower half-wave collects the 16-byte hi chunk, the upper one the lo chunk (one exchange); both land at container d0
         if (head == 0 && h == 0 && qrow < p.Lq) p.o_scale[(int64_t)b * p.Lq + qrow] = out_scale;
-        float* op = p.o + b * p.so + (int64_t)(qrow < p.Lq ? qrow : 0) * p.ldo + head * HD;
+        float* op = p.o + b * p.so + (int64_t)(qrow < p.Lq ? qrow : 0) * p.ldo + head * hd;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -533,24 +535,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
                 fa_split2(fa_f32x2{oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv} * out_scale, h0, l0);
                 fa_split2(fa_f32x2{oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv} * out_scale, h1, l1);
                 const unsigned r0 = __shfl_xor(h ? h0 : l0, 32, 64), r1 = __shfl_xor(h ? h1 : l1, 32, 64);
-                if (qrow < p.Lq) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
+                if (qrow < p.Lq && d0 < hd) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
             }
         return;
     }
     if (qrow < p.Lq) {
-        float* op = p.o + b * p.so + (int64_t)qrow * p.ldo + head * HD;
+        float* op = p.o + b * p.so + (int64_t)qrow * p.ldo + head * hd;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = d * 32 + 8 * g + 4 * h;
                 f32x4 o4 = {oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(op + d0) = o4;
+                if (d0 < hd) *reinterpret_cast<f32x4*>(op + d0) = o4;
             }
     }
 }
 
-// Same contract as psam_attention_f32; head_dim in {64, 128}.  a_scale != NULL: packed output (FlashArgs), o_scale [B*Lq] receives the row
+// Same contract as psam_attention_f32; head_dim 64, or a multiple of 8 in (64, 128] (computed zero-padded to 128: the giant encoder's 88).  a_scale != NULL: packed output (FlashArgs), o_scale [B*Lq] receives the row
 // scales; o must then be 32-byte aligned with ldo % 8 == 0 and H*hd % 8 == 0.
 PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                                          int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
@@ -570,17 +572,16 @@ PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
     p.H = H; p.Lq = Lq; p.Lk = Lk; p.B = B;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.a_scale = a_scale; p.o_scale = o_scale; p.k1 = k1; p.k2 = k2;
+    p.a_scale = a_scale; p.o_scale = o_scale; p.k1 = k1; p.k2 = k2; p.hd = hd;
 #ifdef PSAM_ATTN_ABLATE
     p.abl = g_attn_abl;
 #endif
     const dim3 grid((unsigned)(psam_cdiv(Lq, FA_BQ) * H * B)), block(256);      // 1-D over (query block, head, batch), see the kernel
-    switch (hd) {
-        case 64: hipLaunchKernelGGL((flash_attn_f16x3_kernel<64>), grid, block, 0, stream, p); break;
-        case 128: hipLaunchKernelGGL((flash_attn_f16x3_kernel<128>), grid, block, 0, stream, p); break;
-        default:
-            psam_set_error("psam_attention_f16x3: head_dim must be 64 or 128");
-            return PSAM_EINVAL;
+    if (hd == 64) hipLaunchKernelGGL((flash_attn_f16x3_kernel<64>), grid, block, 0, stream, p);
+    else if (hd > 64 && hd <= 128 && (hd & 7) == 0) hipLaunchKernelGGL((flash_attn_f16x3_kernel<128>), grid, block, 0, stream, p);   // zero-padded to 128
+    else {
+        psam_set_error("psam_attention_f16x3: head_dim must be 64 or a multiple of 8 in (64, 128]");
+        return PSAM_EINVAL;
     }
     return psam_launch_status("psam_attention_f16x3: launch failed");
 }

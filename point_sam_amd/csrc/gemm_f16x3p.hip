@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     // CONTIGUOUS eighth of the tile order; the order walks column panels of `panel` tiles row-major (panel == tiles_n: plain row-major,
     // an XCD reads an eighth of A and all of W; panel ~ tiles_n / 8: an XCD keeps its W panel in L2 and streams A once)
     const int ntiles = p.tiles_m * p.tiles_n;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x, split = 0;
+    if (p.ksplit > 1) { split = tile / ntiles; tile -= split * ntiles; }      // split-K: `ksplit` workgroups per tile, consecutive K ranges
     {
         const int q = ntiles >> 3, r = ntiles & 7, x = tile & 7, y = tile >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
@@ -67,8 +68,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     // ---- DMA source offsets: piece b = wave + i NW covers rows 8b..8b+7 of the stage; lane -> (row b*8 + lane/8, slot lane%8),
     // which must receive chunk slot ^ swz(row) of that row.  Rows past M / N are clamped (their products are never stored).
     const int m0l = (ABL & 8) ? 0 : m0, n0l = (ABL & 8) ? 0 : n0;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0l * p.lda * 4), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0l * p.ldw * 4), 0, 0x7fffffff, 0x00020000);
+    const int nslabs_all = p.K / 32;
+    const int slab0 = p.ksplit > 1 ? (int)((int64_t)split * nslabs_all / p.ksplit) : 0;
+    const int nslabs = p.ksplit > 1 ? (int)((int64_t)(split + 1) * nslabs_all / p.ksplit) - slab0 : nslabs_all;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0l * p.lda * 4 + slab0 * ROWB), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0l * p.ldw * 4 + slab0 * ROWB), 0, 0x7fffffff, 0x00020000);
     int voff[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
     // them through the K loop (gemm_epilogue.h)
     constexpr bool PREFETCH_EPI = TM * TN >= 4 && TN <= 4;
     EpPre<TM> epre;
-    if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
+    float* const Cout = p.C + (int64_t)split * p.plane;
+    if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, Cout, p.residual);
     pf16x8 f0a[TM][2], f0w[TN][2], f1a[TM][2], f1w[TN][2];
     // fragment read n in [0, NFR) of step s from `stage`: n -> (operand, tile, plane)
     bool first_slab = true;
@@ -138,7 +143,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[term]], fw[j][PW[term]], acc[i][j], 0, 0, 0);
     };
 
-    const int nslabs = p.K / 32;
     // ---- prologue: S-1 slabs in flight
 #pragma unroll
     for (int u = 0; u < S - 1 + (PF == 2 ? 1 : 0); ++u) issue(u, u);
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         return;
     }
     gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
-                                  n0 + wn * TN * 32, lane, p.C, p.residual, PREFETCH_EPI ? &epre : nullptr);
+                                  n0 + wn * TN * 32, lane, Cout, p.residual, PREFETCH_EPI ? &epre : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- row scales
@@ -424,7 +428,7 @@ static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
         psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
         return PSAM_EINVAL;
     }
-    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), dim3((unsigned)(p.tiles_m * p.tiles_n * p.ksplit)), dim3(64 * NW), lds, stream, p);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
@@ -439,6 +443,9 @@ struct psam_gemm_fuse_t {
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
     const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
     int64_t hyper_pstride;      // elements between the partial planes of `masks` (psam_gemm_f16x3p_hyper_planes of them)
+    // split-K (few tiles, long K: one cloud through a wide encoder): `splitk` workgroups per tile write partial products to the planes of
+    // splitk_ws (splitk_plane >= M * N floats apart), a second kernel adds them in a fixed order and applies bias / activation / residual
+    float* splitk_ws; int64_t splitk_plane; int32_t splitk;
 };
 
 // partial planes the hyper products of an N-column GEMM are delivered in: 1 with the row-LayerNorm (full-row) epilogue, N / 64 otherwise
@@ -446,6 +453,60 @@ PSAM_API int32_t psam_gemm_f16x3p_hyper_planes(int32_t N, int32_t with_row_ln) {
 
 // segments (of 32 gated columns) per row of the stats buffer of a SwiGLU GEMM with N packed weight rows
 PSAM_API int32_t psam_gemm_f16x3p_stat_segs(int32_t N) { return (N / 2 + 31) / 32; }
+
+static void f16x3p_cfg_tile(int cfg, int& bm, int& bn, int& per_cu) {
+    switch (cfg) {
+        case 4: bm = 256; bn = 128; per_cu = 1; break;
+        case 14: bm = 256; bn = 256; per_cu = 1; break;
+        case 12: case 23: bm = 256; bn = 192; per_cu = 1; break;
+        case 9: bm = 128; bn = 128; per_cu = 1; break;
+        default: bm = 128; bn = 128; per_cu = 2; break;      // 0, 21, 28
+    }
+}
+
+// Split-K factor for a shape (1: none).  A launch whose tiles cover less than half of the CUs (M = 512 rows of one cloud: 44 tiles of
+// 128x128 for the N = 1408 GEMMs of the giant encoder) leaves the rest of the chip idle for a K loop of up to 192 slabs; `ks` workgroups
+// per tile share the slabs (>= 8 each) and psam_gemm_f16x3p_ex adds the partial planes in a fixed order (deterministic).
+// PSAM_GEMM_SPLITK: 0 = never, n > 1 = always n (tuning).
+PSAM_API int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_t act) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("PSAM_GEMM_SPLITK"); forced = e ? atoi(e) : 1; }
+    if (act == 3 || K < 1024 || (K & 31) || forced == 0) return 1;
+    const int nslabs = K / 32;
+    if (forced > 1) return forced <= nslabs / 4 ? forced : (nslabs / 4 > 1 ? nslabs / 4 : 1);
+    int cfg = g_f16x3p_cfg;
+    if (cfg < 0 || cfg >= 50) cfg = f16x3p_pick(M, N, K, act, true);
+    int bm, bn, per_cu;
+    f16x3p_cfg_tile(cfg, bm, bn, per_cu);
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    const int64_t tiles = psam_cdiv(M, bm) * psam_cdiv(N, bn), slots = (int64_t)(ncu - 8) * per_cu;
+    if (tiles * 20 > slots * 11) return 1;        // measured (profiles/r03_splitk.log): a gain up to ~0.55 of the slots, best factor 3-4
+    int ks = (int)((slots + tiles / 2) / tiles);
+    if (ks > 4) ks = 4;
+    if (ks > nslabs / 8) ks = nslabs / 8;
+    return ks > 1 ? ks : 1;
+}
+
+// C = act(alpha * sum_s ws[s] + bias) + residual over `ks` planes, s ascending (the sum order is fixed: results do not depend on timing)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int64_t plane, int ks, int M, int N, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int64_t ldr, float alpha, int act, float* __restrict__ C,
+                                                            int64_t ldc) {
+    typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+    const int n4 = N >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * n4) return;
+    const int r = (int)(t / n4), c = (int)(t % n4) * 4;
+    const float* w = ws + (int64_t)r * N + c;
+    sk_f32x4 a = *reinterpret_cast<const sk_f32x4*>(w);
+    for (int s = 1; s < ks; ++s) a += *reinterpret_cast<const sk_f32x4*>(w + s * plane);
+    a *= alpha;
+    if (bias) a += *reinterpret_cast<const sk_f32x4*>(bias + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = ep_act(a[e], act);
+    if (residual) a += *reinterpret_cast<const sk_f32x4*>(residual + (int64_t)r * ldr + c);
+    *reinterpret_cast<sk_f32x4*>(C + (int64_t)r * ldc + c) = a;
+}
 
 // A [M, K] and W [N, K]: g8-packed, row-scaled (scaleA[M], scaleW[N] powers of two); K % 32 == 0 (pad with zeros), K >= 128.
 PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C,
@@ -469,8 +530,38 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
     p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0; p.epi_abl = 0;
+    p.ksplit = 1; p.plane = 0;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
+    if (fuse && fuse->splitk > 1) {
+        const int ks = fuse->splitk;
+        PSAM_REQUIRE(!fuse->pack_out && !fuse->stats && !fuse->ln_c && !fuse->gmax_out && !fuse->row_ln_g && !fuse->hyper, PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: split-K does not combine with the fused epilogue extras");
+        PSAM_REQUIRE(act != 3 && !rowbias && ks <= K / 128, PSAM_EINVAL, "psam_gemm_f16x3p_ex: split-K needs act != SwiGLU, no rowbias, >= 4 slabs per split");
+        PSAM_REQUIRE(fuse->splitk_ws && fuse->splitk_plane >= (int64_t)M * N && (N & 3) == 0 && (fuse->splitk_plane & 3) == 0, PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: split-K needs a workspace of splitk planes of >= M * N floats, N % 4 == 0");
+        PSAM_REQUIRE((((uintptr_t)fuse->splitk_ws | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0 && (ldc & 3) == 0 && (ldr & 3) == 0,
+                     PSAM_EALIGN, "psam_gemm_f16x3p_ex: split-K needs 16-byte aligned rows");
+        if (cfg >= 50 || cfg == 30 || cfg == 31) cfg = f16x3p_pick(M, N, K, act, true);
+        p.C = fuse->splitk_ws; p.ldc = N; p.bias = nullptr; p.residual = nullptr; p.act = 0; p.alpha = 1.f;
+        p.ksplit = ks; p.plane = fuse->splitk_plane;
+        int32_t rc = PSAM_EINVAL;
+        switch (cfg) {
+            case 0: rc = launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream); break;
+            case 4: rc = launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream); break;
+            case 9: rc = launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream); break;
+            case 12: rc = launch_f16x3p<4, 2, 2, 3, 2, 0>(p, stream); break;
+            case 14: rc = launch_f16x3p<4, 2, 2, 4, 2, 0>(p, stream); break;
+            case 21: rc = launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream); break;
+            case 23: rc = launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream); break;
+            case 28: rc = launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream); break;
+            default: psam_set_error("psam_gemm_f16x3p_ex: split-K has no such tile configuration"); return PSAM_EINVAL;
+        }
+        if (rc != PSAM_OK) return rc;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)psam_cdiv((int64_t)M * (N / 4), 256)), dim3(256), 0, stream, (const float*)fuse->splitk_ws,
+                           fuse->splitk_plane, ks, M, N, bias, residual, ldr, alpha, act, C, ldc);
+        return psam_launch_status("psam_gemm_f16x3p_ex: split-K reduction launch failed");
+    }
     if (fuse && fuse->hyper && !fuse->row_ln_g) {
         // hyper products from the 64-column wave tiles of the 128x128 / 256x128 configurations: N / 64 partial planes, added by psam_sum_planes
         PSAM_REQUIRE((M & 255) == 0 && (N & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: hyper products need M % 256 == 0, N % 128 == 0, no SwiGLU");

@@ -23,6 +23,7 @@ struct F16PArgs {
     float* gmax_out; int64_t gmax_ld; int gmax_k, no_store;
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
     const float* hyper; float* masks; int hyper_c, hyper_rows; int64_t hyper_pstride;
+    int ksplit; int64_t plane;        // split-K (lock-step kernel): workgroup (tile, split) sums its share of the K slabs into C + split * plane
     int epi_abl;      // measurement builds (-DPSAM_GEMM_ABLATE): parts of the epilogue switched off (gemm_epilogue.h)
 };
 

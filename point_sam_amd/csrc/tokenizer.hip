@@ -260,32 +260,63 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     }
 }
 
+// 64-bit maximum over a 16-lane row (four DPP steps, every lane ends with the row's result) and over the wave (+ two cross-row exchanges)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long fps_dpp_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)v), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long fps_max_u64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long fps_row16_max_u64(unsigned long long v) {
+    v = fps_max_u64(v, fps_dpp_u64<DPP_XOR1>(v)); v = fps_max_u64(v, fps_dpp_u64<DPP_XOR2>(v));
+    v = fps_max_u64(v, fps_dpp_u64<DPP_HALF_MIRROR>(v)); v = fps_max_u64(v, fps_dpp_u64<DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long fps_wave_max_u64(unsigned long long v) {
+    v = fps_row16_max_u64(v);
+    v = fps_max_u64(v, __shfl_xor(v, 16, 64));
+    return fps_max_u64(v, __shfl_xor(v, 32, 64));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cooperative FPS for large clouds (N > 32768: cfg #3, N = 131072, G = 2048).  The single-workgroup kernel above streams
 // such a cloud from L2 on ONE CU (22 us per iteration, 45 ms per cloud); here W = npad / (4096 PPT4) workgroups share a cloud,
 // each keeping its 4096 PPT4 points and their running min-distances in registers.  Per iteration every workgroup publishes its
-// local (max min-distance, lowest index) candidate as one 64-bit key, all workgroups of the cloud meet at a counter barrier,
-// and each reduces the W keys itself (same winner everywhere: no second broadcast).  Keys, counter and flags are agent-scope
-// relaxed atomics (device-coherent sc1 accesses on both sides, no bulk cache maintenance); an explicit `s_waitcnt vmcnt(0)` between
-// the key store and the counter increment orders the key before the arrival.  All B*W workgroups must be resident at once: the host only takes this path when B*W <= number of CUs, i.e.
+// local (max min-distance, lowest index) candidate as ONE 64-bit key that also carries the iteration number (12-bit tag), into its
+// own slot; wave 0 of every workgroup polls the W slots (one per lane) until all carry the tag and reduces them itself (same winner
+// everywhere: no second broadcast).  The key is its own arrival flag, so an iteration costs one store and one (polled) load across
+// the fabric -- the first version (key store, acknowledged, then a counter barrier, then the key loads: four round trips) took 3.7 us per
+// iteration.  Slots are double-buffered by iteration parity: a workgroup can only be one iteration ahead of the slowest one (it needs
+// everybody's key to go on), so a slot is rewritten only after all have read it, and the tag of what it held before differs by 2.
+// Keys are agent-scope relaxed atomics (device-coherent sc1 accesses on both sides, no bulk cache maintenance).
+// All B*W workgroups must be resident at once: the host only takes this path when B*W <= number of CUs, i.e.
 // half of the 2-per-CU capacity for 1024-thread workgroups, so two such launches may overlap (BatchPipeline issues all tokenizer
 // work on ONE stream, so they never do); more than two concurrent cooperative launches from different streams are not supported.
 // Same arithmetic and tie-break as fps_kernel -> bit-identical indices.
 // ------------------------------------------------------------------------------------------------
 template <int PPT4>
 __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float* __restrict__ xyz, const float* __restrict__ soa, int N, int64_t npad,
-                                                               int G, int W, unsigned long long* __restrict__ cand, unsigned* __restrict__ bar,
+                                                               int G, int W, int xcd_stride, unsigned long long* __restrict__ cand,
                                                                int64_t* __restrict__ idx_out, float* __restrict__ centers_out) {
-    const int b = blockIdx.y, w = blockIdx.x;
+    // xcd_stride == 8: the grid is 8 W wide and only the workgroups whose id is congruent to the cloud's XCD (ids are dealt to the eight
+    // XCDs round-robin) take part, the others leave at once -- all W workgroups of a cloud then share one XCD and the hand-over is
+    // ~0.3 us shorter (scripts/exp/fabric_probe.hip, profiles/r03_fabric_probe.txt).  Placement is a speed matter only: the keys are
+    // agent-scope atomics either way.
+    const int b = blockIdx.y;
+    int w = blockIdx.x;
+    if (xcd_stride > 1) {
+        // linear workgroup id = blockIdx.x + gridDim.x * blockIdx.y; gridDim.x is a multiple of 8, so id % 8 == blockIdx.x % 8
+        if ((int)(blockIdx.x & 7) != (b & 7)) return;
+        w = blockIdx.x >> 3;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* P = xyz + (int64_t)b * N * 3;
     const float* soa_b = soa + (int64_t)b * 3 * npad;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)soa_b, 0, (int)(3 * npad * 4), 0x00020000);
     const int plane_bytes = (int)(npad * 4);
-    __shared__ float s_val[2][FPS_WAVES];
-    __shared__ int s_idx[2][FPS_WAVES];
+    __shared__ unsigned long long s_key[2][FPS_WAVES];
+    __shared__ int s_last[2];
     unsigned long long* cand_b = cand + (int64_t)b * 2 * 64;
-    unsigned* bar_b = bar + b;
 
     f32x4 md[PPT4], rx[PPT4], ry[PPT4], rz[PPT4];
 #pragma unroll
@@ -307,59 +338,66 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float* __re
         if (tid < 3) centers_out[(int64_t)b * G * 3 + tid] = P[tid];
     }
     for (int j = 1; j < G; ++j) {
-        const float cx = P[(int64_t)last * 3 + 0], cy = P[(int64_t)last * 3 + 1], cz = P[(int64_t)last * 3 + 2];
+        // the centre just selected: three scalar loads (uniform address; ~0.1 us from L2, scripts/exp/fabric_probe.hip)
+        const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[(int64_t)last * 3 + 0])));
+        const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[(int64_t)last * 3 + 1])));
+        const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[(int64_t)last * 3 + 2])));
+        asm volatile("s_nop 4");      // SGPRs possibly written by the VALU feed packed-fp32 VALU operands (inline asm) right below
+        // (a) the scan of fps_kernel: packed fp32, every operation individually rounded (the bits of dist2_exact), the thread's maximum VALUE
+        // only -- 5.5 VALU instructions per point instead of 12 with a (value, slot) pair carried along; with 16 waves sharing four SIMDs
+        // the scan of 16 points per thread was 1.4 us of a 2.5 us iteration
         float best = -1.0f;
-        int bslot = -1;
+        const fps_f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
         for (int g = 0; g < PPT4; ++g) {
-            float d;
-            d = dist2_exact(rx[g].x, ry[g].x, rz[g].x, cx, cy, cz); md[g].x = fminf(md[g].x, d); if (md[g].x > best) { best = md[g].x; bslot = 4 * g; }
-            d = dist2_exact(rx[g].y, ry[g].y, rz[g].y, cx, cy, cz); md[g].y = fminf(md[g].y, d); if (md[g].y > best) { best = md[g].y; bslot = 4 * g + 1; }
-            d = dist2_exact(rx[g].z, ry[g].z, rz[g].z, cx, cy, cz); md[g].z = fminf(md[g].z, d); if (md[g].z > best) { best = md[g].z; bslot = 4 * g + 2; }
-            d = dist2_exact(rx[g].w, ry[g].w, rz[g].w, cx, cy, cz); md[g].w = fminf(md[g].w, d); if (md[g].w > best) { best = md[g].w; bslot = 4 * g + 3; }
+            const f32x4 dx = fps_sub_bcast(rx[g], c2x), dy = fps_sub_bcast(ry[g], c2y), dz = fps_sub_bcast(rz[g], c2z);
+            const f32x4 d = (dx * dx + dy * dy) + dz * dz;      // -ffp-contract=off: no FMA
+            md[g] = f32x4{fps_min(md[g].x, d.x), fps_min(md[g].y, d.y), fps_min(md[g].z, d.z), fps_min(md[g].w, d.w)};
+            best = fmaxf(fmaxf(best, md[g].x), md[g].y);
+            best = fmaxf(fmaxf(best, md[g].z), md[g].w);
         }
-        int besti = bslot < 0 ? 0x7fffffff : (((w * PPT4 + (bslot >> 2)) * FPS_THREADS + tid) * 4 + (bslot & 3));
+        // (b) the wave's candidate: its maximum, then -- only in the lanes that hold it -- the lowest slot, the lowest global index among them.
+        // key: [63:32] min-distance bits (larger wins), [31:20] iteration tag, [19:0] 0xFFFFF - index (then the LOWER index wins; all keys
+        // of an iteration carry the same tag, so it never decides).  A wave of pure padding (maximum < 0) holds distance 0, index field 0.
+        // The tag makes the published key its own arrival flag: one store per workgroup and iteration, nothing to order it against.
+        const unsigned tag = (unsigned)j & 0xFFFu;
+        const float wmax = wave_max(best);
+        unsigned long long key = (unsigned long long)tag << 20;
+        if (wmax >= 0.f) {      // wave-uniform
+            int cand = 0x7fffffff;
+            if (best == wmax) {
+                int bslot = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(besti, o, 64);
-            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                for (int g = PPT4 - 1; g >= 0; --g) {      // descending: the lowest slot is assigned last
+                    if (md[g].w == wmax) bslot = 4 * g + 3;
+                    if (md[g].z == wmax) bslot = 4 * g + 2;
+                    if (md[g].y == wmax) bslot = 4 * g + 1;
+                    if (md[g].x == wmax) bslot = 4 * g;
+                }
+                cand = ((w * PPT4 + (bslot >> 2)) * FPS_THREADS + tid) * 4 + (bslot & 3);
+            }
+            const unsigned wmin = (unsigned)wave_min_dpp(cand);
+            key = ((unsigned long long)__builtin_bit_cast(unsigned, wmax) << 32) | (tag << 20) | (0xFFFFFu - wmin);
         }
         const int slot = j & 1;
-        if (lane == 0) { s_val[slot][wave] = best; s_idx[slot][wave] = besti; }
+        if (lane == 0) s_key[slot][wave] = key;
         __syncthreads();
         if (wave == 0) {
-            float v = lane < FPS_WAVES ? s_val[slot][lane] : -2.0f;
-            int vi = lane < FPS_WAVES ? s_idx[slot][lane] : 0x7fffffff;
-#pragma unroll
-            for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(v, o, 64);
-                const int oi = __shfl_xor(vi, o, 64);
-                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            static_assert(FPS_WAVES == 16, "one 16-lane row holds the waves' keys");
+            const unsigned long long wk = fps_row16_max_u64(s_key[slot][lane & 15]);
+            if (lane == 0) __hip_atomic_store(cand_b + slot * 64 + w, wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every lane < W polls one workgroup's slot until all of them carry this iteration's tag
+            unsigned long long k;
+            for (;;) {
+                k = lane < W ? __hip_atomic_load(cand_b + slot * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 20);
+                if (__all((((unsigned)k >> 20) & 0xFFFu) == tag)) break;
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (lane == 0) {
-                // key: larger min-distance wins, then the LOWER index; a workgroup of pure padding (v < 0) publishes 0
-                const unsigned long long key = v < 0.f ? 0ull : (((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (0xffffffffu - (unsigned)vi));
-                __hip_atomic_store(cand_b + slot * 64 + w, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // The key store is a write-through (sc1) store; it must be ACKNOWLEDGED before the arrival is counted.  A workgroup-scope
-                // release fence compiles to lgkmcnt(0) only on gfx950 (the store could still be in flight when another workgroup sees the
-                // counter reach its target), so drain the vector-memory counter explicitly (CDNA4 counts stores in vmcnt); inline asm so
-                // that the compiler cannot drop or move it.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(bar_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned target = (unsigned)j * (unsigned)W;
-                while (__hip_atomic_load(bar_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-            }
+            k = W <= 16 ? fps_row16_max_u64(k) : fps_wave_max_u64(k);      // W <= 16: the keys sit in lanes 0..15, one row
+            if (lane == 0) s_last[slot] = (int)(0xFFFFFu - ((unsigned)k & 0xFFFFFu));
         }
         __syncthreads();
-        unsigned long long k = lane < W ? __hip_atomic_load(cand_b + slot * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long ok = __shfl_xor(k, o, 64);
-            k = ok > k ? ok : k;
-        }
-        last = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
-        last = __builtin_amdgcn_readfirstlane(last);
+        last = __builtin_amdgcn_readfirstlane(s_last[slot]);
         if (w == 0) {
             if (tid == 0) idx_out[(int64_t)b * G + j] = last;
             if (tid < 3) centers_out[((int64_t)b * G + j) * 3 + tid] = P[(int64_t)last * 3 + tid];
@@ -367,7 +405,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float* __re
     }
 }
 
-__global__ void fps_coop_reset_kernel(unsigned* bar, int B) { if ((int)threadIdx.x < B) bar[threadIdx.x] = 0; }
+// every slot starts with tag 0xFFF (no iteration < 4095 waits for it; by then the slot has long been rewritten)
+__global__ void fps_coop_reset_kernel(unsigned long long* cand, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) cand[i] = ~0ull;
+}
 
 static int fps_num_cus() {
     static int cus = 0;
@@ -378,14 +420,24 @@ static int fps_num_cus() {
     return cus;
 }
 
-// cooperative layout: groups of 4096 points per workgroup, W <= 64 workgroups per cloud, all B*W resident
+// cooperative layout: groups of 4096 points, PPT4 of them per workgroup, W <= 64 workgroups per cloud, all B*W resident.  The hand-over
+// gets slower with W (1.0 us per iteration up to 16 workgroups on one XCD, 1.7 us at 32: profiles/r03_fabric_probe.txt), the scan with
+// PPT4 (16 waves share four SIMDs).  Measured per iteration (profiles/r03_fps_coop.txt, N = 131072): W = 16 x 8 points per thread 1.98 us,
+// W = 8 x 16 points 2.57 us, W = 32 x 4 points 2.98 us; N = 65536: W = 16 x 4 points 1.64 us, W = 8 x 8 points 1.85 us.  So: the fewest
+// points per thread that bring W down to 16, else as few workgroups as the registers allow (PPT4 <= 4).
 static int fps_coop_ppt4(int B, int N, int* W) {
-    if (N <= 32768 || B > 1024) return 0;
+    if (N <= 32768 || N > (1 << 20) || B > 1024) return 0;      // the hand-over key holds a 20-bit index
     const int64_t groups = fps_npad(N) / (4 * FPS_THREADS);
-    for (int ppt4 = 1; ppt4 <= 4; ppt4 *= 2) {
-        if (groups % ppt4 == 0 && groups / ppt4 <= 64 && (int64_t)B * (groups / ppt4) <= fps_num_cus()) { *W = (int)(groups / ppt4); return ppt4; }
+    static int ppt4_max = 0;      // tuning hook (environment, read once)
+    if (!ppt4_max) { const char* e = getenv("PSAM_FPS_COOP_PPT4"); ppt4_max = e && atoi(e) > 0 ? atoi(e) : 4; }
+    int best = 0;
+    for (int ppt4 = 1; ppt4 <= 4 && ppt4 <= ppt4_max; ppt4 *= 2) {
+        const int64_t w = groups / ppt4;
+        if (groups % ppt4 != 0 || w > 64 || (int64_t)B * w > fps_num_cus()) continue;
+        best = ppt4; *W = (int)w;
+        if (w <= 16) break;
     }
-    return 0;
+    return best;
 }
 
 PSAM_API size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G) {
@@ -395,7 +447,7 @@ PSAM_API size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G) {
     return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float) + (size_t)B * (2 * 64 * sizeof(unsigned long long) + 16);
 }
 
-static int g_fps_coop = 1;  // test hook: 0 forces the single-workgroup kernels
+static int g_fps_coop = 1;  // test hook: 0 forces the single-workgroup kernels, 2 the cooperative kernel without the one-XCD placement
 PSAM_API void psam_fps_set_cooperative(int32_t on) { g_fps_coop = on; }
 
 // xyz [B,N,3] f32 -> fps_idx [B,G] i64 (start index 0), centers [B,G,3] f32 (fused batch_index_select).
@@ -414,9 +466,11 @@ PSAM_API int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int
     const int coop = g_fps_coop ? fps_coop_ppt4(B, N, &W) : 0;
     if (coop) {
         unsigned long long* cand = (unsigned long long*)(mdg + (int64_t)B * npad);
-        unsigned* bar = (unsigned*)(cand + (int64_t)B * 2 * 64);
-        hipLaunchKernelGGL(fps_coop_reset_kernel, dim3(1), dim3(1024), 0, stream, bar, B);
-#define FPS_COOP(P) hipLaunchKernelGGL(fps_coop_kernel<P>, dim3(W, B), dim3(FPS_THREADS), 0, stream, xyz, soa, N, npad, G, W, cand, bar, fps_idx, centers)
+        hipLaunchKernelGGL(fps_coop_reset_kernel, dim3((unsigned)psam_cdiv(B * 128, 256)), dim3(256), 0, stream, cand, B * 128);
+        // one XCD (32 CUs) per cloud when its workgroups fit beside those of the other clouds dealt to the same XCD
+        const int xs = ((int64_t)W * psam_cdiv(B, 8) <= fps_num_cus() / 8 && g_fps_coop != 2) ? 8 : 1;
+#define FPS_COOP(P) \
+    hipLaunchKernelGGL(fps_coop_kernel<P>, dim3(W * xs, B), dim3(FPS_THREADS), 0, stream, xyz, soa, N, npad, G, W, xs, cand, fps_idx, centers)
         if (coop == 1) FPS_COOP(1); else if (coop == 2) FPS_COOP(2); else FPS_COOP(4);
 #undef FPS_COOP
         return psam_launch_status("psam_fps: launch failed");

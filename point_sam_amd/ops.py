@@ -264,6 +264,18 @@ def _f16x3p_call(fn_args, flops, M, N, K, fuse=None):
     _sampled_launch(lambda: check(L.psam_gemm_f16x3p_ex(*fn_args), "psam_gemm_f16x3p"), lambda s, e: GEMM_PROFILE.append((s, e, flops, M, N, K, "f16x3")))
 
 
+_SPLITK = {}
+
+
+def splitk_factor(M: int, N: int, K: int, act: int) -> int:
+    """Split-K factor the library suggests for a packed-operand GEMM shape (1: none); a pure function of the shape and the device."""
+    key = (M, N, K, act, torch.cuda.current_device())
+    ks = _SPLITK.get(key)
+    if ks is None:
+        ks = _SPLITK[key] = int(_lib.load().psam_gemm_f16x3p_splitk(M, N, K, act))
+    return ks
+
+
 def fuse_supported(M: int, N: int) -> bool:
     """Shapes for which the fused GEMM extras (packed output, LayerNorm partials, folded LayerNorm) exist."""
     return M % 256 == 0 and N % 128 == 0
@@ -332,6 +344,12 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
             xa, sa = scale_pack_rows_g8(x, K)
         fuse = None
         hyper_parts = None
+        if not fused and rowbias is None and act != ACT_SWIGLU and N % 4 == 0 and ldo % 4 == 0 and ldr % 4 == 0:
+            ks = splitk_factor(M, N, fw.Kp, act)
+            if ks > 1:      # few tiles, long K: partial planes + a fixed-order reduction (psam_gemm_fuse_t.splitk)
+                ws = torch.empty(ks, M * N, dtype=torch.float32, device=x.device)
+                fuse = _lib.GemmFuse()
+                fuse.splitk_ws, fuse.splitk_plane, fuse.splitk = ws.data_ptr(), M * N, ks
         if fused:
             fuse = _lib.GemmFuse()
             fuse.no_store = int(bool(no_store))
@@ -413,8 +431,13 @@ def swiglu_ln(gx, xoff, H, w, b, eps, out):
     return out
 
 
+def _f16x3_head_dim(hd: int) -> bool:
+    """Head dims of psam_attention_f16x3: 64, or a multiple of 8 in (64, 128] (zero-padded to 128 inside the kernel: the giant encoder's 88)."""
+    return hd == 64 or (64 < hd <= 128 and hd % 8 == 0)
+
+
 def attention_can_pack(hd: int) -> bool:
-    return GEMM_MODE == "f16x3" and hd in (64, 128)
+    return GEMM_MODE == "f16x3" and _f16x3_head_dim(hd)
 
 
 def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
@@ -426,11 +449,11 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
     args = (qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale)
     if pack is not None:
         if not attention_can_pack(hd):
-            raise ValueError("packed attention output needs the f16x3 kernel (head dim 64 or 128)")
+            raise ValueError("packed attention output needs the f16x3 kernel (head dim 64, or a multiple of 8 in (64, 128])")
         a_scale, k1, k2, o_scale = pack
         check(L.psam_attention_f16x3_ex(*args, a_scale.data_ptr(), float(k1), float(k2), o_scale.data_ptr(), _stream()), "psam_attention")
         return out
-    fn = L.psam_attention_f16x3 if (GEMM_MODE == "f16x3" and hd in (64, 128)) else L.psam_attention_f32
+    fn = L.psam_attention_f16x3 if (GEMM_MODE == "f16x3" and _f16x3_head_dim(hd)) else L.psam_attention_f32
     check(fn(*args, _stream()), "psam_attention")
     return out
 

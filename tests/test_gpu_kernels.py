@@ -59,7 +59,7 @@ def test_fps_bit_exact(ops, B, N, G, dup):
 
 @pytest.mark.parametrize("B,N,G,dup", [(1, 131072, 2048, 0), (2, 70000, 300, 20000), (3, 33000, 64, 0), (1, 300000, 40, 0), (1, 600000, 24, 0)])
 def test_fps_cooperative_bit_exact(ops, B, N, G, dup):
-    """N > 32768: the multi-workgroup FPS (per-iteration candidate exchange + counter barrier across workgroups) must give the
+    """N > 32768: the multi-workgroup FPS (per-iteration exchange of tagged candidate keys between workgroups) must give the
     oracle's indices bit for bit, and the same as the single-workgroup streaming kernel."""
     xyz, _ = _cloud(B, N, seed=N + G, dup=dup)
     want = O.fps(xyz, G)
@@ -67,12 +67,13 @@ def test_fps_cooperative_bit_exact(ops, B, N, G, dup):
     assert torch.equal(idx.cpu(), want)
     assert torch.equal(centers.cpu(), O.batch_index_select(xyz, want))
     L = ops._lib.load()
-    L.psam_fps_set_cooperative(0)
-    try:
-        idx1, _ = ops.fps(cu(xyz), G)
-    finally:
-        L.psam_fps_set_cooperative(1)
-    assert torch.equal(idx1, idx)
+    for mode in (0, 2):      # single-workgroup kernel; cooperative kernel with its workgroups spread over the XCDs
+        L.psam_fps_set_cooperative(mode)
+        try:
+            idx1, _ = ops.fps(cu(xyz), G)
+        finally:
+            L.psam_fps_set_cooperative(1)
+        assert torch.equal(idx1, idx), mode
 
 
 def test_fps_cooperative_under_memory_load(ops):
@@ -334,6 +335,45 @@ def test_gemm_f16x3_packed_activations(ops, M, N, K):
     with pytest.raises(ValueError):
         with ops.gemm_mode("f32"):
             ops.linear(xp, fw, x_scale=sa, x_packed=True)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(512, 1408, 6144, 0), (512, 1408, 1408, 1), (2048, 1024, 2784, 0), (300, 260, 1024, 2)])
+def test_gemm_f16x3_split_k(ops, M, N, K, act):
+    """Few tiles and a long K loop (one cloud through a wide encoder: fc2 / proj of the giant ViT at M = 512): split-K with a fixed-order
+    reduction.  fp32-grade against fp64 like the unsplit launch, bitwise reproducible, and chosen by the library for these shapes."""
+    import ctypes
+    from point_sam_amd import _lib
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    fw = ops.F16Weight(W)
+    ks = ops.splitk_factor(M, N, fw.Kp, act)
+    assert ks > 1, "these shapes are the ones split-K exists for"
+    with ops.gemm_mode("f16x3"):
+        got = ops.linear(x, fw, b, act=act, residual=res)
+        again = ops.linear(x, fw, b, act=act, residual=res)
+    assert torch.equal(got, again)
+    z = x.double() @ W.double().t() + b.double()
+    want = (torch.nn.functional.gelu(z) if act == 1 else z.clamp_min(0) if act == 2 else z) + res.double()
+    with ops.gemm_mode("f32"):
+        f32 = ops.linear(x, W, b, act=act, residual=res)
+    err, err32 = (got.double() - want).abs().max().item(), (f32.double() - want).abs().max().item()
+    print(f"\n[split-K {M}x{N}x{K} ks={ks}] max err {err:.2e} (f32 kernel {err32:.2e})")
+    assert err < 2 * err32 + 1e-6
+    # the unsplit launch through the C ABI agrees to fp32 rounding of the partial sums; a workspace that is too small is refused
+    xp, sa = ops.scale_pack_rows_g8(x)
+    L = _lib.load()
+    one = torch.empty(M, N, device="cuda")
+    args = lambda out, fuse: (xp.data_ptr(), xp.stride(0), sa.data_ptr(), fw.packed.data_ptr(), fw.packed.stride(0), fw.scale.data_ptr(), out.data_ptr(), N,
+                              b.data_ptr(), res.data_ptr(), N, None, 0, 0, M, N, fw.Kp, 1.0, act, fuse, None)
+    assert L.psam_gemm_f16x3p_ex(*args(one, None)) == 0
+    torch.cuda.synchronize()
+    assert (one - got).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    fuse = _lib.GemmFuse()
+    ws = torch.empty(ks * M * N - 4, device="cuda")
+    fuse.splitk_ws, fuse.splitk_plane, fuse.splitk = ws.data_ptr(), M * N - 4, ks
+    assert L.psam_gemm_f16x3p_ex(*args(one, ctypes.byref(fuse))) != 0
 
 
 @pytest.mark.parametrize("cols,ld", [(1024, 1024), (2730, 2752), (300, 320), (4096, 4096)])
@@ -716,7 +756,7 @@ def test_flash_attention(ops, hd, H, Lq, Lk):
 
 
 @pytest.mark.parametrize("hd,H,Lq,Lk", [(64, 4, 512, 512), (64, 2, 130, 70), (64, 3, 33, 200), (128, 2, 200, 129), (64, 1, 5, 64),
-                                        (64, 2, 2048, 2048), (64, 1, 1000, 2048)])
+                                        (64, 2, 2048, 2048), (64, 1, 1000, 2048), (88, 3, 512, 512), (88, 2, 77, 130), (96, 1, 100, 64)])
 def test_flash_attention_f16x3(ops, hd, H, Lq, Lk):
     """fp16-split flash attention: same tolerance as the f32-MFMA kernel against an fp64 SDPA; q/k/v with very different
     magnitudes per tensor and per row (the scales are per query row / per 64-key tile)."""
@@ -738,7 +778,7 @@ def test_flash_attention_f16x3(ops, hd, H, Lq, Lk):
     assert err < 2e-6 and err < 4 * err32 + 2e-7, (err, err32)
 
 
-@pytest.mark.parametrize("hd,H,L", [(64, 4, 512), (64, 2, 130), (128, 2, 200)])
+@pytest.mark.parametrize("hd,H,L", [(64, 4, 512), (64, 2, 130), (128, 2, 200), (88, 4, 512), (88, 8, 100)])
 def test_flash_attention_f16x3_packed_output(ops, hd, H, L):
     """Packed output of the fp16-split attention (for the output projection): decodes to the fp32 output's hi + lo (22 bits), one
     power-of-two scale per cloud derived from the BOUND of |V|, never overflowing fp16."""
