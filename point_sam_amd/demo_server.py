@@ -115,7 +115,7 @@ class DemoSession:
             if self.pc_xyz is None or not self.masks:
                 raise ValueError("/save needs a point cloud and at least one kept mask")
             os.makedirs(self.output_dir, exist_ok=True)
-            stem = (self.obj_path or "pointcloud").split(".")[0]
+            stem = os.path.splitext(os.path.basename(self.obj_path or "pointcloud"))[0] or "pointcloud"      # 'sub/x.ply' -> 'x', './x.ply' -> 'x'
             np.save(os.path.join(self.output_dir, f"{stem}.npy"),
                     {"xyz": self.pc_xyz[0].cpu().numpy(), "rgb": self.pc_rgb[0].cpu().numpy(), "mask": np.stack(self.masks)})
             self._reset_prompts()
@@ -128,17 +128,25 @@ class DemoSession:
         with self.lock:
             if self.pc_xyz is None:
                 raise ValueError("/segment before a point cloud was set")
-            self.prompts.append(data["prompt_point"])
-            self.labels.append(data["prompt_label"])
-            pts = torch.from_numpy(np.array(self.prompts)).to(self.device).float()[None]
-            lab = torch.from_numpy(np.array(self.labels)).to(self.device)[None]
+            # the click joins the session only after the predictor accepted it: a malformed point must not poison every later click
+            point = np.asarray(data["prompt_point"], dtype=np.float32)
+            label = int(data["prompt_label"])
+            if point.shape != (3,) or not np.isfinite(point).all():
+                raise ValueError("prompt_point must be three finite numbers")
+            prompts, labels = self.prompts + [point.tolist()], self.labels + [label]
+            pts = torch.from_numpy(np.array(prompts, dtype=np.float32)).to(self.device).float()[None]
+            lab = torch.from_numpy(np.array(labels)).to(self.device)[None]
             with torch.no_grad():
                 self.predictor.set_pointcloud(self.pc_xyz, self.pc_rgb)
                 mask, scores, logits = self.predictor.predict_masks(pts, lab, self.prompt_mask, self.prompt_mask is None)
+            self.prompts, self.labels = prompts, labels
             best = torch.argmax(scores[0])
             self.prompt_mask = logits[0][best][None]
             self.segment_mask = mask[0][best] > 0
             return {"seg": self.segment_mask.cpu().numpy().tolist()}
+
+
+MAX_BODY_BYTES = 64 << 20      # a sampled 10^5-point cloud as JSON is a few MB
 
 
 def make_handler(session: DemoSession, allow_origin: str = "*"):
@@ -190,7 +198,12 @@ def make_handler(session: DemoSession, allow_origin: str = "*"):
                 self._send(404, {"error": f"no route {path}"})
 
         def do_POST(self):
-            n = int(self.headers.get("Content-Length") or 0)
+            try:
+                n = int(self.headers.get("Content-Length") or 0)
+            except ValueError:
+                return self._send(400, {"error": "bad Content-Length"})
+            if n < 0 or n > MAX_BODY_BYTES:
+                return self._send(413, {"error": f"request body over {MAX_BODY_BYTES} bytes"})
             try:
                 data = json.loads(self.rfile.read(n) or b"{}")
             except json.JSONDecodeError as e:

@@ -191,8 +191,14 @@ def prepare_sample(xyz: np.ndarray, rgb: np.ndarray, instance_labels: np.ndarray
 @torch.no_grad()
 def evaluate_clouds(model, samples: Iterable[Dict[str, torch.Tensor]], adapt_grouper: bool = True, names: Iterable[str] = None) -> Dict[str, np.ndarray]:
     """IoU after each click, averaged over the masks of a cloud, then over clouds (eval_kitti.py:343-380).  names (optional, one
-    per sample): object names -- the per-object and object-mean IoU of eval_kitti.py:381-390 are reported too."""
+    per sample): object names -- the per-object and object-mean IoU of eval_kitti.py:381-390 are reported too.
+    Aggregation: `per_cloud` [clouds, iters] is the mean over a cloud's B*M masks, so every CLOUD weighs the same in `mean_iou_at_click`.
+    The reference keeps the mask axis ([iters, 1, B*M] averaged over the singleton axis) and averages masks later; for the single-mask KITTI
+    crops of eval_kitti.py both are the same number, for multi-mask samples (prepare_sample) with a varying mask count they differ --
+    `per_mask` (list of [iters, B*M] arrays, one per cloud) is returned so that a caller can reproduce either.  A mask with an empty union
+    (no ground truth, no prediction) has IoU NaN here as in the reference and propagates into its cloud's mean."""
     per_cloud: List[np.ndarray] = []
+    per_mask: List[np.ndarray] = []
     samples = list(samples)
     for data in samples:
         if adapt_grouper:
@@ -200,9 +206,10 @@ def evaluate_clouds(model, samples: Iterable[Dict[str, torch.Tensor]], adapt_gro
         outputs = model(**data, is_eval=True)
         gt = data["gt_masks"].flatten(0, 1)
         ious = [compute_iou(o["prompt_masks"], gt).float().cpu().numpy() for o in outputs]  # [iters][B*M]
-        per_cloud.append(np.array(ious).mean(axis=1))
+        per_mask.append(np.array(ious))
+        per_cloud.append(per_mask[-1].mean(axis=1))
     per_cloud_a = np.array(per_cloud)
-    out = dict(per_cloud=per_cloud_a, mean_iou_at_click=per_cloud_a.mean(axis=0))
+    out = dict(per_cloud=per_cloud_a, mean_iou_at_click=per_cloud_a.mean(axis=0), per_mask=per_mask)
     if names is not None:
         names = list(names)
         objs = {n: per_cloud_a[[i for i, m in enumerate(names) if m == n]].mean(axis=0) for n in dict.fromkeys(names)}

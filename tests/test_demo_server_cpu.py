@@ -18,11 +18,15 @@ class FakePredictor:
 
     def __init__(self):
         self.calls = []
+        self.fail_next = False
 
     def set_pointcloud(self, xyz, rgb):
         self.xyz = xyz
 
     def predict_masks(self, pts, labels, prompt_mask, multimask):
+        if self.fail_next:
+            self.fail_next = False
+            raise ValueError("predictor refused the prompt")
         self.calls.append((pts.clone(), labels.clone(), None if prompt_mask is None else prompt_mask.clone(), multimask))
         c = pts[0][labels[0].bool()].mean(0) if labels[0].bool().any() else pts[0].mean(0)
         logit = 0.5 - (self.xyz[0] - c).norm(dim=-1)
@@ -96,6 +100,30 @@ def test_sampled_pointcloud_and_errors(server):
     assert _req(port, "POST", "/next")[0] == 400                       # nothing segmented yet
     assert _req(port, "POST", "/nope")[0] == 404 and _req(port, "GET", "/index.html")[0] == 404
     assert _req(port, "GET", "/pointcloud/missing.ply")[0] == 400
+
+
+def test_failed_click_leaves_the_session_clean_and_save_uses_the_basename(server):
+    """A malformed /segment must not stay in the prompt list (every later click would carry it); /save names the file after the cloud's
+    base name whatever directory it was loaded from; an oversized body is refused before it is read."""
+    port, sess, pred, pts, tmp = server
+    (tmp / "sub").mkdir()
+    (tmp / "sub" / "deep.ply").write_bytes((tmp / "toy.ply").read_bytes())
+    st, out, _ = _req(port, "GET", "/pointcloud/sub/deep.ply")
+    assert st == 200
+    xyz = np.array(out["xyz"]).reshape(-1, 3)
+    for bad in ([0.1, 0.2], [0.1, float("nan"), 0.0], "xyz"):
+        st, out, _ = _req(port, "POST", "/segment", {"prompt_point": bad, "prompt_label": 1})
+        assert st == 400 and sess.prompts == [] and sess.labels == []
+    pred.fail_next = True
+    st, out, _ = _req(port, "POST", "/segment", {"prompt_point": xyz[2].tolist(), "prompt_label": 1})
+    assert st == 400 and sess.prompts == [] and sess.labels == []
+    st, out, _ = _req(port, "POST", "/segment", {"prompt_point": xyz[3].tolist(), "prompt_label": 1})
+    assert st == 200 and len(sess.prompts) == 1 and pred.calls[-1][0].shape == (1, 1, 3)
+    assert _req(port, "POST", "/next")[0] == 200 and _req(port, "POST", "/save")[1] == {"status": "saved"}
+    assert (tmp / "results" / "deep.npy").exists()
+    c = http.client.HTTPConnection("127.0.0.1", port, timeout=10)
+    c.putrequest("POST", "/segment"); c.putheader("Content-Length", str(1 << 30)); c.endheaders()
+    assert c.getresponse().status == 413
 
 
 def test_static_routes_and_path_sanitisation(tmp_path):
