@@ -163,6 +163,9 @@ typedef struct {
      * M * N floats apart), added in a fixed order with bias / activation / residual applied afterwards.  No other extras, act != SwiGLU,
      * no rowbias, N % 4 == 0, splitk <= K / 128.  psam_gemm_f16x3p_splitk() suggests the factor for a shape (1: none). */
     float* splitk_ws; int64_t splitk_plane; int32_t splitk;
+    /* pack_out with a bound PER ROW: out_scale[row] = f16_row_scale(out_bound[row]) instead of the k1 / k2 form (out_bound[row] >= max |output
+     * row|; psam_layernorm_ex2 writes it from the L2 norm of the A row).  Tighter than k1 / scaleA + k2 by sqrt(K) max|a| / ||a||_2. */
+    const float* out_bound;
 } psam_gemm_fuse_t;
 int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_t act);
 /* hyper without row_ln_*: any N % 128 == 0, M % 256 == 0; every 64-column wave tile contributes the partial products of its columns:
@@ -191,6 +194,11 @@ int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ld
  * room (needs row_scale; 256 <= cols <= 4096; 32-byte aligned output rows): the A operand of psam_gemm_f16x3p. */
 int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                           int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack, psam_stream_t stream);
+/* psam_layernorm_ex2: row_bound (optional, with pack, [rows]) receives c2 t^2 + c1 t + c0, t = 1.0001 x the L2 norm of the output row: the
+ * a-priori bound of the rows of the GEMM that consumes this output (|W_n . h + b_n| <= ||W_n|| t + |b_n|; psam_gemm_fuse_t.out_bound). */
+int32_t psam_layernorm_ex2(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
+                           int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack, float* row_bound, float c2,
+                           float c1, float c0, psam_stream_t stream);
 int32_t psam_layernorm_rs(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y, int64_t ldy,
                           int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, psam_stream_t stream);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "psam_layernorm": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr]),
     "psam_layernorm_rs": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, ptr]),
     "psam_layernorm_ex": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, i32, ptr]),
+    "psam_layernorm_ex2": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, f32, i32, ptr, i32, ptr, f32, f32, f32, ptr]),
     "psam_swiglu_ln": (i32, [ptr, i64, i32, ptr, ptr, ptr, i64, i64, i32, f32, ptr]),
     "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
@@ -74,7 +75,7 @@ class GemmFuse(ctypes.Structure):
     _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
                 ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
                 ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64),
-                ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32)]
+                ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32), ("out_bound", ptr)]
 
 
 _lib = None

@@ -639,19 +639,22 @@ __device__ __forceinline__ fa_s16x4 fa_ds_read_tr16(const unsigned char* lds_ptr
 #define FA_DMA16(rsrc, dst, voff, soff) ((void)(rsrc), (void)(dst), (void)(voff), (void)(soff))
 #endif
 
-constexpr int PA_BQ = 256;     // query rows per workgroup (8 waves x 32)
+constexpr int PA_BQ = 256;     // query rows per workgroup (8 waves x 32); the NW = 4 instance (128 rows) serves grids that would leave CUs idle
 #ifndef PA_PRIO
 #define PA_PRIO 1
 #endif
 constexpr int PA_TILE = FA_BKV * 256;      // bytes of one K (or V) tile: 64 keys x 64 channels x 4 B
 
-__global__ __launch_bounds__(512) void flash_attn_packed_kernel(const PackedAttnArgs p) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void flash_attn_packed_kernel(const PackedAttnArgs p) {
     constexpr int HD = 64, KS = 4, DT = 2, ROWB = 256;
+    constexpr int BQ = NW * 32, NPC = 32 / NW;      // query rows per workgroup; DMA pieces (of the 16 K + 16 V per tile) per wave
+    static_assert(NW == 8 || NW == 4, "waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [3][K tile | V tile]: ring of three tiles, ONE barrier per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
-    const int nq = (p.L + PA_BQ - 1) / PA_BQ, HB = p.H * p.B;
+    const int nq = (p.L + BQ - 1) / BQ, HB = p.H * p.B;
     int qb, hb;        // consecutive workgroup ids go to different XCDs: the query blocks of one (cloud, head) share an XCD's L2
     if ((HB & 7) == 0) { const int id = blockIdx.x, grp = id / (8 * nq), r = id - grp * 8 * nq; hb = grp * 8 + (r & 7); qb = r >> 3; }
     else { qb = blockIdx.x % nq; hb = blockIdx.x / nq; }
@@ -665,11 +668,11 @@ __global__ __launch_bounds__(512) void flash_attn_packed_kernel(const PackedAttn
     // for V (the 4 keys x 4 channel quads of a transposing read on 16 different slots).  8 waves x 4 pieces = K tile + V tile.
     const int nt = (p.L + FA_BKV - 1) / FA_BKV;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-    int dvoff[4];        // byte offset of this lane's chunk inside a tile's rows (row * rowb + column block + chunk * 16), tile base in soffset
-    int dkey[4];
+    int dvoff[NPC];        // byte offset of this lane's chunk inside a tile's rows (row * rowb + column block + chunk * 16), tile base in soffset
+    int dkey[NPC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pc = wave * 4 + i;                             // 0..15: K pieces, 16..31: V pieces
+    for (int i = 0; i < NPC; ++i) {
+        const int pc = wave * NPC + i;                           // 0..15: K pieces, 16..31: V pieces
         const bool isv = pc >= 16;
         const int row = (pc & 15) * 4 + (lane >> 4), slot = lane & 15;
         const int chunk = slot ^ (isv ? ((row & 1) | ((row & 2) << 2)) : (row & 15));
@@ -678,8 +681,8 @@ __global__ __launch_bounds__(512) void flash_attn_packed_kernel(const PackedAttn
     }
     auto issue_tile = [&](int t, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = wave * 4 + i;
+        for (int i = 0; i < NPC; ++i) {
+            const int pc = wave * NPC + i;
             int key = t * FA_BKV + dkey[i];
             key = key < p.L ? key : p.L - 1;                     // rows past the end are clamped (their scores are masked)
             unsigned char* dst = smem + buf * 2 * PA_TILE + (pc >= 16 ? PA_TILE : 0) + (pc & 15) * 1024;
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(512) void flash_attn_packed_kernel(const PackedAttn
     if (nt > 1) issue_tile(1, 1);
 
     // ---- this lane's query row: the hi / lo chunks of channels 16 s + 8 h .. + 7, as stored
-    const int q0 = qb * PA_BQ + wave * 32;
+    const int q0 = qb * BQ + wave * 32;
     const int qrow = q0 + r32;
     fa_f16x8 qh[KS], ql[KS];
     {
@@ -718,10 +721,10 @@ __global__ __launch_bounds__(512) void flash_attn_packed_kernel(const PackedAttn
 
     // the two waves of a SIMD run the same S^T -> softmax -> PV sequence: with equal priority they take the matrix pipe at the same time and
     // leave it idle at the same time; a standing priority for one of them lets it run unimpeded while the other fills its softmax gaps
-    if (PA_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (PA_PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     int buf = 0;
     for (int t = 0; t < (FA_ABL(128) ? 0 : nt); ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's pieces of tile t landed (tile t+1's may fly)
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");      // this wave's pieces of tile t landed (tile t+1's may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!FA_ABL(2)) __builtin_amdgcn_s_barrier();                          // tile t visible to every wave; every wave is done with tile t-1
         if (t + 2 < nt && !FA_ABL(1)) issue_tile(t + 2, buf == 0 ? 2 : buf - 1);      // ... whose buffer takes tile t+2
@@ -863,17 +866,26 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
     p.abl = g_attn_abl;
 #endif
     constexpr int lds = 3 * 2 * PA_TILE;        // 96 KiB
-    static unsigned long long attr_done = 0;      // > 64 KiB of dynamic LDS: opt in per device
+    static unsigned long long attr_done = 0;      // > 64 KiB of dynamic LDS: opt in per device (both instances at once)
+    int dev = 0, ncu = 256;
+    PSAM_REQUIRE(hipGetDevice(&dev) == hipSuccess, PSAM_EINVAL, "psam_attention_packed: no device");
     {
-        int dev = 0;
-        PSAM_REQUIRE(hipGetDevice(&dev) == hipSuccess, PSAM_EINVAL, "psam_attention_packed: no device");
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(__atomic_load_n(&attr_done, __ATOMIC_ACQUIRE) & bit)) {
-            PSAM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+            PSAM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+                         hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
                          PSAM_EINVAL, "psam_attention_packed: cannot reserve LDS");
             __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
         }
     }
-    hipLaunchKernelGGL(flash_attn_packed_kernel, dim3((unsigned)(psam_cdiv(L, PA_BQ) * H * B)), dim3(512), lds, stream, p);
+    static int force_nw = -1;      // tuning hook (environment, read once): PSAM_ATTN_PACKED_NW = 4 | 8
+    if (force_nw < 0) { const char* e = getenv("PSAM_ATTN_PACKED_NW"); force_nw = e ? atoi(e) : 0; }
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    // 256-row workgroups (two waves per SIMD cover each other's softmax gaps) unless they would leave CUs without work: one cloud of 2048 tokens
+    // and 16 heads is 128 of them on 256 CUs (99 us); 128-row workgroups fill the chip
+    const int64_t wg8 = (int64_t)psam_cdiv(L, PA_BQ) * H * B;
+    const bool small = force_nw ? force_nw == 4 : (wg8 < ncu && L > PA_BQ / 2);
+    if (small) hipLaunchKernelGGL(flash_attn_packed_kernel<4>, dim3((unsigned)(psam_cdiv(L, PA_BQ / 2) * H * B)), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(flash_attn_packed_kernel<8>, dim3((unsigned)wg8), dim3(512), lds, stream, p);
     return psam_launch_status("psam_attention_packed: launch failed");
 }

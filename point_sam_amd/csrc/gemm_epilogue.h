@@ -72,7 +72,10 @@ __device__ __forceinline__ EpRows<TM> gemm_epilogue_rows(const ArgsT& p, int row
         o.rs[t] = 1.f; o.mean[t] = 0.f; o.rstd[t] = 1.f;
         if (row >= 0) {
             if constexpr (SCALED) o.rs[t] = p.scaleA[row];      // RAW scale (a power of two): inverted where it is used, so that nothing waits for this load early
-            if constexpr (EXT) { if (p.ln_c) { o.mean[t] = p.ln_mean[row]; o.rstd[t] = p.ln_rstd[row]; } }
+            if constexpr (EXT) {
+                if (p.ln_c) { o.mean[t] = p.ln_mean[row]; o.rstd[t] = p.ln_rstd[row]; }
+                else if (p.out_bound) o.mean[t] = p.out_bound[row];      // the packed output's per-row bound travels in the (unused) mean slot
+            }
         }
     }
     return o;
@@ -274,8 +277,10 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     o_hyper = HYPER && (F < 0 ? (p.hyper != nullptr) : bool(F & EP_HYPER));
                     o_nostore = F < 0 ? (p.no_store != 0) : bool(F & EP_NOSTORE);
                 }
+                bool o_bnd = false;      // packed output scaled by a per-row bound the caller supplies (run-time test: uniform, once per pass)
+                if constexpr (EXT) o_bnd = o_pack && !o_lnc && p.out_bound != nullptr;
                 // what happens to a finished value (after the residual): group maximum, write-back for the hyper row pass, packed or plain store
-                auto finish = [&](ep_f32x4 v, int rl, int row, float rsq) {
+                auto finish = [&](ep_f32x4 v, int rl, int row, float rsq, float obnd) {
                     if (!o_swiglu) {
                         if constexpr (EXT) {
                             if (o_gmax) gm = ep_f32x4{fmaxf(gm[0], v[0]), fmaxf(gm[1], v[1]), fmaxf(gm[2], v[2]), fmaxf(gm[3], v[3])};
@@ -288,7 +293,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     if constexpr (EXT) {
                         if (o_pack) {      // g8-packed output with the bound-derived row scale (see the header of this function)
                             const float bnd = p.out_k1 * rsq + p.out_k2;          // rsq = 1 / scaleA[row]
-                            const float so = f16_row_scale(o_swiglu ? bnd * bnd : bnd);
+                            const float so = f16_row_scale(o_bnd ? obnd : (o_swiglu ? bnd * bnd : bnd));
                             if (c4 == 0 && col_base == 0) p.out_scale[row] = so;
                             unsigned h0, l0, h1, l1;
                             psam_split2_f16(v[0], v[1], so, h0, l0);
@@ -314,6 +319,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     o.rsq = inv_pow2(__shfl(rows.rs[i >> 1], srcl, 64));
                     o.lmean = 0.f; o.lrstd = 1.f;
                     if (o_lnc) { o.lmean = __shfl(rows.mean[i >> 1], srcl, 64); o.lrstd = __shfl(rows.rstd[i >> 1], srcl, 64); }
+                    else if (o_bnd) o.lmean = __shfl(rows.mean[i >> 1], srcl, 64);
                     o.v = ep_f32x4{0.f, 0.f, 0.f, 0.f}; o.x = o.v;
                     if (ALL_ON || lane_on) {
                         o.v = ep_load4(lw + rl * LD + scol);
@@ -381,7 +387,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                         if constexpr (EXT) { if (p.epi_abl & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.456f) C[0] = v[0]; continue; } }
 #endif
                         if (o_res) *reinterpret_cast<ep_f32x4*>(lw + rl * LD + scol) = v;      // parked: the residual rows (in flight since before the staging) are added below
-                        else finish(v, rl, row, rsq);
+                        else finish(v, rl, row, rsq, cur.lmean);
                     }
                 }
                 if (o_res) {     // residual add + store, unrolled over the prefetched rows: every parked float4 is read back first (each lane its own), ONE
@@ -390,13 +396,14 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     for (int c0 = 0; c0 < NPMAX; c0 += RP) {
                         if (c0 > 0 && c0 < np && lane_on) load_res(c0);
                         ep_f32x4 pv[RP];
-                        float prs[RP];
+                        float prs[RP], pbd[RP];
 #pragma unroll
                         for (int q = 0; q < RP; ++q) {
-                            prs[q] = 1.f;
+                            prs[q] = 1.f; pbd[q] = 0.f;
                             if (c0 + q < np) {
                                 const int rl = (c0 + q) * rpp + rl0;
                                 if (o_pack) prs[q] = inv_pow2(__shfl(rows.rs[i >> 1], ((i & 1) * 32 + rl) & 63, 64));
+                                if (o_bnd) pbd[q] = __shfl(rows.mean[i >> 1], ((i & 1) * 32 + rl) & 63, 64);
                                 if (ALL_ON || lane_on) pv[q] = ep_load4(lw + rl * LD + scol);
                             }
                         }
@@ -405,7 +412,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                         for (int q = 0; q < RP; ++q) {
                             if (c0 + q < np) {
                                 const int rl = (c0 + q) * rpp + rl0;
-                                if (ALL_ON || lane_on) finish(pv[q] + res[q], rl, row_base + i * 32 + rl, prs[q]);
+                                if (ALL_ON || lane_on) finish(pv[q] + res[q], rl, row_base + i * 32 + rl, prs[q], pbd[q]);
                             }
                         }
                     }

@@ -446,6 +446,7 @@ struct psam_gemm_fuse_t {
     // split-K (few tiles, long K: one cloud through a wide encoder): `splitk` workgroups per tile write partial products to the planes of
     // splitk_ws (splitk_plane >= M * N floats apart), a second kernel adds them in a fixed order and applies bias / activation / residual
     float* splitk_ws; int64_t splitk_plane; int32_t splitk;
+    const float* out_bound;     // pack_out: out_scale[row] = f16_row_scale(out_bound[row]) (a bound per row, e.g. from psam_layernorm_ex2)
 };
 
 // partial planes the hyper products of an N-column GEMM are delivered in: 1 with the row-LayerNorm (full-row) epilogue, N / 64 otherwise
@@ -526,7 +527,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.C = C; p.bias = bias; p.residual = residual; p.rowbias = rowbias;
     p.scaleA = scaleA; p.scaleW = scaleW; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.M = M; p.N = N; p.K = K; p.rowgroup = rowgroup > 0 ? rowgroup : 1; p.act = act; p.alpha = alpha;
-    p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
+    p.out_scale = nullptr; p.out_k1 = p.out_k2 = 0.f; p.pack_out = 0; p.out_bound = nullptr; p.stats = nullptr; p.stat_cols = 0; p.stat_segs = 0;
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
     p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0; p.epi_abl = 0;
@@ -600,6 +601,8 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         PSAM_REQUIRE(!fuse->ln_c || (fuse->ln_mean && fuse->ln_rstd && act != 3), PSAM_EINVAL, "psam_gemm_f16x3p_ex: folded LayerNorm needs mean, rstd, c (no SwiGLU)");
         PSAM_REQUIRE(((uintptr_t)fuse->ln_c & 15) == 0, PSAM_EALIGN, "psam_gemm_f16x3p_ex: ln_c must be 16-byte aligned");
         p.out_scale = fuse->out_scale; p.out_k1 = fuse->out_k1; p.out_k2 = fuse->out_k2; p.pack_out = fuse->pack_out;
+        p.out_bound = fuse->pack_out ? fuse->out_bound : nullptr;
+        PSAM_REQUIRE(!p.out_bound || !fuse->ln_c, PSAM_EINVAL, "psam_gemm_f16x3p_ex: out_bound does not combine with the folded LayerNorm");
         p.stats = fuse->stats; p.stat_cols = fuse->stat_cols; p.stat_segs = psam_gemm_f16x3p_stat_segs(N);
         p.ln_mean = fuse->ln_mean; p.ln_rstd = fuse->ln_rstd; p.ln_c = fuse->ln_c;
         PSAM_REQUIRE(!fuse->gmax_out || ((fuse->gmax_k == 32 || fuse->gmax_k == 64) && act != 3 && (fuse->gmax_ld & 3) == 0 && fuse->gmax_ld >= N &&

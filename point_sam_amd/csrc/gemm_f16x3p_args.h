@@ -18,6 +18,7 @@ struct F16PArgs {
     int tiles_m, tiles_n, panel;      // panel: width (in column tiles) of the column panels the tile order walks row-major (f16x3p_panel)
     // fused extras (psam_gemm_fuse_t, see gemm_epilogue.h): all null / 0 for the plain GEMM
     float* out_scale; float out_k1, out_k2; int pack_out;
+    const float* out_bound;           // pack_out: per-row bound of the output (replaces the k1 / k2 form)
     float* stats; int stat_cols, stat_segs;
     const float* ln_mean; const float* ln_rstd; const float* ln_c;
     float* gmax_out; int64_t gmax_ld; int gmax_k, no_store;

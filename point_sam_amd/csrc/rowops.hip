@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NV4>
 __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldr,
                                                            const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
-                                                           int64_t ldy, int64_t rows, int cols, float eps, int act, float* __restrict__ rscale, int pack) {
+                                                           int64_t ldy, int64_t rows, int cols, float eps, int act, float* __restrict__ rscale, int pack,
+                                                           float* __restrict__ rbound, float bc2, float bc1, float bc0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
@@ -154,6 +155,13 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
             v[i] = o;
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         }
+        if (rbound) {      // bc2 t^2 + bc1 t + bc0 with t = ||output row||_2: what the consuming GEMM's epilogue bounds ITS output rows with (psam_gemm_fuse_t.out_bound)
+            float n2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV4; ++i) n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            const float t = sqrtf(wave_sum(n2)) * 1.0001f;
+            if (lane == 0) rbound[row] = (bc2 * t + bc1) * t + bc0;
+        }
         amax = wave_max(amax);
         const float sc = f16_row_scale(amax);
         if (lane == 0) rscale[row] = sc;
@@ -201,10 +209,13 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
 // row_scale (optional, [rows]): the f16x3 GEMM's power-of-two row scale of the OUTPUT rows (psam_row_scale_f16 fused in).
 // pack != 0: y receives the g8-packed form of the row-scaled output (psam_pack_rows_f16x2_g8 fused in; needs row_scale and the
 // float4 path: 256 <= cols <= 4096, 32-byte aligned output rows) -- the A operand of psam_gemm_f16x3p.
-PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
-                                   int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack,
-                                   hipStream_t stream) {
+// row_bound (optional, packed output only, [rows]): c2 t^2 + c1 t + c0 with t = the L2 norm of the output row (times 1.0001) -- the a-priori
+// bound of the rows of a GEMM that consumes this output, e.g. |W_n . h + b_n| <= ||W_n|| t + |b_n| (psam_gemm_fuse_t.out_bound).
+PSAM_API int32_t psam_layernorm_ex2(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                    int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack,
+                                    float* row_bound, float c2, float c1, float c0, hipStream_t stream) {
     PSAM_REQUIRE(x && w && b && y, PSAM_EINVAL, "psam_layernorm: null pointer");
+    PSAM_REQUIRE(!row_bound || pack, PSAM_EINVAL, "psam_layernorm: row_bound comes with the packed output");
     PSAM_REQUIRE(rows > 0 && cols > 0, PSAM_EINVAL, "psam_layernorm: bad shape");
     PSAM_REQUIRE(act == 0 || act == 1, PSAM_EINVAL, "psam_layernorm: act must be 0 or 1 (GELU)");
     const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
@@ -214,7 +225,7 @@ PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res
     PSAM_REQUIRE(!pack || (vec && row_scale && (ldy & 7) == 0 && ((uintptr_t)y & 31) == 0 && ldy >= ((cols + 7) & ~7)), PSAM_EINVAL,
                  "psam_layernorm: packed output needs row_scale, the float4 path (256 <= cols <= 4096, aligned) and 32-byte aligned output rows");
     if (vec) {
-#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale, pack)
+#define LNV_LAUNCH(R) hipLaunchKernelGGL(layernorm_v4_kernel<R>, grid, block, 0, stream, x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale, pack, row_bound, c2, c1, c0)
         const int span = pack ? ((cols + 31) & ~31) : cols;     // the packed form also writes the zero padding up to the 32-k slab
         if (span <= 256) LNV_LAUNCH(1);
         else if (span <= 512) LNV_LAUNCH(2);
@@ -233,6 +244,12 @@ PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res
     else LN_LAUNCH(0);
 #undef LN_LAUNCH
     return psam_launch_status("psam_layernorm: launch failed");
+}
+
+PSAM_API int32_t psam_layernorm_ex(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,
+                                   int64_t ldy, int64_t rows, int32_t cols, float eps, int32_t act, float* row_scale, int32_t pack,
+                                   hipStream_t stream) {
+    return psam_layernorm_ex2(x, ldx, res, ldr, w, b, y, ldy, rows, cols, eps, act, row_scale, pack, nullptr, 0.f, 0.f, 0.f, stream);
 }
 
 PSAM_API int32_t psam_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldr, const float* w, const float* b, float* y,

@@ -426,10 +426,22 @@ static int fps_num_cus() {
 // W = 8 x 16 points 2.57 us, W = 32 x 4 points 2.98 us; N = 65536: W = 16 x 4 points 1.64 us, W = 8 x 8 points 1.85 us.  So: the fewest
 // points per thread that bring W down to 16, else as few workgroups as the registers allow (PPT4 <= 4).
 static int fps_coop_ppt4(int B, int N, int* W) {
-    if (N <= 32768 || N > (1 << 20) || B > 1024) return 0;      // the hand-over key holds a 20-bit index
+    static int ppt4_max = 0, min_groups = 0;      // tuning hooks (environment, read once)
+    if (!ppt4_max) {
+        const char* e = getenv("PSAM_FPS_COOP_PPT4"); ppt4_max = e && atoi(e) > 0 ? atoi(e) : 4;
+        const char* f = getenv("PSAM_FPS_COOP_MIN_GROUPS"); min_groups = f && atoi(f) > 0 ? atoi(f) : 8;
+    }
     const int64_t groups = fps_npad(N) / (4 * FPS_THREADS);
-    static int ppt4_max = 0;      // tuning hook (environment, read once)
-    if (!ppt4_max) { const char* e = getenv("PSAM_FPS_COOP_PPT4"); ppt4_max = e && atoi(e) > 0 ? atoi(e) : 4; }
+    if (groups < min_groups || N > (1 << 20) || B > 1024) return 0;      // the hand-over key holds a 20-bit index
+    if (groups == 8) {
+        // N = 32768 (cfg #2 / #5): the single-workgroup kernel scans 32 points per thread (2.6 us per iteration).  Eight workgroups of 4 points
+        // per thread: 1.72 us (0.88 instead of 1.3 ms for G = 512) -- but eight CUs per cloud instead of one, which a batch running beside the
+        // dense stage of the previous one cannot afford (two workgroups of 16 points: 2.55 us, no gain; profiles/r03_fps_coop.txt).  So
+        // only for one or two clouds (the interactive case).
+        if (B > 2 || ppt4_max < 1) return 0;
+        *W = 8;
+        return 1;
+    }
     int best = 0;
     for (int ppt4 = 1; ppt4 <= 4 && ppt4 <= ppt4_max; ppt4 *= 2) {
         const int64_t w = groups / ppt4;

@@ -69,6 +69,7 @@ class PointCloudSAM:
         if precision not in ops.GEMM_MODES:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
         self.precision = precision
+        self.row_bounds = True    # "f16x3": the fused MLP's packed rows are scaled by a per-row bound from ||h||_2 (False: the (k1 / scale + k2)^2 form)
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
         self.fuse_attn_pack = True  # "f16x3": the attention kernel writes its output packed for the output projection (bound-derived scale)
         # "f16x3", head dim 64: the qkv GEMM writes q | k | v already packed (one a-priori power-of-two scale) and the attention kernel consumes
@@ -167,10 +168,23 @@ class PointCloudSAM:
                     blk.w2g = ops.F16Weight(w2g.float().contiguous())
                     blk.k1 = float(2.0 ** 15 * math.sqrt(D) * blk.w1.double().norm(dim=1).max().item())
                     blk.k2 = float(blk.b1.abs().max().item())
+                    # per-row bound of the gated rows from t = ||h||_2 (the LayerNorm kernel emits it): hidden unit n has
+                    # |silu(g_n) x_n| <= (a_n t + b_n)(c_n t + d_n) with a, c the fc1_g / fc1_x weight row norms and b, d the |biases|;
+                    # the maximum over n of the quadratic is bounded coefficient-wise.  Outlier rows of fc1_g and fc1_x rarely share an n,
+                    # and ||h||_2 is far below sqrt(D) max|h| when h has outlier channels: the (k1 / scale + k2)^2 form lost 10+ bits on
+                    # heavy-tailed weights (tests/test_gpu_e2e.py::test_heavy_tailed_weights_against_oracle, profiles/r03_heavy_diag.txt)
+                    a_n, c_n = w[blk.p + ".mlp.fc1_g.weight"].double().norm(dim=1), w[blk.p + ".mlp.fc1_x.weight"].double().norm(dim=1)
+                    b_n, d_n = w[blk.p + ".mlp.fc1_g.bias"].double().abs(), w[blk.p + ".mlp.fc1_x.bias"].double().abs()
+                    blk.u_bound = (1.002 * float((a_n * c_n).max()), 1.002 * float((a_n * d_n + b_n * c_n).max()), 1.002 * float((b_n * d_n).max()) + 1e-30)
                 # a-priori bounds of |q|, |k|, |v| (packed qkv for the operand-packed attention) and of |v| alone (its packed output):
                 # |W_n . h + b_n| <= ||W_n||_2 ||h||_2 + |b_n|, and a LayerNorm output h = z * gamma + beta has ||h||_2 <= max|gamma| sqrt(D) + ||beta||_2
                 g1, b1n = w[blk.p + ".norm1.weight"].double(), w[blk.p + ".norm1.bias"].double()
                 hnorm = float(g1.abs().max() * math.sqrt(D) + b1n.norm())
+                if not cfg.vit.swiglu:
+                    # GELU MLP (the giant encoder): fc1 writes GELU(.) packed for fc2 with one a-priori scale, |GELU(t)| <= |t|
+                    g2, b2n = w[blk.p + ".norm2.weight"].double(), w[blk.p + ".norm2.bias"].double()
+                    blk.fc1_bound = 1.001 * (float(blk.w1.double().norm(dim=1).max()) * float(g2.abs().max() * math.sqrt(D) + b2n.norm())
+                                             + float(blk.b1.abs().max())) + 1e-30
                 wq_all = blk.wqkv.double()
                 blk.qkv_bound = 1.001 * (float(wq_all.norm(dim=1).max()) * hnorm + float(blk.bqkv.abs().max())) + 1e-30
                 blk.v_bound = 1.001 * (float(wq_all[2 * D:].norm(dim=1).max()) * hnorm + float(blk.bqkv[2 * D:].abs().max())) + 1e-30
@@ -277,19 +291,23 @@ class PointCloudSAM:
         else:
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, L, L, hd, hd ** -0.5)
             self._lin(p + ".attn.proj", o, residual=x, out=x)
-        self._ln(p + ".norm2", x, vit.ln_eps, out=h, scale_out=rs, pack=pk)
+        fused_swiglu = (vit.swiglu and pk and self.fuse_mlp and hasattr(blk, "w2g") and ops.fuse_supported(x.shape[0], 2 * blk.hp)
+                        and ops.fuse_supported(x.shape[0], D))
+        ub = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if fused_swiglu and self.row_bounds else None
+        self._ln(p + ".norm2", x, vit.ln_eps, out=h, scale_out=rs, pack=pk, bound_out=None if ub is None else (ub,) + blk.u_bound)
         if vit.swiglu:
             # fc1 with the SiLU gate fused in the GEMM epilogue -> u [M, Hp] (pad columns exactly 0), inner LayerNorm over
             # the first H columns in place, then fc2 over K = Hp (zero-padded weight columns)
             Hh = vit.mlp_hidden
             M = x.shape[0]
-            if pk and self.fuse_mlp and hasattr(blk, "w2g") and ops.fuse_supported(M, 2 * blk.hp) and ops.fuse_supported(M, D):
+            if fused_swiglu:
                 # two GEMMs, nothing in between: fc1 writes the gated rows g8-packed (bound-derived scales su) and their LayerNorm
                 # partials; fc2 runs on them with the LayerNorm folded in (mean / rstd per row from the partials)
                 u = torch.empty(M, blk.hp, dtype=torch.float32, device=x.device)
                 su = torch.empty(M, dtype=torch.float32, device=x.device)
                 st = torch.empty(M, ops.stat_segs(2 * blk.hp), 2, dtype=torch.float32, device=x.device)
-                ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=True, out=u, pack_out=(su, blk.k1, blk.k2), stats=(st, Hh))
+                ops.linear(h, blk.w1, blk.b1, act=ops.ACT_SWIGLU, x_scale=rs, x_packed=True, out=u, stats=(st, Hh),
+                           pack_out=(su, blk.k1, blk.k2) if ub is None else (su, ub))
                 mean, rstd = ops.ln_stats_finalize(st, Hh, vit.ln_eps)
                 ops.linear(u, blk.w2g, blk.ln_d, residual=x, out=x, x_scale=su, x_packed=True, ln_fold=(mean, rstd, blk.ln_c))
                 return x
@@ -299,8 +317,17 @@ class PointCloudSAM:
                           pack=pk2)
             ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=rs if pk2 else None, x_packed=pk2)
         else:
-            g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=pk)
-            ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
+            M, Hh = x.shape[0], vit.mlp_hidden
+            if (pk and self.fuse_mlp and isinstance(blk.w2, ops.F16Weight) and ops.fuse_supported(M, Hh) and Hh % 32 == 0
+                    and ops.splitk_factor(M, Hh, blk.w1.Kp, ACT_GELU) == 1):
+                # fc1 leaves GELU(.) g8-packed for fc2 (one scale from the a-priori bound): no scale + pack pass over the [M, hidden] rows
+                g = torch.empty(M, Hh, dtype=torch.float32, device=x.device)
+                sg = torch.empty(M, dtype=torch.float32, device=x.device)
+                ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=True, out=g, pack_out=(sg, 0.0, blk.fc1_bound))
+                ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=sg, x_packed=True)
+            else:
+                g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=pk)
+                ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x)
         return x
 
     # ------------------------------------------------------------------------------------------ encoder

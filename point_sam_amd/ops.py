@@ -308,7 +308,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
     "f16x3" mode with an F16Weight and M above the threshold runs the packed-operand GEMM (csrc/gemm_f16x3p.hip): x is either already
     g8-packed by its producer (x_packed=True with x_scale: LayerNorm / scale_pack_rows_g8 output, [M, >= K padded to 32]) or is
     scaled and packed here in one extra pass.  Fused extras of that GEMM (fuse_supported shapes; include/pointsam_hip.h psam_gemm_fuse_t):
-    pack_out=(scale_out [M], k1, k2): `out` receives g8-packed rows + their bound-derived scales; stats=(buf [M, stat_segs(N), 2], cols):
+    pack_out=(scale_out [M], k1, k2) or (scale_out [M], bound [M]): `out` receives g8-packed rows + their bound-derived scales; stats=(buf [M, stat_segs(N), 2], cols):
     LayerNorm partials of the SwiGLU-gated rows; ln_fold=(mean [M], rstd [M], c [N]): LayerNorm of x folded into the GEMM;
     group_max_out [M / group_max_k, N] (group_max_k 32 | 64): per-column max over consecutive row groups of the output, no_store: the
     [M, N] output itself is not written (out may then be None).  N == 256 only: row_ln=(gamma, beta, eps): LayerNorm of every output
@@ -366,7 +366,9 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
                 if planes > 1:      # partial products per 64-column wave tile: N / 64 planes, added below in a fixed order
                     hyper_parts = torch.empty(planes, mk.numel(), dtype=torch.float32, device=mk.device)
                     fuse.masks, fuse.hyper_pstride = hyper_parts.data_ptr(), mk.numel()
-            if pack_out is not None:
+            if pack_out is not None and len(pack_out) == 2:      # (scale_out, per-row bound of the output): see psam_gemm_fuse_t.out_bound
+                fuse.out_scale, fuse.out_bound, fuse.pack_out = pack_out[0].data_ptr(), pack_out[1].data_ptr(), 1
+            elif pack_out is not None:
                 fuse.out_scale, fuse.out_k1, fuse.out_k2, fuse.pack_out = pack_out[0].data_ptr(), float(pack_out[1]), float(pack_out[2]), 1
             if stats is not None:
                 fuse.stats, fuse.stat_cols = stats[0].data_ptr(), int(stats[1])
@@ -408,17 +410,24 @@ def packed_cols(cols: int) -> int:
     return _kpad(cols)
 
 
-def layernorm(x, w, b, eps, act=ACT_NONE, residual=None, out=None, scale_out=None, pack=False):
+def layernorm(x, w, b, eps, act=ACT_NONE, residual=None, out=None, scale_out=None, pack=False, bound_out=None):
     """y = act(LN(x + residual)) over the last dim of a 2-D row view.  scale_out ([rows] fp32, optional) receives the f16x3
     row scales of y (what row_scale_f16(y) would compute), for the GEMM that consumes y.  pack=True: out receives the g8-packed
     form of the scaled rows instead of fp32 (linear(..., x_scale=scale_out, x_packed=True)); out needs packed_cols(cols) columns
-    of room per row for the zero padding (or exactly cols when cols % 8 == 0 and the padding already holds zeros)."""
+    of room per row for the zero padding (or exactly cols when cols % 8 == 0 and the padding already holds zeros).
+    bound_out=(buf [rows], c2, c1, c0) (with pack): buf[r] = c2 t^2 + c1 t + c0, t = ||y[r]||_2 -- the per-row output bound of the GEMM that
+    consumes y (linear(..., pack_out=(scale_out, buf)))."""
     xp, ldx = _row_view(x, "x")
     rows, cols = x.shape
     if out is None:
         out = torch.empty(rows, _kpad(cols) if pack else cols, dtype=torch.float32, device=x.device)
     op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
+    if bound_out is not None:
+        bb, c2, c1, c0 = bound_out
+        check(_lib.load().psam_layernorm_ex2(xp, ldx, rp, ldr, w.data_ptr(), b.data_ptr(), op, ldo, rows, cols, eps, act, _p(scale_out), 1 if pack else 0,
+                                             bb.data_ptr(), float(c2), float(c1), float(c0), _stream()), "psam_layernorm")
+        return out
     check(_lib.load().psam_layernorm_ex(xp, ldx, rp, ldr, w.data_ptr(), b.data_ptr(), op, ldo, rows, cols, eps, act, _p(scale_out), 1 if pack else 0,
                                         _stream()), "psam_layernorm")
     return out

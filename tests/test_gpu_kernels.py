@@ -57,7 +57,8 @@ def test_fps_bit_exact(ops, B, N, G, dup):
     assert torch.equal(centers.cpu(), O.batch_index_select(xyz, want))
 
 
-@pytest.mark.parametrize("B,N,G,dup", [(1, 131072, 2048, 0), (2, 70000, 300, 20000), (3, 33000, 64, 0), (1, 300000, 40, 0), (1, 600000, 24, 0)])
+@pytest.mark.parametrize("B,N,G,dup", [(1, 131072, 2048, 0), (2, 70000, 300, 20000), (3, 33000, 64, 0), (1, 300000, 40, 0), (1, 600000, 24, 0),
+                                           (3, 32768, 200, 5000), (2, 30000, 100, 0)])
 def test_fps_cooperative_bit_exact(ops, B, N, G, dup):
     """N > 32768: the multi-workgroup FPS (per-iteration exchange of tagged candidate keys between workgroups) must give the
     oracle's indices bit for bit, and the same as the single-workgroup streaming kernel."""
