@@ -240,6 +240,28 @@ int32_t psam_attention_packed(const void* qkv, int64_t ld, const float* sc, floa
 int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                            float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 
+/* Token side of one TwoWayAttentionBlock in ONE launch (csrc/twoway.hip): self-attention + norm1, token -> image attention + norm2, the MLP
+ * + norm3 on the Z * T <= 64 output-token rows, and the k / v projections of the image -> token attention that follows -- what
+ * pc_sam/model/transformer.py:144-175 does for `queries`; mode 1: only the token -> image attention + LayerNorm of :91-99
+ * (final_attn_token_to_image / norm_final_attn passed in the cq / co / n2 slots).  embedding_dim 256, attention_downsample_rate 2.
+ * Weights are the reference's [out, in] matrices; kimg / vimg are the k / v projections of the patch tokens ([Z, G, 128] views, computed by the
+ * image-side GEMMs); queries [Z*T, 256] is updated in place, ktok / vtok [Z*T, 128] receive the projections for the image -> token attention.
+ * ws: psam_twoway_tokens_ws_floats(mlp) floats of scratch (mode 1: mlp = 0). */
+typedef struct {
+    int32_t Z, T, G, heads, mlp, mode, skip_pe, reserved;
+    float eps;
+    float* queries; const float* pe;
+    const float* kimg; int64_t ldk, sk; const float* vimg; int64_t ldv, sv;
+    const float *sq_w, *sq_b, *sk_w, *sk_b, *sv_w, *sv_b, *so_w, *so_b, *n1_g, *n1_b;
+    const float *cq_w, *cq_b, *co_w, *co_b, *n2_g, *n2_b;
+    const float *m1_w, *m1_b, *m2_w, *m2_b, *n3_g, *n3_b;
+    const float *ik_w, *ik_b, *iv_w, *iv_b;
+    float *ktok, *vtok;
+    float* ws; int64_t ws_floats;
+} psam_twoway_tokens_t;
+int64_t psam_twoway_tokens_ws_floats(int32_t mlp);
+int32_t psam_twoway_tokens(const psam_twoway_tokens_t* args, psam_stream_t stream);
+
 /* Three-layer ReLU MLP on a few rows -- mask_decoder.py:189-211 (MLP), the hyper-networks :171-176 and the IoU head :180 in one launch
  * each.  Weights stacked in the reference's [out, in] layout: w1 [M, dh, din], w2 [M, dh, dh], w3 [M, dout, dh]; biases [M, dh], [M, dh],
  * [M, dout].  MLP m reads the row x + z*ldx + m*sx (z < Z) and writes dout values at out + z*ldo + m*so.  din, dh <= 1024, % 4 == 0. */

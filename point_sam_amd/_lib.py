@@ -44,6 +44,8 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
     "psam_gemm_f16x3p_splitk": (i32, [i32, i32, i32, i32]),
+    "psam_twoway_tokens_ws_floats": (i64, [i32]),
+    "psam_twoway_tokens": (i32, [ptr, ptr]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
     "psam_ln_stats_finalize": (i32, [ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_scale_pack_rows_g8": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, ptr]),
@@ -76,6 +78,14 @@ class GemmFuse(ctypes.Structure):
                 ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
                 ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64),
                 ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32), ("out_bound", ptr)]
+
+
+class TwoWayTokens(ctypes.Structure):
+    """psam_twoway_tokens_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, i32) for n in ("Z", "T", "G", "heads", "mlp", "mode", "skip_pe", "reserved")] + [("eps", f32), ("queries", ptr), ("pe", ptr),
+                ("kimg", ptr), ("ldk", i64), ("sk", i64), ("vimg", ptr), ("ldv", i64), ("sv", i64)] +
+                [(n, ptr) for n in ("sq_w", "sq_b", "sk_w", "sk_b", "sv_w", "sv_b", "so_w", "so_b", "n1_g", "n1_b", "cq_w", "cq_b", "co_w", "co_b", "n2_g", "n2_b",
+                                    "m1_w", "m1_b", "m2_w", "m2_b", "n3_g", "n3_b", "ik_w", "ik_b", "iv_w", "iv_b", "ktok", "vtok", "ws")] + [("ws_floats", i64)])
 
 
 _lib = None

@@ -24,6 +24,7 @@ SOURCES = [
     ("gemm_f16x3pp.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
+    ("twoway.hip", []),
     ("error.cpp", ["-x", "hip"]),
 ]
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ bool gemm_epilogue_interior(const ArgsT& p, int row_b
 }
 // option bits of a specialised pass loop (gemm_store_tile)
 enum : int { EP_SWIGLU = 1, EP_STATS = 2, EP_PACK = 4, EP_LNC = 8, EP_RES = 16, EP_ROWBIAS = 32, EP_GELU = 64, EP_RELU = 128, EP_GMAX = 256, EP_HYPER = 512,
-              EP_NOSTORE = 1024 };
+              EP_NOSTORE = 1024, EP_BND = 2048 };
 
 template <int TM>
 struct EpPre {
@@ -277,8 +277,8 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                     o_hyper = HYPER && (F < 0 ? (p.hyper != nullptr) : bool(F & EP_HYPER));
                     o_nostore = F < 0 ? (p.no_store != 0) : bool(F & EP_NOSTORE);
                 }
-                bool o_bnd = false;      // packed output scaled by a per-row bound the caller supplies (run-time test: uniform, once per pass)
-                if constexpr (EXT) o_bnd = o_pack && !o_lnc && p.out_bound != nullptr;
+                bool o_bnd = false;      // packed output scaled by a per-row bound the caller supplies (psam_gemm_fuse_t.out_bound)
+                if constexpr (EXT) o_bnd = F < 0 ? (o_pack && !o_lnc && p.out_bound != nullptr) : bool(F & EP_BND);
                 // what happens to a finished value (after the residual): group maximum, write-back for the hyper row pass, packed or plain store
                 auto finish = [&](ep_f32x4 v, int rl, int row, float rsq, float obnd) {
                     if (!o_swiglu) {
@@ -424,13 +424,15 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
                 opt = (swiglu ? EP_SWIGLU : 0) | (R ? EP_RES : 0) | (p.rowbias ? EP_ROWBIAS : 0) | (!swiglu && p.act == 1 ? EP_GELU : 0) | (!swiglu && p.act == 2 ? EP_RELU : 0);
                 if constexpr (EXT) {
                     opt |= (p.stats ? EP_STATS : 0) | (p.pack_out ? EP_PACK : 0) | (p.ln_c ? EP_LNC : 0) | (p.gmax_out ? EP_GMAX : 0) | ((HYPER && p.hyper) ? EP_HYPER : 0) |
-                           (p.no_store ? EP_NOSTORE : 0);
+                           (p.no_store ? EP_NOSTORE : 0) | ((p.pack_out && !p.ln_c && p.out_bound) ? EP_BND : 0);
                 }
             }
             using std::integral_constant;
             if (opt == 0) passes(integral_constant<int, 0>{});                                                  // qkv, patch_proj, ...: bias only
             else if (opt == EP_RES) passes(integral_constant<int, EP_RES>{});                                   // attention projection
-            else if (EXT && opt == (EP_SWIGLU | EP_STATS | EP_PACK)) passes(integral_constant<int, EP_SWIGLU | EP_STATS | EP_PACK>{});   // fc1 of the fused EVA02 MLP
+            else if (EXT && opt == (EP_SWIGLU | EP_STATS | EP_PACK | EP_BND)) passes(integral_constant<int, EP_SWIGLU | EP_STATS | EP_PACK | EP_BND>{});   // fc1 of the fused EVA02 MLP
+            else if (EXT && opt == (EP_SWIGLU | EP_STATS | EP_PACK)) passes(integral_constant<int, EP_SWIGLU | EP_STATS | EP_PACK>{});   // ... with the (k1 / scale + k2)^2 bound
+            else if (EXT && opt == EP_PACK) passes(integral_constant<int, EP_PACK>{});                          // qkv written packed for the attention kernel
             else if (EXT && opt == (EP_LNC | EP_RES)) passes(integral_constant<int, EP_LNC | EP_RES>{});         // fc2 with the folded LayerNorm
             else if (EXT && opt == (EP_PACK | EP_GMAX)) passes(integral_constant<int, EP_PACK | EP_GMAX>{});     // PatchEncoder conv1.3
             else if (opt == EP_ROWBIAS) passes(integral_constant<int, EP_ROWBIAS>{});                           // PatchEncoder conv2.0 (x half)

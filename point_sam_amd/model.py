@@ -69,6 +69,9 @@ class PointCloudSAM:
         if precision not in ops.GEMM_MODES:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
         self.precision = precision
+        self.fuse_tokens = False  # the decoder's token side as one launch per two-way layer (csrc/twoway.hip) instead of ~22: parity-green but
+                                  # slower (0.56 vs 0.48 ms at cfg #2, profiles/r03_twoway.txt), so off; tests A/B both
+        self._tw = None
         self.row_bounds = True    # "f16x3": the fused MLP's packed rows are scaled by a per-row bound from ||h||_2 (False: the (k1 / scale + k2)^2 form)
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
         self.fuse_attn_pack = True  # "f16x3": the attention kernel writes its output packed for the output projection (bound-derived scale)
@@ -185,6 +188,7 @@ class PointCloudSAM:
                     g2, b2n = w[blk.p + ".norm2.weight"].double(), w[blk.p + ".norm2.bias"].double()
                     blk.fc1_bound = 1.001 * (float(blk.w1.double().norm(dim=1).max()) * float(g2.abs().max() * math.sqrt(D) + b2n.norm())
                                              + float(blk.b1.abs().max())) + 1e-30
+                    blk.u_bound = (0.0, 1.002 * float(blk.w1.double().norm(dim=1).max()), 1.002 * float(blk.b1.abs().max()) + 1e-30)      # per row, from ||h||_2
                 wq_all = blk.wqkv.double()
                 blk.qkv_bound = 1.001 * (float(wq_all.norm(dim=1).max()) * hnorm + float(blk.bqkv.abs().max())) + 1e-30
                 blk.v_bound = 1.001 * (float(wq_all[2 * D:].norm(dim=1).max()) * hnorm + float(blk.bqkv[2 * D:].abs().max())) + 1e-30
@@ -293,7 +297,9 @@ class PointCloudSAM:
             self._lin(p + ".attn.proj", o, residual=x, out=x)
         fused_swiglu = (vit.swiglu and pk and self.fuse_mlp and hasattr(blk, "w2g") and ops.fuse_supported(x.shape[0], 2 * blk.hp)
                         and ops.fuse_supported(x.shape[0], D))
-        ub = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if fused_swiglu and self.row_bounds else None
+        fused_gelu = (not vit.swiglu and pk and self.fuse_mlp and isinstance(blk.w2, ops.F16Weight) and ops.fuse_supported(x.shape[0], vit.mlp_hidden)
+                      and vit.mlp_hidden % 32 == 0 and ops.splitk_factor(x.shape[0], vit.mlp_hidden, blk.w1.Kp, ACT_GELU) == 1)
+        ub = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if (fused_swiglu or fused_gelu) and self.row_bounds else None
         self._ln(p + ".norm2", x, vit.ln_eps, out=h, scale_out=rs, pack=pk, bound_out=None if ub is None else (ub,) + blk.u_bound)
         if vit.swiglu:
             # fc1 with the SiLU gate fused in the GEMM epilogue -> u [M, Hp] (pad columns exactly 0), inner LayerNorm over
@@ -318,12 +324,11 @@ class PointCloudSAM:
             ops.linear(u, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=rs if pk2 else None, x_packed=pk2)
         else:
             M, Hh = x.shape[0], vit.mlp_hidden
-            if (pk and self.fuse_mlp and isinstance(blk.w2, ops.F16Weight) and ops.fuse_supported(M, Hh) and Hh % 32 == 0
-                    and ops.splitk_factor(M, Hh, blk.w1.Kp, ACT_GELU) == 1):
+            if fused_gelu:
                 # fc1 leaves GELU(.) g8-packed for fc2 (one scale from the a-priori bound): no scale + pack pass over the [M, hidden] rows
                 g = torch.empty(M, Hh, dtype=torch.float32, device=x.device)
                 sg = torch.empty(M, dtype=torch.float32, device=x.device)
-                ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=True, out=g, pack_out=(sg, 0.0, blk.fc1_bound))
+                ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=True, out=g, pack_out=(sg, 0.0, blk.fc1_bound) if ub is None else (sg, ub))
                 ops.linear(g, blk.w2, self.w[p + ".mlp.fc2.bias"], residual=x, out=x, x_scale=sg, x_packed=True)
             else:
                 g = ops.linear(h, blk.w1, blk.b1, act=ACT_GELU, x_scale=rs, x_packed=pk)
@@ -387,10 +392,40 @@ class PointCloudSAM:
         o = torch.empty(Z * Lq, inner, device=q.device)
         return ops.attention_small(q, k, v, o, Z, H, Lq, Lk, hd, 1.0 / math.sqrt(hd))
 
+    def _two_way_fused(self, src, pos, tokens, Z, G, T, rep):
+        """_two_way with the token side of every layer in one launch (csrc/twoway.hip): per layer the image-side k / v projections, the token
+        kernel, then the image -> token attention and its projection + norm4 on the patch tokens."""
+        cfg, E, eps, H = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps, self.cfg.dec_heads
+        P = "mask_decoder.transformer"
+        if self._tw is None:
+            self._tw = [ops.TwoWayLayerWeights(self.w, f"{P}.layers.{i}") for i in range(cfg.dec_depth)] + [ops.TwoWayLayerWeights(self.w, P, final=True)]
+        R, IX = Z * T, self._tw[0].inner
+        queries, keys = tokens.clone(), src
+        k = torch.empty_like(keys)
+        ws = ops.twoway_tokens_ws(max(lw.args.mlp for lw in self._tw), self.device)
+        ktok, vtok = torch.empty(R, IX, device=self.device), torch.empty(R, IX, device=self.device)
+        for i in range(cfg.dec_depth):
+            L = f"{P}.layers.{i}"
+            ops.add_bcast(pos, rep, keys, k, Z, G, E)
+            kimg = self._lin(L + ".cross_attn_token_to_image.k_proj", k)
+            vimg = self._lin(L + ".cross_attn_token_to_image.v_proj", keys)
+            ops.twoway_tokens(self._tw[i], queries, tokens, kimg, vimg, Z, T, G, H, eps, ws, ktok, vtok, skip_pe=(i == 0))
+            qimg = self._lin(L + ".cross_attn_image_to_token.q_proj", k)
+            a = torch.empty(Z * G, IX, device=self.device)
+            ops.attention_small(qimg, ktok, vtok, a, Z, H, G, T, IX // H, 1.0 / math.sqrt(IX // H))
+            keys = self._ln(L + ".norm4", self._lin(L + ".cross_attn_image_to_token.out_proj", a), eps, residual=keys)
+        ops.add_bcast(pos, rep, keys, k, Z, G, E)
+        kimg = self._lin(P + ".final_attn_token_to_image.k_proj", k)
+        vimg = self._lin(P + ".final_attn_token_to_image.v_proj", keys)
+        ops.twoway_tokens(self._tw[-1], queries, tokens, kimg, vimg, Z, T, G, H, eps, ws)
+        return queries, keys
+
     def _two_way(self, src, pos, tokens, Z, G, T, rep):
         """TwoWayTransformer.forward (transformer.py:61-100).  src [Z*G,E] (overwritten), pos [B,G,E], tokens [Z*T,E]."""
         cfg, E, eps = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps
         P = "mask_decoder.transformer"
+        if self.fuse_tokens and ops.TwoWayLayerWeights.supported(E, self.w[P + ".layers.0.cross_attn_token_to_image.q_proj.weight"].shape[0], cfg.dec_heads, Z, T, G):
+            return self._two_way_fused(src, pos, tokens, Z, G, T, rep)
         queries, keys = tokens, src
         q = torch.empty_like(tokens)
         k = torch.empty_like(keys)

@@ -483,6 +483,67 @@ def attention_packed(qkv_packed, scale_rows, out, out_scale, B, H, L, hd, scale,
     return out
 
 
+class TwoWayLayerWeights:
+    """The weight pointers of one TwoWayAttentionBlock's token side (or of the final token -> image attention: final=True) as a
+    psam_twoway_tokens_t skeleton (csrc/twoway.hip); keeps the tensors alive.  w: name -> fp32 tensor; prefix: e.g.
+    'mask_decoder.transformer.layers.0' or, with final=True, 'mask_decoder.transformer' (final_attn_token_to_image / norm_final_attn)."""
+
+    def __init__(self, w, prefix: str, final: bool = False):
+        self.final = final
+        self.keep = []
+        a = self.args = _lib.TwoWayTokens()
+        def put(slot, name):
+            t = w[name]
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16:
+                raise ValueError(f"{name}: the two-way token kernel needs contiguous, 16-byte aligned fp32 weights")
+            self.keep.append(t)
+            setattr(a, slot, t.data_ptr())
+            return t
+        if final:
+            att, norm = prefix + ".final_attn_token_to_image", prefix + ".norm_final_attn"
+        else:
+            att, norm = prefix + ".cross_attn_token_to_image", prefix + ".norm2"
+            for s, n in (("sq", "q_proj"), ("sk", "k_proj"), ("sv", "v_proj"), ("so", "out_proj")):
+                put(s + "_w", f"{prefix}.self_attn.{n}.weight"); put(s + "_b", f"{prefix}.self_attn.{n}.bias")
+            put("n1_g", prefix + ".norm1.weight"); put("n1_b", prefix + ".norm1.bias")
+            m1 = put("m1_w", prefix + ".mlp.lin1.weight"); put("m1_b", prefix + ".mlp.lin1.bias")
+            put("m2_w", prefix + ".mlp.lin2.weight"); put("m2_b", prefix + ".mlp.lin2.bias")
+            put("n3_g", prefix + ".norm3.weight"); put("n3_b", prefix + ".norm3.bias")
+            put("ik_w", prefix + ".cross_attn_image_to_token.k_proj.weight"); put("ik_b", prefix + ".cross_attn_image_to_token.k_proj.bias")
+            put("iv_w", prefix + ".cross_attn_image_to_token.v_proj.weight"); put("iv_b", prefix + ".cross_attn_image_to_token.v_proj.bias")
+            a.mlp = int(m1.shape[0])
+        cq = put("cq_w", att + ".q_proj.weight"); put("cq_b", att + ".q_proj.bias")
+        put("co_w", att + ".out_proj.weight"); put("co_b", att + ".out_proj.bias")
+        put("n2_g", norm + ".weight"); put("n2_b", norm + ".bias")
+        self.embed, self.inner = int(cq.shape[1]), int(cq.shape[0])
+        a.mode = 1 if final else 0
+
+    @staticmethod
+    def supported(E: int, inner_cross: int, heads: int, Z: int, T: int, G: int) -> bool:
+        return E == 256 and inner_cross == 128 and heads in (1, 2, 4, 8, 16, 32) and Z * T <= 64 and max(T, G) <= 4096
+
+
+def twoway_tokens_ws(mlp: int, device) -> torch.Tensor:
+    return torch.empty(int(_lib.load().psam_twoway_tokens_ws_floats(int(mlp))), dtype=torch.float32, device=device)
+
+
+def twoway_tokens(lw: TwoWayLayerWeights, queries, pe, kimg, vimg, Z, T, G, heads, eps, ws, ktok=None, vtok=None, skip_pe=False):
+    """One launch for the token side of a two-way layer (csrc/twoway.hip; transformer.py:144-175): queries [Z*T, 256] updated in place; pe the
+    token embeddings (query_pe); kimg / vimg [Z*G, 128] row views of the patch tokens' k / v projections; ktok / vtok [Z*T, 128] receive the
+    k / v projections for the image -> token attention (not for the final attention)."""
+    import ctypes
+    a = lw.args
+    _chk(queries, name="queries"); _chk(pe, name="pe")
+    kp, ldk = _row_view(kimg, "kimg"); vp, ldv = _row_view(vimg, "vimg")
+    a.Z, a.T, a.G, a.heads, a.skip_pe, a.eps = int(Z), int(T), int(G), int(heads), int(bool(skip_pe)), float(eps)
+    a.queries, a.pe = queries.data_ptr(), pe.data_ptr()
+    a.kimg, a.ldk, a.sk, a.vimg, a.ldv, a.sv = kp, ldk, G * ldk, vp, ldv, G * ldv
+    a.ktok, a.vtok = (0, 0) if lw.final else (ktok.data_ptr(), vtok.data_ptr())
+    a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    check(_lib.load().psam_twoway_tokens(ctypes.byref(a), _stream()), "psam_twoway_tokens")
+    return queries
+
+
 class Mlp3Weights:
     """Three Linear layers (ReLU between) of M stacked MLPs for psam_mlp3: w? [M, out, in] (the reference's layout), b? [M, out]."""
 

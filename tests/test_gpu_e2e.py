@@ -119,12 +119,13 @@ def _heavy_tailed(sd, seed, fc1_shift=0.0, gain=15.0):
     return out
 
 
-@pytest.mark.parametrize("name,B,fc1_shift,gain", [("base", 2, 0.0, 15.0), ("large_slim", 2, 20.0, 15.0), ("large", 2, 0.0, 50.0)])
+@pytest.mark.parametrize("name,B,fc1_shift,gain", [("base", 2, 0.0, 15.0), ("large_slim", 2, 20.0, 15.0), ("large", 2, 0.0, 50.0), ("giant_slim", 4, 0.0, 30.0)])
 def test_heavy_tailed_weights_against_oracle(gpu, name, B, fc1_shift, gain):
     """Robustness of the bound-derived fp16 scales (packed q|k|v with ONE a-priori scale, packed attention output, SwiGLU rows, folded
     LayerNorm) under trained-checkpoint-like weight statistics: nothing overflows fp16 (finite outputs), and the f16x3 path stays as close
     to the oracle as the exact-fp32-product path does (logits here are 10-100x those of Gaussian weights, so the bar is relative)."""
-    cfg = get_config(name, 128, 32) if name != "large_slim" else ModelConfig(replace(get_config("large", 128, 32).vit, depth=4), 128, 32)
+    cfg = {"large_slim": lambda: ModelConfig(replace(get_config("large", 128, 32).vit, depth=4), 128, 32), "giant_slim": _giant_slim}.get(
+        name, lambda: get_config(name, 128, 32))()
     sd = _heavy_tailed(random_state_dict(cfg, seed=11), seed=12, fc1_shift=fc1_shift, gain=gain)
     xyz, rgb, prompt, labels = O.synthetic_batch(B, 4096, seed=13, num_prompts=1)
     want_masks, want_iou, mid = O.predict_masks(sd, cfg, xyz, rgb, prompt, labels, None, True, mode="exact", return_intermediates=True)
@@ -141,6 +142,33 @@ def test_heavy_tailed_weights_against_oracle(gpu, name, B, fc1_shift, gain):
           f"f32 {errs['f32'][0]:.2e} {errs['f32'][1]:.2e} {errs['f32'][2]:.2e} | f16x3 {errs['f16x3'][0]:.2e} {errs['f16x3'][1]:.2e} {errs['f16x3'][2]:.2e}")
     assert errs["f16x3"][1] < TOL * scale and errs["f16x3"][2] < TOL * max(1.0, want_iou.abs().max().item())
     assert errs["f16x3"][1] < 4 * errs["f32"][1] + 1e-5 * scale, errs
+
+
+@pytest.mark.parametrize("precision,B,clicks,rep", [("f32", 2, 1, 1), ("f16x3", 2, 3, 2), ("f16x3", 1, 9, 1)])
+def test_fused_token_decoder_matches_unfused(gpu, precision, B, clicks, rep):
+    """One launch per two-way layer for the token side (csrc/twoway.hip: team of workgroups, counter barriers between the stages) against the
+    ~22 separate launches it replaces: same arithmetic, so the logits agree to fp32 round-off; repeated runs are bitwise equal (no stage reads
+    a row before the barrier that publishes it); with and without a dense prompt mask."""
+    cfg = get_config("base", 128, 32)
+    sd = random_state_dict(cfg, seed=5)
+    xyz, rgb, prompt, labels = O.synthetic_batch(B, 4096, seed=21, num_prompts=clicks)
+    prompt, labels = prompt.repeat_interleave(rep, 0).cuda(), labels.repeat_interleave(rep, 0).cuda()
+    model = gpu(cfg, sd, precision=precision)
+    st = model.encode(xyz.cuda(), rgb.cuda())
+    outs = {}
+    for fuse in (True, False):
+        model.fuse_tokens = fuse
+        m1, i1 = model.decode(st, prompt, labels, None, True)
+        best = torch.gather(m1, 1, i1.argmax(1).view(-1, 1, 1).expand(-1, 1, m1.shape[2]))[:, 0]
+        m2, i2 = model.decode(st, prompt, labels, best, False)
+        outs[fuse] = (m1, i1, m2, i2)
+        if fuse:
+            for _ in range(3):
+                again = model.decode(st, prompt, labels, None, True)
+                assert torch.equal(again[0], m1) and torch.equal(again[1], i1)
+    errs = [_maxerr(a, b) for a, b in zip(outs[True], outs[False])]
+    print(f"\n[token kernel vs separate launches, {precision}, Z={B * rep}, T={5 + clicks}] max|diff| {errs}")
+    assert max(errs) < 2e-5, errs
 
 
 def test_attention_packed_output_is_transparent(gpu):
