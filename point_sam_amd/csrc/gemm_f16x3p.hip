@@ -473,6 +473,7 @@ PSAM_API int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("PSAM_GEMM_SPLITK"); forced = e ? atoi(e) : 1; }
     if (act == 3 || K < 1024 || (K & 31) || forced == 0) return 1;
+    if (forced == 1 && M > 2048) return 1;      // a batch of clouds: its other GEMM stream fills the idle CUs, the extra reduction pass only costs (r03 profile)
     const int nslabs = K / 32;
     if (forced > 1) return forced <= nslabs / 4 ? forced : (nslabs / 4 > 1 ? nslabs / 4 : 1);
     int cfg = g_f16x3p_cfg;
