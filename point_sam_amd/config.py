@@ -45,6 +45,17 @@ class ModelConfig:
     centralize_features: bool = False   # KNNGrouper.centralize_features (common.py:116-118): + (neighbour - centre) features, in_channels 3 + 2*3
     mask_centralize_features: bool = False   # MaskEncoder.centralize_features (common.py:183-186): needs center_idx, i.e. only the
                                              # forward() protocol passes it (pc_sam.py:151-157); in_channels 3 + 2*1
+    # model variants (configs/model/voronoi.yaml, hier.yaml): "knn" = PointCloudSAM; "voronoi" = PointCloudSAMNN (every point belongs to its
+    # nearest FPS centre: NNGrouper / PatchEmbedNN / MaskEncoderNN, pc_encoder.py:165-198, prompt_encoder.py:255-300, pc_sam.py:199-374);
+    # "hier" = PointCloudSAMHier (two kNN levels: PatchEmbedHier / MaskEncoderHier / MaskDecoderHier, pc_encoder.py:201-239,
+    # prompt_encoder.py:136-183, mask_decoder.py:214-370, pc_sam.py:377-496)
+    variant: str = "knn"
+    nn_hidden: int = 256             # PatchEmbedNN.hidden_dim   (voronoi.yaml:7)
+    nn_mask_hidden: int = 1024       # MaskEncoderNN first_nn / ResMlp width: fixed in the reference (prompt_encoder.py:259-260)
+    hier_groups: tuple = (2048, 512)     # PatchEmbedHier.num_patches (hier.yaml:8)
+    hier_sizes: tuple = (32, 32)         # PatchEmbedHier.patch_size  (hier.yaml:9)
+    hier_radius: tuple = (0.05, 0.1)     # hier.yaml:10 (also MaskEncoderHier.radius, :18); None = no normalisation
+    hier_dim1: int = 128                 # level-1 embedding width (pc_encoder.py:222, mask_decoder.py:226 encoder_dim)
 
     @property
     def mask_encoder_radius(self):
@@ -61,6 +72,11 @@ class ModelConfig:
     @property
     def num_mask_tokens(self) -> int:
         return self.num_multimask + 1
+
+    @property
+    def num_tokens(self) -> int:
+        """Patch tokens the transformer sees."""
+        return self.hier_groups[1] if self.variant == "hier" else self.num_groups
 
     def with_groups(self, num_groups: int, group_size: int) -> "ModelConfig":
         return replace(self, num_groups=num_groups, group_size=group_size)
@@ -87,6 +103,11 @@ CONFIGS = {
     "tiny_radius": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3, radius=0.1),
     # centralised group features (KNNGrouper.centralize_features) + different grouper / mask-encoder radii on the tiny test transformer
     "tiny_central": ModelConfig(VIT_TINY_SWIGLU, 32, 16, prompt_iters=3, radius=0.2, mask_radius=0.1, centralize_features=True),
+    # configs/model/voronoi.yaml (PointCloudSAMNN, 7 input channels: unit offset 3 + distance 1 + rgb 3) and hier.yaml (PointCloudSAMHier)
+    "voronoi": ModelConfig(VIT_LARGE, 1024, 1, in_channels=7, prompt_iters=5, variant="voronoi"),
+    "hier": ModelConfig(VIT_LARGE, 512, 32, prompt_iters=8, variant="hier"),
+    "tiny_voronoi": ModelConfig(VIT_TINY_SWIGLU, 32, 1, in_channels=7, prompt_iters=3, variant="voronoi", nn_hidden=64),
+    "tiny_hier": ModelConfig(VIT_TINY_SWIGLU, 16, 8, prompt_iters=3, variant="hier", hier_groups=(64, 16), hier_sizes=(8, 8), hier_radius=(0.2, 0.4)),
 }
 
 

@@ -44,16 +44,33 @@ def expected_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
         s[name + ".weight"] = (n,)
         s[name + ".bias"] = (n,)
 
-    def patch_encoder(prefix, cin, cout):  # common.py:477-497
-        linear(prefix + ".conv1.0", cin, h0)
-        norm(prefix + ".conv1.1", h0)
-        linear(prefix + ".conv1.3", h0, h0)
-        linear(prefix + ".conv2.0", 2 * h0, h1)
-        norm(prefix + ".conv2.1", h1)
-        linear(prefix + ".conv2.3", h1, cout)
+    def patch_encoder(prefix, cin, cout, hidden=None):  # common.py:477-497
+        a, b = hidden or (h0, h1)
+        linear(prefix + ".conv1.0", cin, a)
+        norm(prefix + ".conv1.1", a)
+        linear(prefix + ".conv1.3", a, a)
+        linear(prefix + ".conv2.0", 2 * a, b)
+        norm(prefix + ".conv2.1", b)
+        linear(prefix + ".conv2.3", b, cout)
 
     # --- pc_encoder (pc_encoder.py:84-116)
-    patch_encoder("pc_encoder.patch_embed.patch_encoder", cfg.patch_in_channels, cfg.patch_out)
+    if cfg.variant == "voronoi":      # PatchEmbedNN (pc_encoder.py:165-198): in_proj, 3 + 3 pre-LN residual MLP blocks (:147-162), norm, out_proj
+        Hn = cfg.nn_hidden
+        linear("pc_encoder.patch_embed.in_proj", cfg.in_channels, Hn)
+        for grp in ("blocks1", "blocks2"):
+            for i in range(3):
+                q = f"pc_encoder.patch_embed.{grp}.{i}"
+                linear(q + ".mlp.0", Hn, Hn)
+                norm(q + ".mlp.2", Hn)
+                linear(q + ".mlp.3", Hn, Hn)
+                norm(q + ".norm", Hn)
+        norm("pc_encoder.patch_embed.norm", Hn)
+        linear("pc_encoder.patch_embed.out_proj", Hn, cfg.patch_out)
+    elif cfg.variant == "hier":       # PatchEmbedHier (pc_encoder.py:201-239)
+        patch_encoder("pc_encoder.patch_embed.patch_encoder1", cfg.in_channels, cfg.hier_dim1, (64, 128))
+        patch_encoder("pc_encoder.patch_embed.patch_encoder2", cfg.hier_dim1 + 3, cfg.patch_out, (128, 256))
+    else:
+        patch_encoder("pc_encoder.patch_embed.patch_encoder", cfg.patch_in_channels, cfg.patch_out)
     linear("pc_encoder.patch_proj", cfg.patch_out, D)
     linear("pc_encoder.pos_embed.0", 3, 128)
     linear("pc_encoder.pos_embed.2", 128, D)
@@ -85,7 +102,20 @@ def expected_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     s["point_encoder.pe_layer.positional_encoding_gaussian_matrix"] = (3, E // 2)
     s["point_encoder.point_embeddings.0.weight"] = (1, E)
     s["point_encoder.point_embeddings.1.weight"] = (1, E)
-    patch_encoder("mask_encoder.patch_encoder", cfg.mask_in_channels, E)
+    if cfg.variant == "voronoi":      # MaskEncoderNN (prompt_encoder.py:255-300) with ResMlp (:186-211)
+        Hm = cfg.nn_mask_hidden
+        linear("mask_encoder.first_nn", 5, Hm)
+        linear("mask_encoder.second_nn.mlp.0", Hm, Hm)
+        norm("mask_encoder.second_nn.mlp.1", Hm)
+        for i in (3, 4, 5):
+            linear(f"mask_encoder.second_nn.mlp.{i}.mlp.0", Hm, Hm)
+            norm(f"mask_encoder.second_nn.mlp.{i}.mlp.1", Hm)
+        linear("mask_encoder.second_nn.mlp.6", Hm, E)
+    elif cfg.variant == "hier":       # MaskEncoderHier (prompt_encoder.py:136-183)
+        patch_encoder("mask_encoder.patch_encoder1", 4, cfg.hier_dim1, (64, 128))
+        patch_encoder("mask_encoder.patch_encoder2", cfg.hier_dim1 + 3, E, (128, 256))
+    else:
+        patch_encoder("mask_encoder.patch_encoder", cfg.mask_in_channels, E)
     s["mask_encoder.no_mask_embed.weight"] = (1, E)
     # --- mask decoder (mask_decoder.py:21-63, transformer.py:15-59,103-142,179-202,240-249)
     s["mask_decoder.iou_token.weight"] = (1, E)
@@ -111,12 +141,21 @@ def expected_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
         attention(p + ".cross_attn_image_to_token", cfg.dec_downsample)
     attention("mask_decoder.transformer.final_attn_token_to_image", cfg.dec_downsample)
     norm("mask_decoder.transformer.norm_final_attn", E)
+    hier = cfg.variant == "hier"
     for i in range(cfg.num_mask_tokens):
-        for j in range(3):
-            linear(f"mask_decoder.output_hypernetworks_mlps.{i}.layers.{j}", E, E)
-    linear("mask_decoder.output_upscaling.0", E, E)
-    norm("mask_decoder.output_upscaling.1", E)
-    linear("mask_decoder.output_upscaling.3", E, E)
+        for j in range(3):      # MaskDecoderHier: MLP(E, E, E // 2, 3) (mask_decoder.py:240-245)
+            linear(f"mask_decoder.output_hypernetworks_mlps.{i}.layers.{j}", E, E // 2 if (hier and j == 2) else E)
+    if hier:                      # mask_decoder.py:246-258
+        linear("mask_decoder.output_upscaling2.0", E + cfg.hier_dim1, E)
+        norm("mask_decoder.output_upscaling2.1", E)
+        linear("mask_decoder.output_upscaling2.3", E, E)
+        linear("mask_decoder.output_upscaling1.0", E, E // 2)
+        norm("mask_decoder.output_upscaling1.1", E // 2)
+        linear("mask_decoder.output_upscaling1.3", E // 2, E // 2)
+    else:
+        linear("mask_decoder.output_upscaling.0", E, E)
+        norm("mask_decoder.output_upscaling.1", E)
+        linear("mask_decoder.output_upscaling.3", E, E)
     linear("mask_decoder.iou_prediction_head.layers.0", E, E)
     linear("mask_decoder.iou_prediction_head.layers.1", E, E)
     linear("mask_decoder.iou_prediction_head.layers.2", E, cfg.num_mask_tokens)
@@ -140,8 +179,16 @@ def _is_norm_key(name: str) -> bool:
         leaf_parent.startswith("norm")
         or leaf_parent == "fc_norm"
         or name.endswith(("conv1.1.weight", "conv1.1.bias", "conv2.1.weight", "conv2.1.bias"))
-        or ".output_upscaling.1." in name
+        or ".output_upscaling.1." in name or ".output_upscaling1.1." in name or ".output_upscaling2.1." in name
+        or (".patch_embed.blocks" in name and ".mlp.2." in name)                       # Block: Linear, GELU, LayerNorm, Linear (pc_encoder.py:152-157)
+        or (name.startswith("mask_encoder.second_nn.mlp.") and _resmlp_norm(name))
     )
+
+
+def _resmlp_norm(name: str) -> bool:
+    """LayerNorms of MaskEncoderNN.second_nn (ResMlp, prompt_encoder.py:186-211): mlp.1 and mlp.{3,4,5}.mlp.1."""
+    parts = name.split(".")
+    return (len(parts) == 5 and parts[3] == "1") or (len(parts) == 7 and parts[5] == "1")
 
 
 def random_state_dict(cfg: ModelConfig, seed: int = 42) -> "OrderedDict[str, torch.Tensor]":

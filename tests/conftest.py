@@ -50,6 +50,16 @@ def golden_forward():
 
 
 @pytest.fixture(scope="session")
+def golden_voronoi():
+    return load_golden("ref_tiny_voronoi")
+
+
+@pytest.fixture(scope="session")
+def golden_hier():
+    return load_golden("ref_tiny_hier")
+
+
+@pytest.fixture(scope="session")
 def golden_ply():
     return load_golden("ref_demo_ply")
 

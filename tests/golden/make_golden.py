@@ -234,6 +234,91 @@ def make_forward_case(name, cfg_name, B, N, seed, iters):
     print(name, os.path.getsize(path) // 1024, "KiB", [arrays[f"prompt_labels_{i}"][:, -1].tolist() for i in range(iters)])
 
 
+def build_reference_variant(cfg, sd):
+    """PointCloudSAMNN (configs/model/voronoi.yaml) / PointCloudSAMHier (configs/model/hier.yaml) from the reference's own classes."""
+    _install_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pc_sam.model.mask_decoder import MaskDecoder, MaskDecoderHier
+    from pc_sam.model.pc_encoder import PatchEmbedHier, PatchEmbedNN, PointCloudEncoder
+    from pc_sam.model.pc_sam import PointCloudSAMHier, PointCloudSAMNN
+    from pc_sam.model.prompt_encoder import MaskEncoderHier, MaskEncoderNN
+    from pc_sam.model.transformer import TwoWayTransformer
+
+    tw = TwoWayTransformer(cfg.dec_depth, cfg.embed_dim, cfg.dec_heads, cfg.dec_mlp)
+    if cfg.variant == "voronoi":
+        model = PointCloudSAMNN(
+            pc_encoder=PointCloudEncoder(PatchEmbedNN(cfg.in_channels, cfg.nn_hidden, cfg.patch_out, cfg.num_groups), StandInEva(cfg.vit), cfg.embed_dim),
+            mask_encoder=MaskEncoderNN(cfg.embed_dim, cfg.num_groups), mask_decoder=MaskDecoder(cfg.embed_dim, tw), prompt_iters=cfg.prompt_iters)
+    else:
+        rad = list(cfg.hier_radius) if cfg.hier_radius else None
+        model = PointCloudSAMHier(
+            pc_encoder=PointCloudEncoder(PatchEmbedHier(cfg.in_channels, cfg.patch_out, list(cfg.hier_groups), list(cfg.hier_sizes), rad), StandInEva(cfg.vit),
+                                         cfg.embed_dim),
+            mask_encoder=MaskEncoderHier(cfg.embed_dim, radius=rad), mask_decoder=MaskDecoderHier(cfg.embed_dim, tw), prompt_iters=cfg.prompt_iters)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return model.eval()
+
+
+def make_variant_case(name, cfg_name, B, N, M, P, seed, iters=3):
+    """Encoder, both prompt encoders and the mask decoder of a model variant, click 1 (multimask, no mask prompt) and click 2 (previous best
+    mask as the dense prompt), called component by component exactly as the variant's forward does (pc_sam.py:326-352 / :437-471); for the
+    voronoi variant also its whole forward(..., is_eval=True)."""
+    from pc_sam.model.mask_decoder import AuxInputs  # noqa: E402  (after the stubs)
+    cfg = get_config(cfg_name)
+    sd = random_state_dict(cfg, seed=seed)
+    model = build_reference_variant(cfg, sd)
+    xyz, rgb, _, _ = O.synthetic_batch(B, N, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    pidx = torch.randint(0, N, (B * M, P), generator=g)
+    prompt_coords = torch.stack([xyz[i // M][pidx[i]] for i in range(B * M)])
+    prompt_labels = (torch.rand(B * M, P, generator=g) > 0.3).to(torch.int64)
+    prompt_labels[:, 0] = 1
+    out = {}
+    rep = lambda t: t.repeat_interleave(B * M // t.shape[0], 0)
+    with torch.no_grad():
+        emb, patches = model.pc_encoder(xyz, rgb)
+        sparse = model.point_encoder(prompt_coords, prompt_labels)
+        if cfg.variant == "voronoi":
+            centers, nn_idx = patches["centers"], patches["nn_idx"]
+            out.update(centers=centers, nn_idx=nn_idx, group_features=patches["features"], patch_embeddings=patches["embeddings"])
+            pc_pe = model.point_encoder.pe_layer(centers)
+            dec = lambda pm, multi: model.mask_decoder(emb, pc_pe, sparse, rep(model.mask_encoder(pm, nn_idx, centers, xyz)),
+                                                       aux_inputs=AuxInputs(coords=xyz, features=rgb, centers=centers), multimask_output=multi)
+            dense_of = lambda pm: model.mask_encoder(pm, nn_idx, centers, xyz)
+        else:
+            p1, p2 = patches
+            out.update(centers1=p1["centers"], knn_idx1=p1["knn_idx"], centers2=p2["centers"], knn_idx2=p2["knn_idx"], embeddings1=p1["embeddings"],
+                       patch_embeddings=p2["embeddings"])
+            pc_pe = model.point_encoder.pe_layer(p2["centers"])
+            dense_of = lambda pm: (lambda d: d if isinstance(d, torch.Tensor) else d[-1])(
+                model.mask_encoder(pm, xyz, p1["centers"], p1["knn_idx"], p2["centers"], p2["knn_idx"]))
+            dec = lambda pm, multi: model.mask_decoder(
+                emb, pc_pe, sparse, rep(dense_of(pm)), aux_inputs1=AuxInputs(coords=xyz, features=rgb, centers=p1["centers"]),
+                aux_inputs2=AuxInputs(coords=p1["centers"], features=p1["embeddings"], centers=p2["centers"]), multimask_output=multi)
+        out.update(pc_embeddings=emb, pc_pe=pc_pe, sparse=sparse)
+        masks, iou = dec(None, True)
+        best = torch.gather(masks, 1, iou.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0]
+        out.update(masks_click1=masks, iou_click1=iou, prompt_masks_click2=best, dense_click2=dense_of(best))
+        masks2, iou2 = dec(best, False)
+        out.update(masks_click2=masks2, iou_click2=iou2)
+        if cfg.variant == "voronoi":
+            model.prompt_iters = iters
+            gt = torch.stack([xyz[..., 0] > 0.1, (xyz - torch.tensor([0.2, 0.1, -0.1])).norm(dim=-1) < 0.25], 1)
+            outs = model(xyz, rgb, gt, is_eval=True)
+            out["gt_masks"] = gt
+            for i, o in enumerate(outs):
+                out.update({f"fwd_prompt_coords_{i}": o["prompt_coords"], f"fwd_prompt_labels_{i}": o["prompt_labels"], f"fwd_masks_{i}": o["masks"],
+                            f"fwd_iou_preds_{i}": o["iou_preds"], f"fwd_prompt_masks_{i}": o["prompt_masks"]})
+    arrays = {k: v.numpy() for k, v in out.items()}
+    arrays.update(xyz=xyz.numpy(), rgb=rgb.numpy(), prompt_coords=prompt_coords.numpy(), prompt_labels=prompt_labels.numpy())
+    meta = dict(cfg=cfg_name, B=B, N=N, M=M, P=P, seed=seed, iters=iters, weights_checksum=state_dict_checksum(sd), torch=torch.__version__)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{name}.npz")
+    np.savez_compressed(path, meta=np.array(repr(meta)), **arrays)
+    print(name, {k: v.shape for k, v in arrays.items()}, os.path.getsize(path) // 1024, "KiB")
+
+
 PLY_DIR = os.path.join(REF, "demo", "static", "models")
 PLY_FILES = ["rhino.ply", "scene.ply", "sixaxis_10000_points.ply", "sixaxis_50000_points.ply", "tiko_10000_points.ply", "tiko_50000_points.ply"]
 
@@ -290,6 +375,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "central":  # only the centralize_features fixture
         make_case("ref_tiny_central", "tiny_central", B=2, N=800, M=2, P=1, seed=9)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":  # only the voronoi / hier fixtures
+        _install_stubs()
+        sys.path.insert(0, REF)
+        make_variant_case("ref_tiny_voronoi", "tiny_voronoi", B=2, N=600, M=2, P=2, seed=21)
+        make_variant_case("ref_tiny_hier", "tiny_hier", B=2, N=700, M=1, P=2, seed=23)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ply":      # only the demo-PLY fixture
         make_ply_cases("ref_demo_ply", "tiny", G=128, K=32, seed=13)
         sys.exit(0)
@@ -299,3 +390,5 @@ if __name__ == "__main__":
     make_case("ref_tiny_central", "tiny_central", B=2, N=800, M=2, P=1, seed=9)
     make_forward_case("ref_tiny_forward_eval", "tiny", B=2, N=1024, seed=7, iters=4)
     make_ply_cases("ref_demo_ply", "tiny", G=128, K=32, seed=13)
+    make_variant_case("ref_tiny_voronoi", "tiny_voronoi", B=2, N=600, M=2, P=2, seed=21)
+    make_variant_case("ref_tiny_hier", "tiny_hier", B=2, N=700, M=1, P=2, seed=23)
