@@ -79,6 +79,9 @@ int32_t psam_patch_l1(const float* xyz, const float* feats, const float* centers
  * configs/model/enc_with_radius.yaml): relative coordinates divided by radius; radius <= 0 = none. */
 int32_t psam_group_gather_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B, int32_t rep,
                             int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, psam_stream_t stream);
+/* the same with a row stride ldo >= 3 + C; the tail of every row is written as zeros (K of the following Linear % 4 == 0) */
+int32_t psam_group_gather_ld(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B, int32_t rep, int32_t N,
+                             int32_t G, int32_t K, int32_t C, float radius, float* out, int64_t ldo, psam_stream_t stream);
 int32_t psam_patch_l1_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, const float* W, const float* bias,
                         const float* lnw, const float* lnb, float eps, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
                         float radius, float* out, psam_stream_t stream);
@@ -261,6 +264,17 @@ typedef struct {
 } psam_twoway_tokens_t;
 int64_t psam_twoway_tokens_ws_floats(int32_t mlp);
 int32_t psam_twoway_tokens(const psam_twoway_tokens_t* args, psam_stream_t stream);
+
+/* Voronoi variant (PointCloudSAMNN, configs/model/voronoi.yaml).  psam_nn_group_feats: per-point features relative to the nearest centre --
+ * mode 0 = NNGrouper.forward (pc_sam/model/common.py:203-211): [unit offset 3 | distance 1 | feats C]; mode 1 = MaskEncoderNN.forward
+ * (prompt_encoder.py:281-287): [logit | offset 3 | distance] for mask set z = b * rep + r; rows ldo floats apart, zero-padded (ldo % 4 == 0
+ * for the Linear that follows).  psam_scatter_amax: the max-pool of rows into their cells (torch scatter_reduce "amax": pc_encoder.py:190-193
+ * with include_self = 0 -- cells without points end as 0 --, prompt_encoder.py:291-297 with include_self = 1 -- zeros take part);
+ * dest(r) = idx[(r / rows_per_set / idx_rep) * rows_per_set + r % rows_per_set] + (r / rows_per_set) * set_stride; exact in any order. */
+int32_t psam_nn_group_feats(const float* xyz, const float* centers, const int64_t* nn_idx, const float* feats, const float* logits, int32_t B, int32_t rep,
+                            int32_t N, int32_t G, int32_t C, int32_t mode, float* out, int64_t ldo, psam_stream_t stream);
+int32_t psam_scatter_amax(const float* x, int64_t ldx, const int64_t* idx, int64_t rows, int32_t C, int64_t rows_per_set, int64_t set_stride,
+                          int32_t idx_rep, float* out, int64_t out_rows, int32_t include_self, psam_stream_t stream);
 
 /* Three-layer ReLU MLP on a few rows -- mask_decoder.py:189-211 (MLP), the hyper-networks :171-176 and the IoU head :180 in one launch
  * each.  Weights stacked in the reference's [out, in] layout: w1 [M, dh, din], w2 [M, dh, dh], w3 [M, dout, dh]; biases [M, dh], [M, dh],

@@ -24,6 +24,7 @@ SIGNATURES = {
     "psam_three_nn": (i32, [ptr, ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_group_gather": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, ptr]),
     "psam_group_gather_r": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),
+    "psam_group_gather_ld": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, f32, ptr, i64, ptr]),
     "psam_patch_l1": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, ptr, ptr]),
     "psam_patch_l1_r": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),
     "psam_patch_l1_ex": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, f32, i32, i32, i32, i32, i32, i32, f32, ptr, ptr, ptr]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
     "psam_gemm_f16x3p_splitk": (i32, [i32, i32, i32, i32]),
+    "psam_nn_group_feats": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, i64, ptr]),
+    "psam_scatter_amax": (i32, [ptr, i64, ptr, i64, i32, i64, i64, i32, ptr, i64, i32, ptr]),
     "psam_twoway_tokens_ws_floats": (i64, [i32]),
     "psam_twoway_tokens": (i32, [ptr, ptr]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),

@@ -355,6 +355,85 @@ PSAM_API int32_t psam_group_max(const float* x, int64_t ldx, float* y, int64_t l
 }
 
 // ------------------------------------------------------------------------------------------------
+// Voronoi variant (PointCloudSAMNN): per-point features relative to the point's nearest centre, and the max-pool of point rows into their cells.
+//   mode 0, NNGrouper.forward (common.py:203-211):          out[b*N + n] = [ (xyz - c) / max(|xyz - c|, 1e-8) : 3 | |xyz - c| : 1 | feats[b, n, :C] ]
+//   mode 1, MaskEncoderNN.forward (prompt_encoder.py:281-287): out[z*N + n] = [ logit[z, n] | xyz - c : 3 | |xyz - c| : 1 ],  z = b * rep + r
+// rows are ldo floats apart and zero-padded behind the last channel (ldo % 4 == 0: the K of the Linear that follows).
+// ------------------------------------------------------------------------------------------------
+__global__ void nn_group_feats_kernel(const float* __restrict__ xyz, const float* __restrict__ centers, const int64_t* __restrict__ nn_idx,
+                                      const float* __restrict__ feats, const float* __restrict__ logits, int B, int rep, int N, int G, int C, int mode,
+                                      float* __restrict__ out, int ldo) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * rep * N) return;
+    const int n = (int)(t % N);
+    const int z = (int)(t / N), b = z / rep;
+    const float* p = xyz + ((int64_t)b * N + n) * 3;
+    const float* c = centers + ((int64_t)b * G + nn_idx[(int64_t)b * N + n]) * 3;
+    const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+    const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+    float* o = out + t * ldo;
+    int w = 0;
+    if (mode == 0) {
+        const float inv = fmaxf(dist, 1e-8f);
+        o[0] = dx / inv; o[1] = dy / inv; o[2] = dz / inv; o[3] = dist;
+        for (int k = 0; k < C; ++k) o[4 + k] = feats[((int64_t)b * N + n) * C + k];
+        w = 4 + C;
+    } else {
+        o[0] = logits[(int64_t)z * N + n]; o[1] = dx; o[2] = dy; o[3] = dz; o[4] = dist;
+        w = 5;
+    }
+    for (int k = w; k < ldo; ++k) o[k] = 0.f;
+}
+
+PSAM_API int32_t psam_nn_group_feats(const float* xyz, const float* centers, const int64_t* nn_idx, const float* feats, const float* logits, int32_t B,
+                                     int32_t rep, int32_t N, int32_t G, int32_t C, int32_t mode, float* out, int64_t ldo, hipStream_t stream) {
+    PSAM_REQUIRE(xyz && centers && nn_idx && out && B > 0 && rep > 0 && N > 0 && G > 0, PSAM_EINVAL, "psam_nn_group_feats: bad argument");
+    PSAM_REQUIRE((mode == 0 && (C == 0 || feats) && rep == 1 && ldo >= 4 + C) || (mode == 1 && logits && ldo >= 5), PSAM_EINVAL,
+                 "psam_nn_group_feats: mode 0 needs feats (rep 1), mode 1 needs logits; ldo must hold the row");
+    hipLaunchKernelGGL(nn_group_feats_kernel, dim3((unsigned)psam_cdiv((int64_t)B * rep * N, 256)), dim3(256), 0, stream, xyz, centers, nn_idx, feats, logits,
+                       B, rep, N, G, C, mode, out, (int)ldo);
+    return psam_launch_status("psam_nn_group_feats: launch failed");
+}
+
+// out[dest(r), :] = max over the rows r that map to it of x[r, :]; dest(r) = idx[(r / rows_per_set / idx_rep) * rows_per_set + r % rows_per_set]
+// + (r / rows_per_set) * set_stride.  The maximum is exact and order-independent, so integer atomics on the float pattern give the same
+// bits in any arrival order: non-negative values by signed max, negative ones by unsigned min.  include_self != 0: the destination starts at
+// 0 and takes part (torch.scatter_reduce(zeros, ..., "amax"), prompt_encoder.py:291-297); otherwise it starts at -inf and destinations that
+// received nothing end as 0 (scatter_reduce_(..., include_self=False) into zeros, pc_encoder.py:190-193).
+__global__ void scatter_fill_kernel(float* __restrict__ out, int64_t n, float v) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = v;
+}
+__global__ void scatter_amax_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ idx, int64_t rows, int C, int64_t rows_per_set,
+                                    int64_t set_stride, int idx_rep, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * C) return;
+    const int64_t r = t / C;
+    const int c = (int)(t % C);
+    const int64_t set = r / rows_per_set, within = r - set * rows_per_set;
+    const int64_t dest = idx[(set / idx_rep) * rows_per_set + within] + set * set_stride;
+    const float v = x[r * ldx + c];
+    float* o = out + dest * C + c;
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(o), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(o), __float_as_uint(v));
+}
+__global__ void scatter_fix_kernel(float* __restrict__ out, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && out[t] == -INFINITY) out[t] = 0.f;
+}
+
+PSAM_API int32_t psam_scatter_amax(const float* x, int64_t ldx, const int64_t* idx, int64_t rows, int32_t C, int64_t rows_per_set, int64_t set_stride,
+                                   int32_t idx_rep, float* out, int64_t out_rows, int32_t include_self, hipStream_t stream) {
+    PSAM_REQUIRE(x && idx && out && rows > 0 && C > 0 && rows_per_set > 0 && rows % rows_per_set == 0 && idx_rep > 0 && out_rows > 0 && ldx >= C, PSAM_EINVAL,
+                 "psam_scatter_amax: bad argument");
+    const int64_t n = out_rows * C;
+    hipLaunchKernelGGL(scatter_fill_kernel, dim3((unsigned)psam_cdiv(n, 256)), dim3(256), 0, stream, out, n, include_self ? 0.f : -INFINITY);
+    hipLaunchKernelGGL(scatter_amax_kernel, dim3((unsigned)psam_cdiv(rows * C, 256)), dim3(256), 0, stream, x, ldx, idx, rows, C, rows_per_set, set_stride, idx_rep, out);
+    if (!include_self) hipLaunchKernelGGL(scatter_fix_kernel, dim3((unsigned)psam_cdiv(n, 256)), dim3(256), 0, stream, out, n);
+    return psam_launch_status("psam_scatter_amax: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
 // pos_embed first layer: y[r, 0:128] = GELU(W[128,3] @ centers[r] + bias)                (pc_encoder.py:102-104)
 // ------------------------------------------------------------------------------------------------
 __global__ void pos_l1_kernel(const float* __restrict__ c, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ y,

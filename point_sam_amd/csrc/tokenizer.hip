@@ -710,7 +710,7 @@ PSAM_API int32_t psam_three_nn(const float* xyz, const float* centers, int32_t B
 // ------------------------------------------------------------------------------------------------
 __global__ void group_gather_kernel(const float* __restrict__ xyz, const float* __restrict__ feats, const float* __restrict__ centers,
                                     const int64_t* __restrict__ knn_idx, int rep, int N, int G, int K, int C, int64_t total,
-                                    float inv_radius, float* __restrict__ out) {
+                                    float inv_radius, float* __restrict__ out, int64_t ldo) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int64_t row = t;  // (bf, g, k)
@@ -721,22 +721,29 @@ __global__ void group_gather_kernel(const float* __restrict__ xyz, const float* 
     const int64_t n = knn_idx[(b * G + g) * K + k];
     const float* p = xyz + (b * N + n) * 3;
     const float* c = centers + (b * G + g) * 3;
-    float* o = out + row * (3 + C);
+    float* o = out + row * ldo;
     o[0] = (p[0] - c[0]) * inv_radius; o[1] = (p[1] - c[1]) * inv_radius; o[2] = (p[2] - c[2]) * inv_radius;   // inv_radius == 1: exact
     const float* f = feats + (bf * N + n) * C;
     for (int i = 0; i < C; ++i) o[3 + i] = f[i];
+    for (int i = 3 + C; i < ldo; ++i) o[i] = 0.f;      // zero padding up to the row stride (the K of the Linear that follows must be % 4)
 }
 
 // radius > 0: relative coordinates are divided by it (KNNGrouper.radius / MaskEncoder.radius, configs/model/enc_with_radius.yaml;
 // as ATen does for a scalar divisor: multiply by the fp32 reciprocal); radius <= 0: none.
-PSAM_API int32_t psam_group_gather_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
-                                     int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, hipStream_t stream) {
+// ldo: floats between output rows (>= 3 + C; the tail of a row is written as zeros)
+PSAM_API int32_t psam_group_gather_ld(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
+                                      int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, int64_t ldo, hipStream_t stream) {
     PSAM_REQUIRE(xyz && feats && centers && knn_idx && out, PSAM_EINVAL, "psam_group_gather: null pointer");
-    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0 && C > 0, PSAM_EINVAL, "psam_group_gather: bad shape");
+    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && K > 0 && C > 0 && ldo >= 3 + C, PSAM_EINVAL, "psam_group_gather: bad shape");
     const int64_t total = (int64_t)B * rep * G * K;
     hipLaunchKernelGGL(group_gather_kernel, dim3((unsigned)psam_cdiv(total, 256)), dim3(256), 0, stream, xyz, feats, centers, knn_idx,
-                       rep, N, G, K, C, total, radius > 0.f ? 1.0f / radius : 1.0f, out);
+                       rep, N, G, K, C, total, radius > 0.f ? 1.0f / radius : 1.0f, out, ldo);
     return psam_launch_status("psam_group_gather: launch failed");
+}
+
+PSAM_API int32_t psam_group_gather_r(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,
+                                     int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C, float radius, float* out, hipStream_t stream) {
+    return psam_group_gather_ld(xyz, feats, centers, knn_idx, B, rep, N, G, K, C, radius, out, 3 + C, stream);
 }
 
 PSAM_API int32_t psam_group_gather(const float* xyz, const float* feats, const float* centers, const int64_t* knn_idx, int32_t B,

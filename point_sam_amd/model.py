@@ -34,6 +34,7 @@ class TokenizerState:
     knn_idx: torch.Tensor        # [B, G, K] int64
     interp_index: torch.Tensor   # [B, N, 3] int64
     interp_weight: torch.Tensor  # [B, N, 3]
+    extra: Optional[dict] = None  # model variants (point_sam_amd/variants.py): e.g. the hier model's level-1 groups
 
     def tensors(self):
         return (self.fps_idx, self.centers, self.knn_idx, self.interp_index, self.interp_weight)
@@ -53,6 +54,7 @@ class EncoderState:
     patch_embeddings: torch.Tensor   # [B, G, patch_out]
     interp_index: Optional[torch.Tensor] = None   # [B, N, 3] int64 (cached after the first decode)
     interp_weight: Optional[torch.Tensor] = None  # [B, N, 3]
+    extra: Optional[dict] = None                  # model variants (point_sam_amd/variants.py)
 
 
 class PointCloudSAM:
@@ -148,8 +150,11 @@ class PointCloudSAM:
                 if name.endswith(".weight") and t.dim() == 2 and ops.F16Weight.eligible(*t.shape) and not name.startswith("pc_encoder.transformer."):
                     self.fw[name] = ops.F16Weight(t)
             self.pe_bound = {}
-            self.up_ln_bound = ops.row_ln_bound(w["mask_decoder.output_upscaling.1.weight"], w["mask_decoder.output_upscaling.1.bias"])
+            if "mask_decoder.output_upscaling.1.weight" in w:
+                self.up_ln_bound = ops.row_ln_bound(w["mask_decoder.output_upscaling.1.weight"], w["mask_decoder.output_upscaling.1.bias"])
             for prefix in ("pc_encoder.patch_embed.patch_encoder", "mask_encoder.patch_encoder"):   # cat([max, x]) @ W^T as two GEMMs
+                if prefix + ".conv1.3.weight" not in w:      # model variants have other patch embeddings (point_sam_amd/variants.py)
+                    continue
                 w13 = w[prefix + ".conv1.3.weight"]     # bound of |conv1.3 row| from the scale of its (packed) input row: see psam_gemm_fuse_t
                 self.pe_bound[prefix] = (float(2.0 ** 15 * math.sqrt(w13.shape[1]) * w13.double().norm(dim=1).max().item()),
                                          float(w[prefix + ".conv1.3.bias"].abs().max().item()))
@@ -367,8 +372,7 @@ class PointCloudSAM:
         cfg, w = self.cfg, self.w
         fps_idx, centers, knn_idx = tok.fps_idx, tok.centers, tok.knn_idx
         G = centers.shape[1]
-        emb = self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, centers, knn_idx, radius=cfg.radius,
-                                  center_idx=fps_idx if cfg.centralize_features else None)
+        emb = self._patch_tokens(coords, features, tok)
         x = self._lin("pc_encoder.patch_proj", emb)
         p1 = ops.pos_l1(centers, w["pc_encoder.pos_embed.0.weight"], w["pc_encoder.pos_embed.0.bias"])
         self._lin("pc_encoder.pos_embed.2", p1, residual=x, out=x)
@@ -378,7 +382,13 @@ class PointCloudSAM:
         pc_emb = self._lin("pc_encoder.out_proj", h).view(B, G, E)
         pc_pe = torch.empty(B, G, E, device=self.device)
         ops.fourier_pe(centers, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], pc_pe, G, G * E, flag=self._flag)
-        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1), tok.interp_index, tok.interp_weight)
+        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1), tok.interp_index, tok.interp_weight, tok.extra)
+
+    def _patch_tokens(self, coords, features, tok):
+        """PatchEmbed.forward after the grouping (pc_encoder.py:36-41) -> [B*G, patch_out]; the model variants override this."""
+        cfg = self.cfg
+        return self._patch_encoder("pc_encoder.patch_embed.patch_encoder", coords, features, tok.centers, tok.knn_idx, radius=cfg.radius,
+                                   center_idx=tok.fps_idx if cfg.centralize_features else None)
 
     # ------------------------------------------------------------------------------------------ decoder
     def _attn(self, prefix, q_in, k_in, v_in, Z, Lq, Lk):
@@ -453,50 +463,20 @@ class PointCloudSAM:
         queries = self._ln(P + ".norm_final_attn", self._lin(P + ".final_attn_token_to_image.out_proj", a), eps, residual=queries)
         return queries, keys
 
-    @torch.no_grad()
-    def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, use_center_idx=False):
-        """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState.  use_center_idx: the mask
-        encoder receives the groups' FPS indices (what PointCloudSAM.forward does, pc_sam.py:156; predict_masks does not, :65-70)."""
-        with ops.gemm_mode(self.precision):
-            return self._decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output, use_center_idx)
+    def _dense_prompt(self, st, pm, Z, N, use_center_idx):
+        """MaskEncoder.forward on a given mask prompt pm [Z, N] (prompt_encoder.py:122-133) -> [Z*G, E]."""
+        cfg = self.cfg
+        if cfg.mask_centralize_features and not use_center_idx:
+            raise ValueError("MaskEncoder.centralize_features needs center_idx: only PointCloudSAM.forward passes it (pc_sam.py:151-157); "
+                             "predict_masks would fail in the reference too (prompt_encoder.py:122-131 with center_idx=None)")
+        return self._patch_encoder("mask_encoder.patch_encoder", st.coords, pm.view(Z, N, 1), st.centers, st.knn_idx, radius=cfg.mask_encoder_radius,
+                                   center_idx=st.fps_idx if cfg.mask_centralize_features else None)
 
-    def _decode(self, st, prompt_coords, prompt_labels, prompt_masks, multimask_output, use_center_idx=False):
+    def _masks_from_keys(self, st, keys, hs, Z, T, rep, multimask_output):
+        """Upscaling + hyper-network products (mask_decoder.py:146-176): keys [Z*G, E] after the transformer, hs [Z, T, E] -> (masks [Z, C, N],
+        the selected mask-token indices)."""
         cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
-        B, N, _ = st.coords.shape
-        G = st.centers.shape[1]
-        prompt_coords = prompt_coords.to(self.device, torch.float32).contiguous()
-        if prompt_coords.shape[:-1] != prompt_labels.shape:  # prompt_encoder.py:73
-            raise AssertionError((tuple(prompt_coords.shape), tuple(prompt_labels.shape)))
-        prompt_labels = prompt_labels.to(self.device, torch.int64).contiguous()
-        Z, Pn, _ = prompt_coords.shape
-        if Z % B != 0:
-            raise ValueError(f"prompt batch {Z} is not a multiple of the cloud batch {B}")
-        rep = Z // B
-        nmt = cfg.num_mask_tokens
-        T = 1 + nmt + Pn
-        # tokens = [iou_token, mask_tokens, sparse prompt embeddings]   (mask_decoder.py:126-133)
-        tokens = torch.empty(Z, T, E, device=self.device)
-        ops.add_bcast(self.out_tokens, Z, None, tokens, Z, 1 + nmt, E, sa=0, so=T * E)
-        ops.fourier_pe(prompt_coords, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], tokens.view(-1)[(1 + nmt) * E:], Pn,
-                       T * E, labels=prompt_labels, emb0=w["point_encoder.point_embeddings.0.weight"],
-                       emb1=w["point_encoder.point_embeddings.1.weight"], flag=self._flag)
-        # src = repeat(pc_embeddings) + dense prompt embedding        (prompt_encoder.py:118-133, mask_decoder.py:136-139)
-        src = torch.empty(Z, G, E, device=self.device)
-        if prompt_masks is None:
-            ops.add_bcast(st.pc_embeddings, rep, w["mask_encoder.no_mask_embed.weight"], src, Z, G, E, sb=0, ldb=0)
-        else:
-            pm = prompt_masks.to(self.device, torch.float32).contiguous()
-            if pm.shape != (Z, N):
-                raise AssertionError((tuple(pm.shape), (Z, N)))
-            if cfg.mask_centralize_features and not use_center_idx:
-                raise ValueError("MaskEncoder.centralize_features needs center_idx: only PointCloudSAM.forward passes it (pc_sam.py:151-157); "
-                                 "predict_masks would fail in the reference too (prompt_encoder.py:122-131 with center_idx=None)")
-            dense = self._patch_encoder("mask_encoder.patch_encoder", st.coords, pm.view(Z, N, 1), st.centers, st.knn_idx, radius=cfg.mask_encoder_radius,
-                                        center_idx=st.fps_idx if cfg.mask_centralize_features else None)
-            ops.add_bcast(st.pc_embeddings, rep, dense, src, Z, G, E)
-        hs, keys = self._two_way(src.view(Z * G, E), st.pc_pe, tokens.view(Z * T, E), Z, G, T, rep)
-        hs = hs.view(Z, T, E)
-        assert hs.is_contiguous()
+        N, G, nmt = st.coords.shape[1], st.centers.shape[1], cfg.num_mask_tokens
         # upscale: 3-NN interpolation G -> N, MLP, hyper-network dot product    (mask_decoder.py:146-176)
         if st.interp_index is None:
             st.interp_index, st.interp_weight = ops.three_nn(st.coords, st.centers)
@@ -545,6 +525,49 @@ class PointCloudSAM:
             self._ln("mask_decoder.output_upscaling.1", u1, cfg.ln_eps, act=ACT_GELU, out=u1, scale_out=rs, pack=pk)
             self._lin(U3, u1, act=ACT_GELU, out=up, x_scale=rs, x_packed=pk)
             ops.gemm_batched(hyper, up, masks, C, N, E, E, E, N, C * E, N * E, C * N, Z)
+        return masks, sel
+
+    @torch.no_grad()
+    def decode(self, st: EncoderState, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, use_center_idx=False):
+        """Prompt encoders + MaskDecoder (pc_sam.py:62-87, mask_decoder.py:65-184) on a cached EncoderState.  use_center_idx: the mask
+        encoder receives the groups' FPS indices (what PointCloudSAM.forward does, pc_sam.py:156; predict_masks does not, :65-70)."""
+        with ops.gemm_mode(self.precision):
+            return self._decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output, use_center_idx)
+
+    def _decode(self, st, prompt_coords, prompt_labels, prompt_masks, multimask_output, use_center_idx=False):
+        cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
+        B, N, _ = st.coords.shape
+        G = st.centers.shape[1]
+        prompt_coords = prompt_coords.to(self.device, torch.float32).contiguous()
+        if prompt_coords.shape[:-1] != prompt_labels.shape:  # prompt_encoder.py:73
+            raise AssertionError((tuple(prompt_coords.shape), tuple(prompt_labels.shape)))
+        prompt_labels = prompt_labels.to(self.device, torch.int64).contiguous()
+        Z, Pn, _ = prompt_coords.shape
+        if Z % B != 0:
+            raise ValueError(f"prompt batch {Z} is not a multiple of the cloud batch {B}")
+        rep = Z // B
+        nmt = cfg.num_mask_tokens
+        T = 1 + nmt + Pn
+        # tokens = [iou_token, mask_tokens, sparse prompt embeddings]   (mask_decoder.py:126-133)
+        tokens = torch.empty(Z, T, E, device=self.device)
+        ops.add_bcast(self.out_tokens, Z, None, tokens, Z, 1 + nmt, E, sa=0, so=T * E)
+        ops.fourier_pe(prompt_coords, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], tokens.view(-1)[(1 + nmt) * E:], Pn,
+                       T * E, labels=prompt_labels, emb0=w["point_encoder.point_embeddings.0.weight"],
+                       emb1=w["point_encoder.point_embeddings.1.weight"], flag=self._flag)
+        # src = repeat(pc_embeddings) + dense prompt embedding        (prompt_encoder.py:118-133, mask_decoder.py:136-139)
+        src = torch.empty(Z, G, E, device=self.device)
+        if prompt_masks is None:
+            ops.add_bcast(st.pc_embeddings, rep, w["mask_encoder.no_mask_embed.weight"], src, Z, G, E, sb=0, ldb=0)
+        else:
+            pm = prompt_masks.to(self.device, torch.float32).contiguous()
+            if pm.shape != (Z, N):
+                raise AssertionError((tuple(pm.shape), (Z, N)))
+            dense = self._dense_prompt(st, pm, Z, N, use_center_idx)
+            ops.add_bcast(st.pc_embeddings, rep, dense, src, Z, G, E)
+        hs, keys = self._two_way(src.view(Z * G, E), st.pc_pe, tokens.view(Z * T, E), Z, G, T, rep)
+        hs = hs.view(Z, T, E)
+        assert hs.is_contiguous()
+        masks, sel = self._masks_from_keys(st, keys, hs, Z, T, rep, multimask_output)
         iou = torch.empty(Z, nmt, device=self.device)
         ops.mlp3(hs, T * E, 0, self.iou_mw, iou, nmt, 0, Z)      # token 0 = IoU token
         return masks, iou[:, sel[0]:sel[-1] + 1]

@@ -135,16 +135,17 @@ def three_nn(xyz: torch.Tensor, centers: torch.Tensor, eps: float = 1e-8):
     return idx, w
 
 
-def group_gather(xyz, feats, centers, knn_idx, radius=None):
-    """feats [B*rep,N,C] -> [B*rep,G,K,3+C].  common.py:99-120 / 126-187."""
+def group_gather(xyz, feats, centers, knn_idx, radius=None, width=None):
+    """feats [B*rep,N,C] -> [B*rep,G,K,3+C].  common.py:99-120 / 126-187.  width (>= 3 + C): rows zero-padded to that many columns."""
     _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64)
     B, N, _ = xyz.shape
     rep = feats.shape[0] // B
     G, K = knn_idx.shape[1:]
     C = feats.shape[-1]
-    out = torch.empty(B * rep, G, K, 3 + C, dtype=torch.float32, device=xyz.device)
-    check(_lib.load().psam_group_gather_r(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), B, rep, N, G, K, C,
-                                          float(radius or 0.0), out.data_ptr(), _stream()), "psam_group_gather")
+    width = width or 3 + C
+    out = torch.empty(B * rep, G, K, width, dtype=torch.float32, device=xyz.device)
+    check(_lib.load().psam_group_gather_ld(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), B, rep, N, G, K, C,
+                                           float(radius or 0.0), out.data_ptr(), width, _stream()), "psam_group_gather")
     return out
 
 
@@ -167,6 +168,36 @@ def patch_l1(xyz, feats, centers, knn_idx, W, bias, lnw, lnb, eps, out=None, rad
     check(_lib.load().psam_patch_l1_ex(xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(), _p(center_idx), W.data_ptr(),
                                        bias.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), eps, B, rep, N, G, K, C, float(radius or 0.0), out.data_ptr(),
                                        _p(scale_out), _stream()), "psam_patch_l1")
+    return out
+
+
+def nn_group_feats(xyz, centers, nn_idx, feats=None, logits=None, width=8):
+    """Voronoi variant: per-point rows relative to the nearest centre, zero-padded to `width` columns (csrc/rowops.hip nn_group_feats_kernel).
+    feats [B,N,C]: NNGrouper.forward (common.py:203-211) -> [B*N, width]; logits [Z,N]: MaskEncoderNN's input (prompt_encoder.py:281-287) -> [Z*N, width]."""
+    _chk(xyz); _chk(centers); _chk(nn_idx, torch.int64)
+    B, N, _ = xyz.shape
+    G = centers.shape[1]
+    if logits is None:
+        _chk(feats)
+        C, rep, mode = feats.shape[-1], 1, 0
+    else:
+        _chk(logits)
+        C, rep, mode = 0, logits.shape[0] // B, 1
+    assert width % 4 == 0 and width >= (4 + C if mode == 0 else 5)
+    out = torch.empty(B * rep * N, width, dtype=torch.float32, device=xyz.device)
+    check(_lib.load().psam_nn_group_feats(xyz.data_ptr(), centers.data_ptr(), nn_idx.data_ptr(), _p(feats), _p(logits), B, rep, N, G, C, mode, out.data_ptr(),
+                                          width, _stream()), "psam_nn_group_feats")
+    return out
+
+
+def scatter_amax(x, idx, out_rows, rows_per_set, set_stride, idx_rep=1, include_self=False):
+    """Max-pool of the rows of x [R, C] into out [out_rows, C]: row r goes to idx[(r // rows_per_set // idx_rep), r % rows_per_set] + (r //
+    rows_per_set) * set_stride (torch scatter_reduce 'amax'; see include/pointsam_hip.h psam_scatter_amax)."""
+    xp, ldx = _row_view(x, "x"); _chk(idx, torch.int64)
+    R, C = x.shape
+    out = torch.empty(out_rows, C, dtype=torch.float32, device=x.device)
+    check(_lib.load().psam_scatter_amax(xp, ldx, idx.data_ptr(), R, C, rows_per_set, set_stride, idx_rep, out.data_ptr(), out_rows, int(bool(include_self)),
+                                        _stream()), "psam_scatter_amax")
     return out
 
 

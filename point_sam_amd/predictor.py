@@ -30,7 +30,8 @@ class PointSAMPredictor:
                     device="cuda", precision: str = "f16x3") -> "PointSAMPredictor":
         cfg: ModelConfig = get_config(name, num_groups, group_size)
         sd = load_safetensors(cfg, ckpt_path) if ckpt_path else random_state_dict(cfg, seed)
-        return cls(PointCloudSAM(cfg, sd, device, precision=precision))
+        from .variants import build_model      # cfg.variant: PointCloudSAM | PointCloudSAMNN (voronoi) | PointCloudSAMHier
+        return cls(build_model(cfg, sd, device, precision=precision))
 
     # -- state ---------------------------------------------------------------------------------------------
     @staticmethod
