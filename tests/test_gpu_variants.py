@@ -63,6 +63,23 @@ def test_voronoi_forward_eval_against_reference_golden(build, golden_voronoi):
         assert _err(o["masks"], a[f"fwd_masks_{i}"]) < TOL and _err(o["iou_preds"], a[f"fwd_iou_preds_{i}"]) < TOL, i
 
 
+@pytest.mark.parametrize("name", ["tiny_hier", "tiny_voronoi"])
+def test_variant_forward_eval_against_oracle(build, name):
+    """The click loop (encoder once, then prompt_iters x {simulated click from the error region, decode with all clicks and the previous best
+    mask}) of both variants against the oracle's loop: the same clicks bit for bit, logits within tolerance."""
+    cfg = get_config(name)
+    sd = random_state_dict(cfg, seed=41)
+    xyz, rgb, _, _ = O.synthetic_batch(2, 900, seed=42)
+    gt = torch.stack([xyz[..., 0] > 0.1, (xyz - torch.tensor([0.2, 0.1, -0.1])).norm(dim=-1) < 0.3], 1)
+    want = V.forward_eval(sd, cfg, xyz, rgb, gt, prompt_iters=3, mode="exact")
+    model = build(cfg, sd, "cuda", precision="f16x3")
+    model.prompt_iters = 3
+    outs = model(xyz.cuda(), rgb.cuda(), gt.cuda(), is_eval=True)
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert torch.equal(o["prompt_coords"].cpu(), w["prompt_coords"]) and torch.equal(o["prompt_labels"].cpu(), w["prompt_labels"]), i
+        assert _err(o["masks"], w["masks"]) < TOL and _err(o["iou_preds"], w["iou_preds"]) < TOL, i
+
+
 CASES = {
     # wide enough that the packed-operand GEMMs run (rows >= 256, widths >= 128)
     "voronoi_256": lambda: ModelConfig(VIT_TINY_SWIGLU, 64, 1, in_channels=7, prompt_iters=3, variant="voronoi", nn_hidden=256),
