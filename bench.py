@@ -162,7 +162,8 @@ class HipHarness:
             pipe = BatchPipeline(self.model, dense_streams=1)
         xyz, rgb, prompt, labels = self.batch
         n = 2
-        for k in range(n):
+        c_blocks, self.model.c_blocks = self.model.c_blocks, False      # the sampler wraps the launches the Python host issues: this pass sequences the
+        for k in range(n):                                              # blocks' kernels itself (the same launches psam_eva_block issues in the timed region)
             last = k == n - 1
             if last:
                 others = [s for i, s in enumerate(pipe.dense) if i != pipe.count % len(pipe.dense)] if pipe.dense else []
@@ -178,6 +179,7 @@ class HipHarness:
         while len(pipe):
             pipe.next()
         torch.cuda.synchronize()
+        self.model.c_blocks = c_blocks
         return prof
 
     def stage_times(self):

@@ -243,6 +243,30 @@ int32_t psam_attention_packed(const void* qkv, int64_t ld, const float* sc, floa
 int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                            float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 
+/* ONE EVA02 (SwiGLU) transformer block of the patch encoder in one call (csrc/blocks.hip) -- timm's block as the reference runs it
+ * (pc_sam/model/pc_encoder.py:138-139, no rope): x += proj(SDPA(LN1 x)); x += fc2(LN(SiLU(fc1_g h) * fc1_x h)), h = LN2 x.  "f16x3" arithmetic with
+ * every hand-over fused as the Python host does it: eight launches, nothing in between.  Head dim 64, dim % 32 == 0, B * L % 256 == 0.
+ * psam_eva_block_prepare (load time; copies the weights to the host once, uses a temporary device buffer, synchronises) packs a block's weights
+ * -- given in the reference's / timm's state-dict layout, [out, in] fp32 device pointers -- into `prepared` (psam_eva_block_prepared_bytes) and
+ * fills the host-side `plan`; the LayerNorm parameters and the projection bias are read through the plan at run time and must stay alive. */
+typedef struct {
+    const float *norm1_w, *norm1_b, *q_w, *q_b, *k_w, *v_w, *v_b, *proj_w, *proj_b, *norm2_w, *norm2_b;      /* attn.k_proj has no bias */
+    const float *fc1_g_w, *fc1_g_b, *fc1_x_w, *fc1_x_b, *mlp_norm_w, *mlp_norm_b, *fc2_w, *fc2_b;
+    int32_t dim, heads, hidden;      /* hidden: SwiGLU width (2730 for eva02_large) */
+    float eps;                       /* LayerNorm eps of the transformer (1e-6) */
+} psam_eva_block_weights_t;
+typedef struct {
+    int32_t dim, heads, hidden, hidden_pad;
+    float eps, qkv_bound, v_bound, u_c2, u_c1, u_c0;      /* a-priori bounds of the packed hand-overs */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *proj_b;
+    int64_t o_wqkv, o_sqkv, o_bqkv, o_wproj, o_sproj, o_w1, o_s1, o_b1, o_w2g, o_s2g, o_lnc, o_lnd;      /* byte offsets into `prepared` */
+} psam_eva_block_plan_t;
+size_t psam_eva_block_prepared_bytes(int32_t dim, int32_t hidden);
+int32_t psam_eva_block_prepare(const psam_eva_block_weights_t* weights, psam_eva_block_plan_t* plan, void* prepared, size_t prepared_bytes, psam_stream_t stream);
+size_t psam_eva_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden);
+/* x [B*L, dim] fp32, updated in place; ws: psam_eva_block_ws_bytes(B*L, dim, hidden) bytes of scratch */
+int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes, psam_stream_t stream);
+
 /* Token side of one TwoWayAttentionBlock in ONE launch (csrc/twoway.hip): self-attention + norm1, token -> image attention + norm2, the MLP
  * + norm3 on the Z * T <= 64 output-token rows, and the k / v projections of the image -> token attention that follows -- what
  * pc_sam/model/transformer.py:144-175 does for `queries`; mode 1: only the token -> image attention + LayerNorm of :91-99

@@ -47,6 +47,10 @@ SIGNATURES = {
     "psam_gemm_f16x3p_splitk": (i32, [i32, i32, i32, i32]),
     "psam_nn_group_feats": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, i64, ptr]),
     "psam_scatter_amax": (i32, [ptr, i64, ptr, i64, i32, i64, i64, i32, ptr, i64, i32, ptr]),
+    "psam_eva_block_prepared_bytes": (size_t, [i32, i32]),
+    "psam_eva_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
+    "psam_eva_block_ws_bytes": (size_t, [i64, i32, i32]),
+    "psam_eva_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
     "psam_twoway_tokens_ws_floats": (i64, [i32]),
     "psam_twoway_tokens": (i32, [ptr, ptr]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
@@ -81,6 +85,19 @@ class GemmFuse(ctypes.Structure):
                 ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
                 ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64),
                 ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32), ("out_bound", ptr)]
+
+
+class EvaBlockWeights(ctypes.Structure):
+    """psam_eva_block_weights_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, ptr) for n in ("norm1_w", "norm1_b", "q_w", "q_b", "k_w", "v_w", "v_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_g_w", "fc1_g_b",
+                                    "fc1_x_w", "fc1_x_b", "mlp_norm_w", "mlp_norm_b", "fc2_w", "fc2_b")] + [("dim", i32), ("heads", i32), ("hidden", i32), ("eps", f32)])
+
+
+class EvaBlockPlan(ctypes.Structure):
+    """psam_eva_block_plan_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "hidden_pad")] + [(n, f32) for n in ("eps", "qkv_bound", "v_bound", "u_c2", "u_c1", "u_c0")] +
+                [(n, ptr) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "proj_b")] +
+                [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_b1", "o_w2g", "o_s2g", "o_lnc", "o_lnd")])
 
 
 class TwoWayTokens(ctypes.Structure):

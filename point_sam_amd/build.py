@@ -25,6 +25,7 @@ SOURCES = [
     ("attention.hip", []),
     ("rowops.hip", []),
     ("twoway.hip", []),
+    ("blocks.hip", []),
     ("error.cpp", ["-x", "hip"]),
 ]
 

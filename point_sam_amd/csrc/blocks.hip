@@ -1,0 +1,223 @@
+// Coarse C-ABI entry point: ONE EVA02 (SwiGLU) transformer block of the patch encoder -- timm's block as the reference calls it
+// (pc_sam/model/pc_encoder.py:138-139: x = block(x), no rope):  x += proj(SDPA(q, k, v)(LN1 x));  x += fc2(LN(SiLU(fc1_g h) * fc1_x h)), h = LN2 x.
+//
+// psam_eva_block_prepare packs a block's weights ONCE (what the Python host did in PointCloudSAM._pack): q|k|v concatenated, fc1_g / fc1_x
+// interleaved in 32-row blocks, fc2 pre-multiplied by the inner LayerNorm's gamma (the LayerNorm folded into the GEMM), every matrix split
+// into g8-packed hi|lo fp16 with power-of-two row scales, and the a-priori bounds of the packed hand-overs.  psam_eva_block then runs the
+// block as eight launches with nothing in between -- LayerNorm (packed output + per-row bound) | qkv GEMM (packed q|k|v) | attention on
+// packed operands | projection + residual | LayerNorm | fc1 (SwiGLU gate, packed output, LayerNorm partials) | partial merge | fc2 with the
+// folded LayerNorm + residual -- so that a caller in any language drives the dominant 83 % of the path's FLOPs with one call per layer.
+// Host code only; every kernel is another entry point of this library.
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "common.h"
+#pragma GCC visibility push(default)
+#include "../../include/pointsam_hip.h"
+#pragma GCC visibility pop
+
+namespace {
+constexpr int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+inline int kpad(int k) { return (k + 31) / 32 * 32; }
+
+struct Carve {      // bump allocator over a caller-provided buffer
+    char* base; int64_t off = 0;
+    explicit Carve(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T> T* take(int64_t count) { T* r = reinterpret_cast<T*>(base + off); off += align256(count * (int64_t)sizeof(T)); return r; }
+};
+
+double row_norm(const float* w, int k) {
+    double s = 0.0;
+    for (int i = 0; i < k; ++i) s += (double)w[i] * (double)w[i];
+    return std::sqrt(s);
+}
+}  // namespace
+
+// bytes of the device blob psam_eva_block_prepare fills
+PSAM_API size_t psam_eva_block_prepared_bytes(int32_t dim, int32_t hidden) {
+    if (dim <= 0 || hidden <= 0) return 0;
+    const int64_t D = dim, Dp = kpad(dim), Hp = (hidden + 31) / 32 * 32;
+    int64_t b = 0;
+    b += align256(3 * D * Dp * 4) + align256(3 * D * 4) + align256(3 * D * 4);      // wqkv packed, scales, bias
+    b += align256(D * Dp * 4) + align256(D * 4);                                    // proj packed, scales
+    b += align256(2 * Hp * Dp * 4) + align256(2 * Hp * 4) + align256(2 * Hp * 4);   // fc1 (g/x interleaved) packed, scales, bias
+    b += align256(D * Hp * 4) + align256(D * 4) + align256(D * 4) + align256(D * 4);   // fc2 * gamma packed, scales, ln_c, ln_d
+    return (size_t)b;
+}
+
+// Packs one block's weights into `prepared` (device, psam_eva_block_prepared_bytes) and fills `plan` (host).  Load-time call: it copies the
+// weights to the host, builds the concatenated / interleaved / gamma-folded matrices and the bounds there in double precision, and uses a
+// temporary device buffer for the fp32 staging of the largest matrix.  Synchronises `stream`.
+PSAM_API int32_t psam_eva_block_prepare(const psam_eva_block_weights_t* wt, psam_eva_block_plan_t* plan, void* prepared, size_t prepared_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(wt && plan && prepared, PSAM_EINVAL, "psam_eva_block_prepare: null pointer");
+    const int D = wt->dim, H = wt->hidden, heads = wt->heads;
+    PSAM_REQUIRE(D > 0 && H > 0 && heads > 0 && D % heads == 0 && D / heads == 64 && D % 32 == 0, PSAM_EINVAL,
+                 "psam_eva_block_prepare: head dim must be 64 and dim % 32 == 0 (the packed-operand attention)");
+    const int Hp = (H + 31) / 32 * 32, Dp = kpad(D);
+    PSAM_REQUIRE(Hp % 64 == 0, PSAM_EINVAL, "psam_eva_block_prepare: hidden rounded up to 32 must be a multiple of 64 (fused SwiGLU epilogue)");
+    PSAM_REQUIRE(prepared_bytes >= psam_eva_block_prepared_bytes(D, H), PSAM_EWORKSPACE, "psam_eva_block_prepare: prepared buffer too small");
+    const float* ptrs[] = {wt->norm1_w, wt->norm1_b, wt->q_w, wt->q_b, wt->k_w, wt->v_w, wt->v_b, wt->proj_w, wt->proj_b, wt->norm2_w, wt->norm2_b,
+                           wt->fc1_g_w, wt->fc1_g_b, wt->fc1_x_w, wt->fc1_x_b, wt->mlp_norm_w, wt->mlp_norm_b, wt->fc2_w, wt->fc2_b};
+    for (const float* p : ptrs) PSAM_REQUIRE(p, PSAM_EINVAL, "psam_eva_block_prepare: null weight pointer");
+
+    auto fetch = [&](const float* dev, int64_t n) { std::vector<float> h((size_t)n); return hipMemcpy(h.data(), dev, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? h : std::vector<float>(); };
+#define FETCH(name, dev, n) std::vector<float> name = fetch(dev, n); PSAM_REQUIRE((int64_t)name.size() == (int64_t)(n), PSAM_EINVAL, "psam_eva_block_prepare: cannot read a weight tensor")
+    FETCH(qw, wt->q_w, (int64_t)D * D); FETCH(kw, wt->k_w, (int64_t)D * D); FETCH(vw, wt->v_w, (int64_t)D * D);
+    FETCH(qb, wt->q_b, D); FETCH(vb, wt->v_b, D);
+    FETCH(g1, wt->norm1_w, D); FETCH(b1n, wt->norm1_b, D);
+    FETCH(gw, wt->fc1_g_w, (int64_t)H * D); FETCH(xw, wt->fc1_x_w, (int64_t)H * D); FETCH(gb, wt->fc1_g_b, H); FETCH(xb, wt->fc1_x_b, H);
+    FETCH(mg, wt->mlp_norm_w, H); FETCH(mb, wt->mlp_norm_b, H);
+    FETCH(w2, wt->fc2_w, (int64_t)D * H); FETCH(b2, wt->fc2_b, D);
+#undef FETCH
+
+    // ---- host-side matrices
+    std::vector<float> wqkv((size_t)3 * D * D), bqkv((size_t)3 * D, 0.f);
+    std::memcpy(wqkv.data(), qw.data(), (size_t)D * D * 4);
+    std::memcpy(wqkv.data() + (size_t)D * D, kw.data(), (size_t)D * D * 4);
+    std::memcpy(wqkv.data() + (size_t)2 * D * D, vw.data(), (size_t)D * D * 4);
+    for (int i = 0; i < D; ++i) { bqkv[i] = qb[i]; bqkv[2 * D + i] = vb[i]; }      // k_proj has no bias (timm EvaAttention)
+    // fc1: alternating 32-row blocks of fc1_g / fc1_x, hidden padded to Hp with zero rows (PSAM_ACT_SWIGLU)
+    std::vector<float> w1((size_t)2 * Hp * D, 0.f), bias1((size_t)2 * Hp, 0.f);
+    for (int n = 0; n < H; ++n) {
+        const int64_t blk = n / 32, r = n % 32;
+        std::memcpy(&w1[(size_t)((blk * 2) * 32 + r) * D], &gw[(size_t)n * D], (size_t)D * 4);
+        std::memcpy(&w1[(size_t)((blk * 2 + 1) * 32 + r) * D], &xw[(size_t)n * D], (size_t)D * 4);
+        bias1[(size_t)(blk * 2) * 32 + r] = gb[n];
+        bias1[(size_t)(blk * 2 + 1) * 32 + r] = xb[n];
+    }
+    // fc2 with the inner LayerNorm folded in: fc2(LN(u)) = rstd (u (W2 gamma)^T - mean c) + d,  c = (W2 gamma) 1,  d = W2 beta + b2
+    std::vector<float> w2g((size_t)D * Hp, 0.f), lnc(D), lnd(D);
+    for (int n = 0; n < D; ++n) {
+        double c = 0.0, d = (double)b2[n];
+        for (int k = 0; k < H; ++k) {
+            const double wg = (double)w2[(size_t)n * H + k] * (double)mg[k];
+            w2g[(size_t)n * Hp + k] = (float)wg;
+            c += wg;
+            d += (double)w2[(size_t)n * H + k] * (double)mb[k];
+        }
+        lnc[n] = (float)c; lnd[n] = (float)d;
+    }
+    // ---- bounds: |W_n . h + b_n| <= ||W_n|| ||h|| + |b_n|;  a LayerNorm output has ||h|| <= max|gamma| sqrt(D) + ||beta||
+    double gmax = 0.0, bnorm = 0.0;
+    for (int i = 0; i < D; ++i) { gmax = std::fmax(gmax, std::fabs((double)g1[i])); bnorm += (double)b1n[i] * (double)b1n[i]; }
+    const double hnorm = gmax * std::sqrt((double)D) + std::sqrt(bnorm);
+    double nmax_all = 0.0, nmax_v = 0.0, bmax_all = 0.0, bmax_v = 0.0;
+    for (int n = 0; n < 3 * D; ++n) {
+        const double nn = row_norm(&wqkv[(size_t)n * D], D);
+        nmax_all = std::fmax(nmax_all, nn); bmax_all = std::fmax(bmax_all, std::fabs((double)bqkv[n]));
+        if (n >= 2 * D) { nmax_v = std::fmax(nmax_v, nn); bmax_v = std::fmax(bmax_v, std::fabs((double)bqkv[n])); }
+    }
+    // gated rows: |silu(g_n) x_n| <= (a_n t + b_n)(c_n t + d_n), t = ||h||_2 per row; coefficient-wise maxima over the hidden units
+    double k2 = 0.0, k1 = 0.0, k0 = 0.0;
+    for (int n = 0; n < H; ++n) {
+        const double a = row_norm(&gw[(size_t)n * D], D), c = row_norm(&xw[(size_t)n * D], D), b = std::fabs((double)gb[n]), d = std::fabs((double)xb[n]);
+        k2 = std::fmax(k2, a * c); k1 = std::fmax(k1, a * d + b * c); k0 = std::fmax(k0, b * d);
+    }
+    std::memset(plan, 0, sizeof(*plan));
+    plan->dim = D; plan->heads = heads; plan->hidden = H; plan->hidden_pad = Hp; plan->eps = wt->eps;
+    plan->qkv_bound = (float)(1.001 * (nmax_all * hnorm + bmax_all) + 1e-30);
+    plan->v_bound = (float)(1.001 * (nmax_v * hnorm + bmax_v) + 1e-30);
+    plan->u_c2 = (float)(1.002 * k2); plan->u_c1 = (float)(1.002 * k1); plan->u_c0 = (float)(1.002 * k0 + 1e-30);
+    plan->norm1_w = wt->norm1_w; plan->norm1_b = wt->norm1_b; plan->norm2_w = wt->norm2_w; plan->norm2_b = wt->norm2_b; plan->proj_b = wt->proj_b;
+
+    // ---- device blob: upload the fp32 matrix to a temporary, row scales + g8 packing by the library's own kernels
+    Carve cv(prepared);
+    float* p_wqkv = cv.take<float>((int64_t)3 * D * Dp); float* s_wqkv = cv.take<float>(3 * D); float* d_bqkv = cv.take<float>(3 * D);
+    float* p_proj = cv.take<float>((int64_t)D * Dp); float* s_proj = cv.take<float>(D);
+    float* p_w1 = cv.take<float>((int64_t)2 * Hp * Dp); float* s_w1 = cv.take<float>(2 * Hp); float* d_b1 = cv.take<float>(2 * Hp);
+    float* p_w2g = cv.take<float>((int64_t)D * Hp); float* s_w2g = cv.take<float>(D); float* d_lnc = cv.take<float>(D); float* d_lnd = cv.take<float>(D);
+    plan->o_wqkv = (char*)p_wqkv - cv.base; plan->o_sqkv = (char*)s_wqkv - cv.base; plan->o_bqkv = (char*)d_bqkv - cv.base;
+    plan->o_wproj = (char*)p_proj - cv.base; plan->o_sproj = (char*)s_proj - cv.base;
+    plan->o_w1 = (char*)p_w1 - cv.base; plan->o_s1 = (char*)s_w1 - cv.base; plan->o_b1 = (char*)d_b1 - cv.base;
+    plan->o_w2g = (char*)p_w2g - cv.base; plan->o_s2g = (char*)s_w2g - cv.base; plan->o_lnc = (char*)d_lnc - cv.base; plan->o_lnd = (char*)d_lnd - cv.base;
+
+    float* tmp = nullptr;
+    const int64_t tmp_floats = std::max<int64_t>({(int64_t)3 * D * D, (int64_t)2 * Hp * D, (int64_t)D * Hp});
+    PSAM_REQUIRE(hipMalloc(&tmp, (size_t)tmp_floats * 4) == hipSuccess, PSAM_EINVAL, "psam_eva_block_prepare: cannot allocate the staging buffer");
+    int32_t rc = PSAM_OK;
+    auto pack = [&](const float* host, const float* dev_src, int rows, int K, float* packed, float* scales) {
+        if (rc != PSAM_OK) return;
+        const float* src = dev_src;
+        if (host) {
+            if (hipMemcpyAsync(tmp, host, (size_t)rows * K * 4, hipMemcpyHostToDevice, stream) != hipSuccess) { psam_set_error("psam_eva_block_prepare: upload failed"); rc = PSAM_EINVAL; return; }
+            src = tmp;
+        }
+        rc = psam_row_scale_f16(src, K, rows, K, scales, stream);
+        if (rc == PSAM_OK) rc = psam_pack_rows_f16x2_g8(src, K, scales, rows, K, packed, kpad(K), stream);
+        if (rc == PSAM_OK && hipStreamSynchronize(stream) != hipSuccess) { psam_set_error("psam_eva_block_prepare: packing failed"); rc = PSAM_EINVAL; }
+    };
+    pack(wqkv.data(), nullptr, 3 * D, D, p_wqkv, s_wqkv);
+    pack(nullptr, wt->proj_w, D, D, p_proj, s_proj);
+    pack(w1.data(), nullptr, 2 * Hp, D, p_w1, s_w1);
+    pack(w2g.data(), nullptr, D, Hp, p_w2g, s_w2g);
+    auto up = [&](float* dst, const std::vector<float>& src) {
+        if (rc == PSAM_OK && hipMemcpy(dst, src.data(), src.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { psam_set_error("psam_eva_block_prepare: upload failed"); rc = PSAM_EINVAL; }
+    };
+    up(d_bqkv, bqkv); up(d_b1, bias1); up(d_lnc, lnc); up(d_lnd, lnd);
+    hipFree(tmp);
+    return rc;
+}
+
+// workspace of one psam_eva_block call on M token rows
+PSAM_API size_t psam_eva_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden) {
+    if (M <= 0 || dim <= 0 || hidden <= 0) return 0;
+    const int64_t D = dim, Dp = kpad(dim), Hp = (hidden + 31) / 32 * 32, segs = psam_gemm_f16x3p_stat_segs((int32_t)(2 * Hp));
+    int64_t b = 0;
+    b += align256(M * Dp * 4);            // h: LayerNorm output, packed
+    b += 3 * align256(M * 4);             // its row scales, the gated rows' bound, attention output scales
+    b += align256(M * 3 * D * 4);         // q | k | v packed
+    b += align256(M * 4);                 // their scale
+    b += align256(M * Dp * 4);            // attention output, packed
+    b += align256(M * Hp * 4);            // gated hidden rows, packed
+    b += align256(M * 4);                 // their scales
+    b += align256(M * segs * 2 * 4);      // LayerNorm partials
+    b += 2 * align256(M * 4);             // mean, rstd
+    return (size_t)b;
+}
+
+// x [B*L, dim] (fp32, updated in place) <- block(x).  M = B * L must be a multiple of 256 (the fused GEMM epilogues work on whole tiles).
+PSAM_API int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(plan && prepared && x && ws, PSAM_EINVAL, "psam_eva_block: null pointer");
+    const int D = plan->dim, H = plan->hidden, Hp = plan->hidden_pad, heads = plan->heads, Dp = kpad(D);
+    const int64_t M = (int64_t)B * L;
+    PSAM_REQUIRE(B > 0 && L > 0 && M % 256 == 0 && M < ((int64_t)1 << 31), PSAM_EINVAL, "psam_eva_block: B * L must be a positive multiple of 256");
+    PSAM_REQUIRE(ws_bytes >= psam_eva_block_ws_bytes(M, D, H), PSAM_EWORKSPACE, "psam_eva_block: workspace too small");
+    const char* pb = static_cast<const char*>(prepared);
+    auto P = [&](int64_t off) { return reinterpret_cast<const float*>(pb + off); };
+    const int segs = psam_gemm_f16x3p_stat_segs(2 * Hp);
+    Carve cv(ws);
+    float* h = cv.take<float>(M * Dp);
+    float* rs = cv.take<float>(M); float* ub = cv.take<float>(M); float* so = cv.take<float>(M);
+    float* qkv = cv.take<float>(M * 3 * D);
+    float* sq = cv.take<float>(M);
+    float* o = cv.take<float>(M * Dp);
+    float* u = cv.take<float>(M * Hp);
+    float* su = cv.take<float>(M);
+    float* st = cv.take<float>(M * segs * 2);
+    float* mean = cv.take<float>(M); float* rstd = cv.take<float>(M);
+    int32_t rc;
+    // attention half
+    rc = psam_layernorm_ex(x, D, nullptr, 0, plan->norm1_w, plan->norm1_b, h, Dp, M, D, plan->eps, 0, rs, 1, stream);
+    if (rc) return rc;
+    psam_gemm_fuse_t f;
+    std::memset(&f, 0, sizeof(f));
+    f.pack_out = 1; f.out_scale = sq; f.out_k1 = 0.f; f.out_k2 = plan->qkv_bound;
+    rc = psam_gemm_f16x3p_ex(h, Dp, rs, P(plan->o_wqkv), Dp, P(plan->o_sqkv), qkv, 3 * D, P(plan->o_bqkv), nullptr, 0, nullptr, 0, 0, (int32_t)M, 3 * D, Dp, 1.f, 0, &f, stream);
+    if (rc) return rc;
+    rc = psam_attention_packed(qkv, 3 * D, sq, o, Dp, so, B, heads, L, D / heads, 1.0f / std::sqrt((float)(D / heads)), plan->v_bound, stream);
+    if (rc) return rc;
+    rc = psam_gemm_f16x3p_ex(o, Dp, so, P(plan->o_wproj), Dp, P(plan->o_sproj), x, D, plan->proj_b, x, D, nullptr, 0, 0, (int32_t)M, D, Dp, 1.f, 0, nullptr, stream);
+    if (rc) return rc;
+    // MLP half
+    rc = psam_layernorm_ex2(x, D, nullptr, 0, plan->norm2_w, plan->norm2_b, h, Dp, M, D, plan->eps, 0, rs, 1, ub, plan->u_c2, plan->u_c1, plan->u_c0, stream);
+    if (rc) return rc;
+    std::memset(&f, 0, sizeof(f));
+    f.pack_out = 1; f.out_scale = su; f.out_bound = ub; f.stats = st; f.stat_cols = H;
+    rc = psam_gemm_f16x3p_ex(h, Dp, rs, P(plan->o_w1), Dp, P(plan->o_s1), u, Hp, P(plan->o_b1), nullptr, 0, nullptr, 0, 0, (int32_t)M, 2 * Hp, Dp, 1.f, PSAM_ACT_SWIGLU, &f, stream);
+    if (rc) return rc;
+    rc = psam_ln_stats_finalize(st, (int32_t)M, segs, H, plan->eps, mean, rstd, stream);
+    if (rc) return rc;
+    std::memset(&f, 0, sizeof(f));
+    f.ln_mean = mean; f.ln_rstd = rstd; f.ln_c = P(plan->o_lnc);
+    return psam_gemm_f16x3p_ex(u, Hp, su, P(plan->o_w2g), Hp, P(plan->o_s2g), x, D, P(plan->o_lnd), x, D, nullptr, 0, 0, (int32_t)M, D, Hp, 1.f, 0, &f, stream);
+}

@@ -71,6 +71,8 @@ class PointCloudSAM:
         if precision not in ops.GEMM_MODES:
             raise ValueError(f"precision must be one of {ops.GEMM_MODES}")
         self.precision = precision
+        self.c_blocks = True      # "f16x3", EVA02 blocks: one psam_eva_block call per layer (csrc/blocks.hip: the same eight launches, sequenced and
+                                  # packed by the library) instead of sequencing them here; False: the Python sequence below (tests A/B both)
         self.fuse_tokens = False  # the decoder's token side as one launch per two-way layer (csrc/twoway.hip) instead of ~22: parity-green but
                                   # slower (0.56 vs 0.48 ms at cfg #2, profiles/r03_twoway.txt), so off; tests A/B both
         self._tw = None
@@ -208,6 +210,9 @@ class PointCloudSAM:
                 pw = w[blk.p + ".attn.proj.weight"]
                 if ops.F16Weight.eligible(*pw.shape):
                     self.fw[blk.p + ".attn.proj.weight"] = ops.F16Weight(pw)
+            if cfg.vit.swiglu and ops.EvaBlock.supported(D, cfg.vit.heads, cfg.vit.mlp_hidden):
+                for blk in self.blocks:     # the library's own packing of the block (psam_eva_block_prepare)
+                    blk.c_block = ops.EvaBlock(w, blk.p, D, cfg.vit.heads, cfg.vit.mlp_hidden, cfg.vit.ln_eps)
             torch.cuda.current_stream(self.device).synchronize()   # the packed weights are consumed from several streams afterwards
 
     # ------------------------------------------------------------------------------------------ building blocks
@@ -276,6 +281,9 @@ class PointCloudSAM:
         # "f16x3" GEMMs need a power-of-two scale per operand row and stage hi/lo fp16 planes: the LayerNorms that feed them emit
         # the scale and (when the float4 LN path applies) the packed planes directly, so the GEMM does no split arithmetic for A
         f16 = self.precision == "f16x3"
+        if (f16 and self.c_blocks and hasattr(blk, "c_block") and x.shape[0] % 256 == 0 and self.fuse_mlp and self.fuse_attn_pack and self.fuse_attn_operands
+                and self.row_bounds and ops.GEMM_MODE == "f16x3" and x.is_contiguous()):
+            return blk.c_block.run(x, B, L)
         pk = f16 and x.shape[0] >= ops.SPLIT_MIN_M and isinstance(blk.wqkv, ops.F16Weight) and ops.layernorm_can_pack(D)
         rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if pk else None
         h = self._ln(p + ".norm1", x, vit.ln_eps, scale_out=rs, pack=pk)

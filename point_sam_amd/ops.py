@@ -514,6 +514,50 @@ def attention_packed(qkv_packed, scale_rows, out, out_scale, B, H, L, hd, scale,
     return out
 
 
+class EvaBlock:
+    """One EVA02 (SwiGLU) transformer block prepared for psam_eva_block (csrc/blocks.hip): packed weights + bounds, built once at load by the
+    library itself (psam_eva_block_prepare) from the state-dict tensors.  w: name -> fp32 device tensor; prefix 'pc_encoder.transformer.blocks.i'."""
+
+    def __init__(self, w, prefix: str, dim: int, heads: int, hidden: int, eps: float):
+        import ctypes
+        L = _lib.load()
+        wt = _lib.EvaBlockWeights()
+        self.keep = []
+        names = dict(norm1_w="norm1.weight", norm1_b="norm1.bias", q_w="attn.q_proj.weight", q_b="attn.q_proj.bias", k_w="attn.k_proj.weight",
+                     v_w="attn.v_proj.weight", v_b="attn.v_proj.bias", proj_w="attn.proj.weight", proj_b="attn.proj.bias", norm2_w="norm2.weight",
+                     norm2_b="norm2.bias", fc1_g_w="mlp.fc1_g.weight", fc1_g_b="mlp.fc1_g.bias", fc1_x_w="mlp.fc1_x.weight", fc1_x_b="mlp.fc1_x.bias",
+                     mlp_norm_w="mlp.norm.weight", mlp_norm_b="mlp.norm.bias", fc2_w="mlp.fc2.weight", fc2_b="mlp.fc2.bias")
+        for slot, n in names.items():
+            t = w[f"{prefix}.{n}"]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"{prefix}.{n}: contiguous fp32 expected")
+            self.keep.append(t)
+            setattr(wt, slot, t.data_ptr())
+        wt.dim, wt.heads, wt.hidden, wt.eps = int(dim), int(heads), int(hidden), float(eps)
+        self.plan = _lib.EvaBlockPlan()
+        self.blob = torch.empty(int(L.psam_eva_block_prepared_bytes(dim, hidden)), dtype=torch.uint8, device=self.keep[0].device)
+        check(L.psam_eva_block_prepare(ctypes.byref(wt), ctypes.byref(self.plan), self.blob.data_ptr(), self.blob.numel(), _stream()), "psam_eva_block_prepare")
+        self.dim, self.hidden = int(dim), int(hidden)
+
+    @staticmethod
+    def supported(dim: int, heads: int, hidden: int) -> bool:
+        return dim % heads == 0 and dim // heads == 64 and dim % 32 == 0 and ((hidden + 31) // 32 * 32) % 64 == 0
+
+    def run(self, x, B: int, L: int, ws=None):
+        """x [B*L, dim] fp32, updated in place."""
+        import ctypes
+        lib = _lib.load()
+        _chk(x, name="x")
+        M = B * L
+        if x.shape != (M, self.dim) or not x.is_contiguous():
+            raise ValueError("x must be a contiguous [B*L, dim] tensor")
+        need = int(lib.psam_eva_block_ws_bytes(M, self.dim, self.hidden))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        check(lib.psam_eva_block(ctypes.byref(self.plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), _stream()), "psam_eva_block")
+        return x
+
+
 class TwoWayLayerWeights:
     """The weight pointers of one TwoWayAttentionBlock's token side (or of the final token -> image attention: final=True) as a
     psam_twoway_tokens_t skeleton (csrc/twoway.hip); keeps the tensors alive.  w: name -> fp32 tensor; prefix: e.g.

@@ -174,6 +174,37 @@ def test_fused_token_decoder_matches_unfused(gpu, precision, B, clicks, rep):
     assert max(errs) < 2e-5, errs
 
 
+def test_c_eva_block_matches_python_sequence(gpu):
+    """psam_eva_block (csrc/blocks.hip: the library packs a block's weights and sequences its eight launches) against the same launches sequenced by
+    the Python host from its own packing: the kernels and their order are the same, the bounds are computed twice (C++ doubles / torch doubles), so the
+    embeddings agree to fp32 round-off at worst; also directly through the C ABI on one block."""
+    from point_sam_amd import ops
+    cfg = get_config("base", 128, 32)
+    sd = random_state_dict(cfg, seed=8)
+    xyz, rgb, prompt, labels = O.synthetic_batch(2, 4096, seed=9)
+    model = gpu(cfg, sd, precision="f16x3")
+    assert all(hasattr(b, "c_block") for b in model.blocks)
+    outs = {}
+    for c in (True, False):
+        model.c_blocks = c
+        st = model.encode(xyz.cuda(), rgb.cuda())
+        outs[c] = (st.pc_embeddings, *model.decode(st, prompt.cuda(), labels.cuda(), None, True))
+    errs = [_maxerr(a, b) for a, b in zip(outs[True], outs[False])]
+    print(f"\n[psam_eva_block vs Python-sequenced block, ViT-B x12] max|diff| embeddings {errs[0]:.2e} masks {errs[1]:.2e} iou {errs[2]:.2e}")
+    assert max(errs) < 2e-5
+    # one block alone, bitwise repeatable, workspace too small refused
+    blk = model.blocks[0].c_block
+    x = torch.randn(256, cfg.vit.dim, device="cuda")
+    a, b = blk.run(x.clone(), 2, 128), blk.run(x.clone(), 2, 128)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and not torch.equal(a, x)
+    import ctypes
+    lib = ops._lib.load()
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    assert lib.psam_eva_block(ctypes.byref(blk.plan), blk.blob.data_ptr(), x.data_ptr(), 2, 128, small.data_ptr(), small.numel(), None) == -3      # PSAM_EWORKSPACE
+    with pytest.raises(Exception):
+        blk.run(torch.randn(100, cfg.vit.dim, device="cuda"), 1, 100)      # M % 256 != 0
+
+
 def test_attention_packed_output_is_transparent(gpu):
     """Attention writing its output packed for the projection (bound-derived per-cloud scale) vs fp32 output + separate pack pass: a
     power-of-two scale does not change the decoded hi + lo except where lo goes subnormal (elements ~2^-10 below the row maximum, since
