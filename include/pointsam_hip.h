@@ -267,6 +267,42 @@ size_t psam_eva_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden);
 /* x [B*L, dim] fp32, updated in place; ws: psam_eva_block_ws_bytes(B*L, dim, hidden) bytes of scratch */
 int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes, psam_stream_t stream);
 
+/* PatchEncoder.forward on kNN groups in one call (csrc/blocks.hip): the mini-PointNet of the patch embedding (features = rgb) and of the mask
+ * encoder (features = mask logits) -- pc_sam/model/common.py:477-506 after the gather of :99-120 / :126-187 -- "f16x3", fused as the Python host
+ * runs it (six launches; both max-pools inside GEMM epilogues).  hidden_dims[0] == 128, group size 32 or 64, B * rep * G * K % 256 == 0.
+ * Weights: the reference's conv1.{0,1,3} / conv2.{0,1,3} tensors ([out, in] fp32 device pointers); the plan keeps pointers to the small ones. */
+typedef struct {
+    const float *c10_w, *c10_b, *c11_w, *c11_b, *c13_w, *c13_b, *c20_w, *c20_b, *c21_w, *c21_b, *c23_w, *c23_b;
+    int32_t cin, h0, h1, cout;
+    float eps;
+} psam_patch_encoder_weights_t;
+typedef struct {
+    int32_t cin, h0, h1, cout;
+    float eps, k1, k2;
+    const float *c10_w, *c10_b, *c11_w, *c11_b, *c13_b, *c20_w, *c20_b, *c21_w, *c21_b, *c23_b;
+    int64_t o_w13, o_s13, o_w20m, o_s20m, o_w20x, o_s20x, o_w23, o_s23;
+} psam_patch_encoder_plan_t;
+size_t psam_patch_encoder_prepared_bytes(int32_t h0, int32_t h1, int32_t cout);
+int32_t psam_patch_encoder_prepare(const psam_patch_encoder_weights_t* weights, psam_patch_encoder_plan_t* plan, void* prepared, size_t prepared_bytes,
+                                   psam_stream_t stream);
+size_t psam_patch_encoder_ws_bytes(int64_t rows, int64_t groups, int32_t h0, int32_t h1);
+/* feats [B*rep, N, C] (rep mask sets per cloud share xyz / centers / knn_idx); center_idx [B, G] != NULL: centralize_features; out [B*rep*G, cout] */
+int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const void* prepared, const float* xyz, const float* feats, const float* centers,
+                           const int64_t* knn_idx, const int64_t* center_idx, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
+                           float radius, float* out, void* ws, size_t ws_bytes, psam_stream_t stream);
+
+/* The mask decoder after its transformer in one call (csrc/blocks.hip; pc_sam/model/mask_decoder.py:146-176): 3-NN interpolation G -> N,
+ * output_upscaling and the hyper-network products, "f16x3", fused as the Python host runs it (the first Linear on the G patch rows before the
+ * interpolation, LayerNorm + GELU inside the interpolation kernel, the products inside the second GEMM's epilogue).  transformer_dim 256. */
+typedef struct { const float *u0_w, *u0_b, *u1_w, *u1_b, *u3_w, *u3_b; int32_t dim; float eps; } psam_upscale_weights_t;
+typedef struct { int32_t dim; float eps; const float *u0_w, *u0_b, *u1_w, *u1_b, *u3_b; int64_t o_w0, o_s0, o_w3, o_s3; } psam_upscale_plan_t;
+size_t psam_upscale_masks_prepared_bytes(int32_t dim);
+int32_t psam_upscale_masks_prepare(const psam_upscale_weights_t* weights, psam_upscale_plan_t* plan, void* prepared, size_t prepared_bytes, psam_stream_t stream);
+size_t psam_upscale_masks_ws_bytes(int64_t Z, int32_t N, int32_t G, int32_t C, int32_t dim);
+/* keys [Z*G, 256], idx3 / w3 [Z / rep, N, 3] (psam_three_nn), hyper [Z, C, 256] (psam_mlp3) -> masks [Z, C, N]; Z * N % 256 == 0, N % 32 == 0, C <= 4 */
+int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void* prepared, const float* keys, const int64_t* idx3, const float* w3, const float* hyper,
+                           int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C, float* masks, void* ws, size_t ws_bytes, psam_stream_t stream);
+
 /* Token side of one TwoWayAttentionBlock in ONE launch (csrc/twoway.hip): self-attention + norm1, token -> image attention + norm2, the MLP
  * + norm3 on the Z * T <= 64 output-token rows, and the k / v projections of the image -> token attention that follows -- what
  * pc_sam/model/transformer.py:144-175 does for `queries`; mode 1: only the token -> image attention + LayerNorm of :91-99

@@ -51,6 +51,14 @@ SIGNATURES = {
     "psam_eva_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_eva_block_ws_bytes": (size_t, [i64, i32, i32]),
     "psam_eva_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
+    "psam_patch_encoder_prepared_bytes": (size_t, [i32, i32, i32]),
+    "psam_patch_encoder_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
+    "psam_patch_encoder_ws_bytes": (size_t, [i64, i64, i32, i32]),
+    "psam_patch_encoder": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, f32, ptr, ptr, size_t, ptr]),
+    "psam_upscale_masks_prepared_bytes": (size_t, [i32]),
+    "psam_upscale_masks_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
+    "psam_upscale_masks_ws_bytes": (size_t, [i64, i32, i32, i32, i32]),
+    "psam_upscale_masks": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr, ptr, size_t, ptr]),
     "psam_twoway_tokens_ws_floats": (i64, [i32]),
     "psam_twoway_tokens": (i32, [ptr, ptr]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
@@ -98,6 +106,29 @@ class EvaBlockPlan(ctypes.Structure):
     _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "hidden_pad")] + [(n, f32) for n in ("eps", "qkv_bound", "v_bound", "u_c2", "u_c1", "u_c0")] +
                 [(n, ptr) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "proj_b")] +
                 [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_b1", "o_w2g", "o_s2g", "o_lnc", "o_lnd")])
+
+
+class PatchEncoderWeights(ctypes.Structure):
+    """psam_patch_encoder_weights_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, ptr) for n in ("c10_w", "c10_b", "c11_w", "c11_b", "c13_w", "c13_b", "c20_w", "c20_b", "c21_w", "c21_b", "c23_w", "c23_b")] +
+                [(n, i32) for n in ("cin", "h0", "h1", "cout")] + [("eps", f32)])
+
+
+class PatchEncoderPlan(ctypes.Structure):
+    """psam_patch_encoder_plan_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, i32) for n in ("cin", "h0", "h1", "cout")] + [(n, f32) for n in ("eps", "k1", "k2")] +
+                [(n, ptr) for n in ("c10_w", "c10_b", "c11_w", "c11_b", "c13_b", "c20_w", "c20_b", "c21_w", "c21_b", "c23_b")] +
+                [(n, i64) for n in ("o_w13", "o_s13", "o_w20m", "o_s20m", "o_w20x", "o_s20x", "o_w23", "o_s23")])
+
+
+class UpscaleWeights(ctypes.Structure):
+    """psam_upscale_weights_t (include/pointsam_hip.h)."""
+    _fields_ = [(n, ptr) for n in ("u0_w", "u0_b", "u1_w", "u1_b", "u3_w", "u3_b")] + [("dim", i32), ("eps", f32)]
+
+
+class UpscalePlan(ctypes.Structure):
+    """psam_upscale_plan_t (include/pointsam_hip.h)."""
+    _fields_ = [("dim", i32), ("eps", f32)] + [(n, ptr) for n in ("u0_w", "u0_b", "u1_w", "u1_b", "u3_b")] + [(n, i64) for n in ("o_w0", "o_s0", "o_w3", "o_s3")]
 
 
 class TwoWayTokens(ctypes.Structure):

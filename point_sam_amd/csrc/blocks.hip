@@ -221,3 +221,178 @@ PSAM_API int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* p
     f.ln_mean = mean; f.ln_rstd = rstd; f.ln_c = P(plan->o_lnc);
     return psam_gemm_f16x3p_ex(u, Hp, su, P(plan->o_w2g), Hp, P(plan->o_s2g), x, D, P(plan->o_lnd), x, D, nullptr, 0, 0, (int32_t)M, D, Hp, 1.f, 0, &f, stream);
 }
+
+// ================================================================================================================================
+// psam_patch_encoder: PatchEncoder.forward on kNN groups (pc_sam/model/common.py:477-506 after KNNGrouper / group_with_centers_and_knn,
+// :99-120 / :126-187) -- the mini-PointNet of the patch embedding (features = rgb) and of the mask encoder (features = mask logits) -- as the
+// Python host runs it in "f16x3": gather + Linear + LayerNorm + GELU in one kernel (packed rows) | conv1.3 GEMM with the group maximum and a
+// packed output in its epilogue | the pooled half of conv2.0 once per group | conv2.0 on the rows with that as a row bias | LayerNorm + GELU
+// (packed) | conv2.3 GEMM whose epilogue keeps only the group maximum.  hidden_dims[0] == 128, group size 32 or 64, rows % 256 == 0.
+// ================================================================================================================================
+PSAM_API size_t psam_patch_encoder_prepared_bytes(int32_t h0, int32_t h1, int32_t cout) {
+    if (h0 <= 0 || h1 <= 0 || cout <= 0) return 0;
+    const int64_t a = kpad(h0), b = kpad(h1);
+    return (size_t)(align256((int64_t)h0 * a * 4) + align256(h0 * 4) + 2 * (align256((int64_t)h1 * a * 4) + align256(h1 * 4)) + align256((int64_t)cout * b * 4) + align256(cout * 4));
+}
+
+PSAM_API int32_t psam_patch_encoder_prepare(const psam_patch_encoder_weights_t* wt, psam_patch_encoder_plan_t* plan, void* prepared, size_t prepared_bytes,
+                                            hipStream_t stream) {
+    PSAM_REQUIRE(wt && plan && prepared, PSAM_EINVAL, "psam_patch_encoder_prepare: null pointer");
+    const int h0 = wt->h0, h1 = wt->h1, cout = wt->cout, cin = wt->cin;
+    PSAM_REQUIRE(h0 == 128 && h1 >= 256 && h1 % 128 == 0 && h1 <= 4096 && cout >= 128 && cout % 128 == 0 && cin >= 4, PSAM_EINVAL,
+                 "psam_patch_encoder_prepare: hidden_dims[0] must be 128, hidden_dims[1] a multiple of 128 in [256, 4096], out_channels a multiple of 128");
+    PSAM_REQUIRE(wt->c10_w && wt->c10_b && wt->c11_w && wt->c11_b && wt->c13_w && wt->c13_b && wt->c20_w && wt->c20_b && wt->c21_w && wt->c21_b && wt->c23_w && wt->c23_b,
+                 PSAM_EINVAL, "psam_patch_encoder_prepare: null weight pointer");
+    PSAM_REQUIRE(prepared_bytes >= psam_patch_encoder_prepared_bytes(h0, h1, cout), PSAM_EWORKSPACE, "psam_patch_encoder_prepare: prepared buffer too small");
+    std::vector<float> w13((size_t)h0 * h0), b13(h0);
+    PSAM_REQUIRE(hipMemcpy(w13.data(), wt->c13_w, w13.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(b13.data(), wt->c13_b, b13.size() * 4, hipMemcpyDeviceToHost) == hipSuccess,
+                 PSAM_EINVAL, "psam_patch_encoder_prepare: cannot read conv1.3");
+    double nmax = 0.0, bmax = 0.0;
+    for (int n = 0; n < h0; ++n) { nmax = std::fmax(nmax, row_norm(&w13[(size_t)n * h0], h0)); bmax = std::fmax(bmax, std::fabs((double)b13[n])); }
+    std::memset(plan, 0, sizeof(*plan));
+    plan->cin = cin; plan->h0 = h0; plan->h1 = h1; plan->cout = cout; plan->eps = wt->eps;
+    plan->k1 = (float)(32768.0 * std::sqrt((double)h0) * nmax);      // |conv1.3 row| <= k1 / scale(input row) + k2 (psam_gemm_fuse_t)
+    plan->k2 = (float)bmax;
+    plan->c10_w = wt->c10_w; plan->c10_b = wt->c10_b; plan->c11_w = wt->c11_w; plan->c11_b = wt->c11_b; plan->c13_b = wt->c13_b; plan->c20_w = wt->c20_w;
+    plan->c20_b = wt->c20_b; plan->c21_w = wt->c21_w; plan->c21_b = wt->c21_b; plan->c23_b = wt->c23_b;
+    Carve cv(prepared);
+    const int a = kpad(h0), b = kpad(h1);
+    float* p13 = cv.take<float>((int64_t)h0 * a); float* s13 = cv.take<float>(h0);
+    float* p20m = cv.take<float>((int64_t)h1 * a); float* s20m = cv.take<float>(h1);
+    float* p20x = cv.take<float>((int64_t)h1 * a); float* s20x = cv.take<float>(h1);
+    float* p23 = cv.take<float>((int64_t)cout * b); float* s23 = cv.take<float>(cout);
+    plan->o_w13 = (char*)p13 - cv.base; plan->o_s13 = (char*)s13 - cv.base; plan->o_w20m = (char*)p20m - cv.base; plan->o_s20m = (char*)s20m - cv.base;
+    plan->o_w20x = (char*)p20x - cv.base; plan->o_s20x = (char*)s20x - cv.base; plan->o_w23 = (char*)p23 - cv.base; plan->o_s23 = (char*)s23 - cv.base;
+    int32_t rc = psam_row_scale_f16(wt->c13_w, h0, h0, h0, s13, stream);
+    if (!rc) rc = psam_pack_rows_f16x2_g8(wt->c13_w, h0, s13, h0, h0, p13, a, stream);
+    // conv2.0 [h1, 2 h0] = [pooled half | per-row half]: cat([max, x]) W^T = max W[:, :h0]^T + x W[:, h0:]^T, each half packed with its own row scales
+    if (!rc) rc = psam_row_scale_f16(wt->c20_w, 2 * h0, h1, h0, s20m, stream);
+    if (!rc) rc = psam_pack_rows_f16x2_g8(wt->c20_w, 2 * h0, s20m, h1, h0, p20m, a, stream);
+    if (!rc) rc = psam_row_scale_f16(wt->c20_w + h0, 2 * h0, h1, h0, s20x, stream);
+    if (!rc) rc = psam_pack_rows_f16x2_g8(wt->c20_w + h0, 2 * h0, s20x, h1, h0, p20x, a, stream);
+    if (!rc) rc = psam_row_scale_f16(wt->c23_w, h1, cout, h1, s23, stream);
+    if (!rc) rc = psam_pack_rows_f16x2_g8(wt->c23_w, h1, s23, cout, h1, p23, b, stream);
+    if (!rc && hipStreamSynchronize(stream) != hipSuccess) { psam_set_error("psam_patch_encoder_prepare: packing failed"); rc = PSAM_EINVAL; }
+    return rc;
+}
+
+PSAM_API size_t psam_patch_encoder_ws_bytes(int64_t rows, int64_t groups, int32_t h0, int32_t h1) {
+    if (rows <= 0 || groups <= 0 || h0 <= 0 || h1 <= 0) return 0;
+    const int64_t a = kpad(h0), b = kpad(h1);
+    return (size_t)(2 * align256(rows * a * 4) + 3 * align256(rows * 4) + 2 * align256(groups * a * 4) + align256(groups * 4) + align256(groups * h1 * 4) + align256(rows * b * 4));
+}
+
+// out [B*rep*G, cout] = max over the K group members of conv2(cat(max conv1(x), conv1(x))), x = [rel. xyz (/ radius) | feats (| feats - centre feats)]
+PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const void* prepared, const float* xyz, const float* feats, const float* centers,
+                                    const int64_t* knn_idx, const int64_t* center_idx, int32_t B, int32_t rep, int32_t N, int32_t G, int32_t K, int32_t C,
+                                    float radius, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(plan && prepared && xyz && feats && centers && knn_idx && out && ws, PSAM_EINVAL, "psam_patch_encoder: null pointer");
+    const int h0 = plan->h0, h1 = plan->h1, cout = plan->cout, a = kpad(h0), b = kpad(h1);
+    const int64_t groups = (int64_t)B * rep * G, rows = groups * K;
+    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && (K == 32 || K == 64) && rows % 256 == 0 && rows < ((int64_t)1 << 31), PSAM_EINVAL,
+                 "psam_patch_encoder: group size must be 32 or 64 and B * rep * G * K a multiple of 256");
+    PSAM_REQUIRE(plan->cin == 3 + C * (center_idx ? 2 : 1), PSAM_EINVAL, "psam_patch_encoder: feature channels do not match the first Linear");
+    PSAM_REQUIRE(ws_bytes >= psam_patch_encoder_ws_bytes(rows, groups, h0, h1), PSAM_EWORKSPACE, "psam_patch_encoder: workspace too small");
+    const char* pb = static_cast<const char*>(prepared);
+    auto P = [&](int64_t off) { return reinterpret_cast<const float*>(pb + off); };
+    Carve cv(ws);
+    float* x1 = cv.take<float>(rows * a); float* x2 = cv.take<float>(rows * a);
+    float* s1 = cv.take<float>(rows); float* s2 = cv.take<float>(rows); float* rs = cv.take<float>(rows);
+    float* y1 = cv.take<float>(groups * a); float* y1p = cv.take<float>(groups * a); float* sy = cv.take<float>(groups);
+    float* g1 = cv.take<float>(groups * h1);
+    float* x3 = cv.take<float>(rows * b);
+    int32_t rc = psam_patch_l1_ex(xyz, feats, centers, knn_idx, center_idx, plan->c10_w, plan->c10_b, plan->c11_w, plan->c11_b, plan->eps, B, rep, N, G, K, C, radius, x1, s1, stream);
+    if (rc) return rc;
+    psam_gemm_fuse_t f;
+    std::memset(&f, 0, sizeof(f));
+    f.pack_out = 1; f.out_scale = s2; f.out_k1 = plan->k1; f.out_k2 = plan->k2; f.gmax_out = y1; f.gmax_ld = h0; f.gmax_k = K;
+    rc = psam_gemm_f16x3p_ex(x1, a, s1, P(plan->o_w13), a, P(plan->o_s13), x2, a, plan->c13_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, h0, a, 1.f, 0, &f, stream);
+    if (rc) return rc;
+    if (groups >= 256) {      // the pooled half of conv2.0, one row per group
+        rc = psam_scale_pack_rows_g8(y1, h0, (int32_t)groups, h0, y1p, a, sy, stream);
+        if (!rc) rc = psam_gemm_f16x3p_ex(y1p, a, sy, P(plan->o_w20m), a, P(plan->o_s20m), g1, h1, plan->c20_b, nullptr, 0, nullptr, 0, 0, (int32_t)groups, h1, a, 1.f, 0, nullptr, stream);
+    } else {
+        rc = psam_linear(y1, h0, plan->c20_w, 2 * h0, plan->c20_b, nullptr, 0, g1, h1, (int32_t)groups, h1, h0, 0, stream);
+    }
+    if (rc) return rc;
+    rc = psam_gemm_f16x3p_ex(x2, a, s2, P(plan->o_w20x), a, P(plan->o_s20x), x3, h1, nullptr, nullptr, 0, g1, h1, K, (int32_t)rows, h1, a, 1.f, 0, nullptr, stream);
+    if (rc) return rc;
+    rc = psam_layernorm_ex(x3, h1, nullptr, 0, plan->c21_w, plan->c21_b, x3, b, rows, h1, plan->eps, PSAM_ACT_GELU, rs, 1, stream);
+    if (rc) return rc;
+    std::memset(&f, 0, sizeof(f));
+    f.gmax_out = out; f.gmax_ld = cout; f.gmax_k = K; f.no_store = 1;
+    return psam_gemm_f16x3p_ex(x3, b, rs, P(plan->o_w23), b, P(plan->o_s23), out, cout, plan->c23_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, cout, b, 1.f, 0, &f, stream);
+}
+
+// ================================================================================================================================
+// psam_upscale_masks: the mask decoder after its transformer (pc_sam/model/mask_decoder.py:146-176) -- 3-NN interpolation G -> N, output_upscaling
+// (Linear, LayerNorm, GELU, Linear, GELU) and the hyper-network products -- as the Python host runs it in "f16x3": the first Linear on the G
+// patch rows BEFORE the interpolation (an affine combination commutes with it), LayerNorm + GELU inside the interpolation kernel (packed rows),
+// the second Linear + GELU as one GEMM whose epilogue takes the C products per row; the [N, 256] activations are never written.
+// transformer_dim 256, Z * N % 256 == 0, N % 32 == 0, C <= 4.
+// ================================================================================================================================
+PSAM_API size_t psam_upscale_masks_prepared_bytes(int32_t dim) {
+    if (dim <= 0) return 0;
+    const int64_t a = kpad(dim);
+    return (size_t)(2 * (align256((int64_t)dim * a * 4) + align256(dim * 4)));
+}
+
+PSAM_API int32_t psam_upscale_masks_prepare(const psam_upscale_weights_t* wt, psam_upscale_plan_t* plan, void* prepared, size_t prepared_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(wt && plan && prepared && wt->u0_w && wt->u0_b && wt->u1_w && wt->u1_b && wt->u3_w && wt->u3_b, PSAM_EINVAL, "psam_upscale_masks_prepare: null pointer");
+    PSAM_REQUIRE(wt->dim == 256, PSAM_EINVAL, "psam_upscale_masks_prepare: transformer_dim must be 256");
+    PSAM_REQUIRE(prepared_bytes >= psam_upscale_masks_prepared_bytes(wt->dim), PSAM_EWORKSPACE, "psam_upscale_masks_prepare: prepared buffer too small");
+    const int E = wt->dim, a = kpad(E);
+    std::memset(plan, 0, sizeof(*plan));
+    plan->dim = E; plan->eps = wt->eps; plan->u0_w = wt->u0_w; plan->u0_b = wt->u0_b; plan->u1_w = wt->u1_w; plan->u1_b = wt->u1_b; plan->u3_b = wt->u3_b;
+    Carve cv(prepared);
+    float* p0 = cv.take<float>((int64_t)E * a); float* s0 = cv.take<float>(E); float* p3 = cv.take<float>((int64_t)E * a); float* s3 = cv.take<float>(E);
+    plan->o_w0 = (char*)p0 - cv.base; plan->o_s0 = (char*)s0 - cv.base; plan->o_w3 = (char*)p3 - cv.base; plan->o_s3 = (char*)s3 - cv.base;
+    int32_t rc = psam_row_scale_f16(wt->u0_w, E, E, E, s0, stream);
+    if (!rc) rc = psam_pack_rows_f16x2_g8(wt->u0_w, E, s0, E, E, p0, a, stream);
+    if (!rc) rc = psam_row_scale_f16(wt->u3_w, E, E, E, s3, stream);
+    if (!rc) rc = psam_pack_rows_f16x2_g8(wt->u3_w, E, s3, E, E, p3, a, stream);
+    if (!rc && hipStreamSynchronize(stream) != hipSuccess) { psam_set_error("psam_upscale_masks_prepare: packing failed"); rc = PSAM_EINVAL; }
+    return rc;
+}
+
+PSAM_API size_t psam_upscale_masks_ws_bytes(int64_t Z, int32_t N, int32_t G, int32_t C, int32_t dim) {
+    if (Z <= 0 || N <= 0 || G <= 0 || C <= 0 || dim <= 0) return 0;
+    const int64_t a = kpad(dim), planes = psam_gemm_f16x3p_hyper_planes(dim, 0);
+    return (size_t)(2 * align256(Z * G * a * 4) + align256(Z * G * 4) + align256(Z * N * a * 4) + align256(Z * N * 4) + align256(planes * Z * C * N * 4));
+}
+
+// keys [Z*G, 256]: the patch tokens after the transformer; idx3 / w3 [Z / rep, N, 3]: compute_interp_weights (psam_three_nn); hyper [Z, C, 256]: the
+// hyper-network outputs of the selected mask tokens (psam_mlp3); masks [Z, C, N] out.
+PSAM_API int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void* prepared, const float* keys, const int64_t* idx3, const float* w3,
+                                    const float* hyper, int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C, float* masks, void* ws, size_t ws_bytes,
+                                    hipStream_t stream) {
+    PSAM_REQUIRE(plan && prepared && keys && idx3 && w3 && hyper && masks && ws, PSAM_EINVAL, "psam_upscale_masks: null pointer");
+    const int E = plan->dim, a = kpad(E);
+    PSAM_REQUIRE(rep > 0 && Z > 0 && Z % rep == 0 && N > 0 && G > 0 && C > 0 && C <= 4 && (Z * N) % 256 == 0 && N % 32 == 0 && Z * N < ((int64_t)1 << 31), PSAM_EINVAL,
+                 "psam_upscale_masks: need Z * N % 256 == 0, N % 32 == 0, C <= 4");
+    PSAM_REQUIRE(ws_bytes >= psam_upscale_masks_ws_bytes(Z, N, G, C, E), PSAM_EWORKSPACE, "psam_upscale_masks: workspace too small");
+    const char* pb = static_cast<const char*>(prepared);
+    auto P = [&](int64_t off) { return reinterpret_cast<const float*>(pb + off); };
+    const int planes = psam_gemm_f16x3p_hyper_planes(E, 0);
+    const int64_t count = Z * C * N;
+    Carve cv(ws);
+    float* kp = cv.take<float>(Z * G * a); float* k1 = cv.take<float>(Z * G * a); float* sk = cv.take<float>(Z * G);
+    float* up = cv.take<float>(Z * N * a); float* s1 = cv.take<float>(Z * N);
+    float* parts = cv.take<float>(planes * count);
+    int32_t rc;
+    if (Z * G >= 256) {
+        rc = psam_scale_pack_rows_g8(keys, E, (int32_t)(Z * G), E, kp, a, sk, stream);
+        if (!rc) rc = psam_gemm_f16x3p_ex(kp, a, sk, P(plan->o_w0), a, P(plan->o_s0), k1, E, plan->u0_b, nullptr, 0, nullptr, 0, 0, (int32_t)(Z * G), E, a, 1.f, 0, nullptr, stream);
+    } else {
+        rc = psam_linear(keys, E, plan->u0_w, E, plan->u0_b, nullptr, 0, k1, E, (int32_t)(Z * G), E, E, 0, stream);
+    }
+    if (rc) return rc;
+    rc = psam_interp3_ex(k1, idx3, w3, up, rep, Z, N, G, E, s1, plan->u1_w, plan->u1_b, plan->eps, PSAM_ACT_GELU, stream);
+    if (rc) return rc;
+    psam_gemm_fuse_t f;
+    std::memset(&f, 0, sizeof(f));
+    f.hyper = hyper; f.masks = planes > 1 ? parts : masks; f.hyper_c = C; f.hyper_rows = N; f.hyper_pstride = count; f.no_store = 1;
+    rc = psam_gemm_f16x3p_ex(up, a, s1, P(plan->o_w3), a, P(plan->o_s3), masks, E, plan->u3_b, nullptr, 0, nullptr, 0, 0, (int32_t)(Z * N), E, a, 1.f, PSAM_ACT_GELU, &f, stream);
+    if (rc || planes <= 1) return rc;
+    return psam_sum_planes(parts, planes, count, count, masks, stream);
+}

@@ -210,6 +210,13 @@ class PointCloudSAM:
                 pw = w[blk.p + ".attn.proj.weight"]
                 if ops.F16Weight.eligible(*pw.shape):
                     self.fw[blk.p + ".attn.proj.weight"] = ops.F16Weight(pw)
+            self.c_patch, self.c_upscale = {}, None      # coarse C-ABI entries (csrc/blocks.hip): the library's own packing + sequencing
+            for prefix in ("pc_encoder.patch_embed.patch_encoder", "mask_encoder.patch_encoder"):
+                if prefix in self.pe_bound and ops.CPatchEncoder.supported(w[prefix + ".conv1.0.weight"].shape[0], w[prefix + ".conv2.0.weight"].shape[0],
+                                                                            w[prefix + ".conv2.3.weight"].shape[0]):
+                    self.c_patch[prefix] = ops.CPatchEncoder(w, prefix, cfg.ln_eps)
+            if cfg.embed_dim == 256 and "mask_decoder.output_upscaling.0.weight" in w:
+                self.c_upscale = ops.CUpscale(w, cfg.ln_eps)
             if cfg.vit.swiglu and ops.EvaBlock.supported(D, cfg.vit.heads, cfg.vit.mlp_hidden):
                 for blk in self.blocks:     # the library's own packing of the block (psam_eva_block_prepare)
                     blk.c_block = ops.EvaBlock(w, blk.p, D, cfg.vit.heads, cfg.vit.mlp_hidden, cfg.vit.ln_eps)
@@ -240,6 +247,8 @@ class PointCloudSAM:
         w2a = w[prefix + ".conv2.0.weight"]
         fused = (self.precision == "f16x3" and self.fuse_patch and K in (32, 64) and ops.fuse_supported(rows, 128) and prefix in self.pe_bound
                  and all((prefix + n) in self.fw for n in (".conv1.3.weight", ".conv2.0.weight#x", ".conv2.3.weight")))
+        if fused and self.c_blocks and prefix in getattr(self, "c_patch", {}) and ops.GEMM_MODE == "f16x3":
+            return self.c_patch[prefix].run(coords, feats, centers, knn_idx, radius=radius, center_idx=center_idx)      # psam_patch_encoder: the same six launches
         if fused:
             # every hand-over stays in the GEMMs' packed form and both max-pools happen in GEMM epilogues: the [rows, 128] / [rows, 512]
             # activations are written once (packed) or not at all (conv2.3 only leaves its pooled [groups, Cout] rows)
@@ -496,6 +505,10 @@ class PointCloudSAM:
         up = torch.empty(Z * N, E, device=self.device)
         U0, U3 = "mask_decoder.output_upscaling.0", "mask_decoder.output_upscaling.3"
         packed_interp = self.precision == "f16x3" and self.fuse_upscale and E == 256 and Z * N >= ops.SPLIT_MIN_M and (U0 + ".weight") in self.fw
+        if (self.upscale_linear_first and E == 256 and self.c_blocks and getattr(self, "c_upscale", None) is not None and packed_interp and self.fuse_hyper
+                and (U3 + ".weight") in self.fw and (Z * N) % 256 == 0 and N % 32 == 0 and C <= 4 and ops.GEMM_MODE == "f16x3" and keys.is_contiguous()):
+            self.c_upscale.run(keys.view(Z * G, E), st.interp_index, st.interp_weight, hyper, masks, rep, Z, N, G, C)      # psam_upscale_masks: the same launches
+            return masks, sel
         if self.upscale_linear_first and E == 256:
             k1 = self._lin(U0, keys.view(Z * G, E))
             pk = packed_interp and (U3 + ".weight") in self.fw

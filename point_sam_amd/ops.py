@@ -558,6 +558,78 @@ class EvaBlock:
         return x
 
 
+class CPatchEncoder:
+    """A PatchEncoder (common.py:477-506) prepared for psam_patch_encoder (csrc/blocks.hip).  prefix: 'pc_encoder.patch_embed.patch_encoder' |
+    'mask_encoder.patch_encoder'."""
+
+    def __init__(self, w, prefix: str, eps: float):
+        import ctypes
+        L = _lib.load()
+        wt = _lib.PatchEncoderWeights()
+        self.keep = []
+        for slot, n in (("c10", "conv1.0"), ("c11", "conv1.1"), ("c13", "conv1.3"), ("c20", "conv2.0"), ("c21", "conv2.1"), ("c23", "conv2.3")):
+            for suf, part in (("_w", ".weight"), ("_b", ".bias")):
+                t = w[f"{prefix}.{n}{part}"]
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError(f"{prefix}.{n}{part}: contiguous fp32 expected")
+                self.keep.append(t)
+                setattr(wt, slot + suf, t.data_ptr())
+        c10, c20, c23 = w[prefix + ".conv1.0.weight"], w[prefix + ".conv2.0.weight"], w[prefix + ".conv2.3.weight"]
+        wt.cin, wt.h0, wt.h1, wt.cout, wt.eps = int(c10.shape[1]), int(c10.shape[0]), int(c20.shape[0]), int(c23.shape[0]), float(eps)
+        self.h0, self.h1, self.cout = wt.h0, wt.h1, wt.cout
+        self.plan = _lib.PatchEncoderPlan()
+        self.blob = torch.empty(int(L.psam_patch_encoder_prepared_bytes(wt.h0, wt.h1, wt.cout)), dtype=torch.uint8, device=c10.device)
+        check(L.psam_patch_encoder_prepare(ctypes.byref(wt), ctypes.byref(self.plan), self.blob.data_ptr(), self.blob.numel(), _stream()), "psam_patch_encoder_prepare")
+
+    @staticmethod
+    def supported(h0: int, h1: int, cout: int) -> bool:
+        return h0 == 128 and 256 <= h1 <= 4096 and h1 % 128 == 0 and cout >= 128 and cout % 128 == 0
+
+    def run(self, xyz, feats, centers, knn_idx, radius=None, center_idx=None):
+        import ctypes
+        lib = _lib.load()
+        _chk(xyz); _chk(feats); _chk(centers); _chk(knn_idx, torch.int64)
+        B, N, _ = xyz.shape
+        rep = feats.shape[0] // B
+        G, K = knn_idx.shape[1:]
+        groups = B * rep * G
+        out = torch.empty(groups, self.cout, dtype=torch.float32, device=xyz.device)
+        ws = torch.empty(int(lib.psam_patch_encoder_ws_bytes(groups * K, groups, self.h0, self.h1)), dtype=torch.uint8, device=xyz.device)
+        check(lib.psam_patch_encoder(ctypes.byref(self.plan), self.blob.data_ptr(), xyz.data_ptr(), feats.data_ptr(), centers.data_ptr(), knn_idx.data_ptr(),
+                                     _p(center_idx), B, rep, N, G, K, feats.shape[-1], float(radius or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+              "psam_patch_encoder")
+        return out
+
+
+class CUpscale:
+    """The mask decoder's upscaling + hyper-network products prepared for psam_upscale_masks (csrc/blocks.hip; mask_decoder.py:146-176)."""
+
+    def __init__(self, w, eps: float):
+        import ctypes
+        L = _lib.load()
+        wt = _lib.UpscaleWeights()
+        self.keep = []
+        for slot, n in (("u0", "0"), ("u1", "1"), ("u3", "3")):
+            for suf, part in (("_w", ".weight"), ("_b", ".bias")):
+                t = w[f"mask_decoder.output_upscaling.{n}{part}"]
+                self.keep.append(t)
+                setattr(wt, slot + suf, t.data_ptr())
+        wt.dim, wt.eps = int(w["mask_decoder.output_upscaling.0.weight"].shape[0]), float(eps)
+        self.dim = wt.dim
+        self.plan = _lib.UpscalePlan()
+        self.blob = torch.empty(int(L.psam_upscale_masks_prepared_bytes(wt.dim)), dtype=torch.uint8, device=self.keep[0].device)
+        check(L.psam_upscale_masks_prepare(ctypes.byref(wt), ctypes.byref(self.plan), self.blob.data_ptr(), self.blob.numel(), _stream()), "psam_upscale_masks_prepare")
+
+    def run(self, keys, idx3, w3, hyper, masks, rep, Z, N, G, C):
+        import ctypes
+        lib = _lib.load()
+        _chk(keys); _chk(idx3, torch.int64); _chk(w3); _chk(hyper); _chk(masks)
+        ws = torch.empty(int(lib.psam_upscale_masks_ws_bytes(Z, N, G, C, self.dim)), dtype=torch.uint8, device=keys.device)
+        check(lib.psam_upscale_masks(ctypes.byref(self.plan), self.blob.data_ptr(), keys.data_ptr(), idx3.data_ptr(), w3.data_ptr(), hyper.data_ptr(), rep, Z, N, G, C,
+                                     masks.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "psam_upscale_masks")
+        return masks
+
+
 class TwoWayLayerWeights:
     """The weight pointers of one TwoWayAttentionBlock's token side (or of the final token -> image attention: final=True) as a
     psam_twoway_tokens_t skeleton (csrc/twoway.hip); keeps the tensors alive.  w: name -> fp32 tensor; prefix: e.g.

@@ -185,12 +185,16 @@ def test_c_eva_block_matches_python_sequence(gpu):
     model = gpu(cfg, sd, precision="f16x3")
     assert all(hasattr(b, "c_block") for b in model.blocks)
     outs = {}
-    for c in (True, False):
+    assert set(model.c_patch) == {"pc_encoder.patch_embed.patch_encoder", "mask_encoder.patch_encoder"} and model.c_upscale is not None
+    for c in (True, False):      # c_blocks also switches psam_patch_encoder (patch embedding, mask encoder) and psam_upscale_masks
         model.c_blocks = c
         st = model.encode(xyz.cuda(), rgb.cuda())
-        outs[c] = (st.pc_embeddings, *model.decode(st, prompt.cuda(), labels.cuda(), None, True))
+        m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+        best = torch.gather(m1, 1, i1.argmax(1).view(-1, 1, 1).expand(-1, 1, m1.shape[2]))[:, 0]
+        outs[c] = (st.patch_embeddings, st.pc_embeddings, m1, i1, *model.decode(st, prompt.cuda(), labels.cuda(), best, False))
     errs = [_maxerr(a, b) for a, b in zip(outs[True], outs[False])]
-    print(f"\n[psam_eva_block vs Python-sequenced block, ViT-B x12] max|diff| embeddings {errs[0]:.2e} masks {errs[1]:.2e} iou {errs[2]:.2e}")
+    print(f"\n[coarse C-ABI entries vs Python-sequenced launches, ViT-B x12] max|diff| patch emb {errs[0]:.2e} embeddings {errs[1]:.2e} click1 {errs[2]:.2e} "
+          f"{errs[3]:.2e} click2 {errs[4]:.2e} {errs[5]:.2e}")
     assert max(errs) < 2e-5
     # one block alone, bitwise repeatable, workspace too small refused
     blk = model.blocks[0].c_block
