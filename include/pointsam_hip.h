@@ -303,6 +303,35 @@ size_t psam_upscale_masks_ws_bytes(int64_t Z, int32_t N, int32_t G, int32_t C, i
 int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void* prepared, const float* keys, const int64_t* idx3, const float* w3, const float* hyper,
                            int32_t rep, int64_t Z, int32_t N, int32_t G, int32_t C, float* masks, void* ws, size_t ws_bytes, psam_stream_t stream);
 
+/* TwoWayTransformer.forward in one call (csrc/blocks.hip; pc_sam/model/transformer.py:61-100 with TwoWayAttentionBlock :103-176 and Attention
+ * :179-236): the decoder's transformer over the patch tokens and the output / prompt tokens, sequenced as the Python host sequences it (per
+ * nn.Linear the kernel the host would pick by row count; psam_attention_small; LayerNorm with the residual folded in).  Weights in the
+ * reference's state-dict layout ([out, in] fp32 device pointers); _prepare packs every matrix for the rows >= 256 case. */
+#define PSAM_TWOWAY_MAX_DEPTH 4
+typedef struct { const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b; } psam_attn_weights_t;      /* q_proj, k_proj, v_proj, out_proj */
+typedef struct {
+    psam_attn_weights_t self_attn, t2i, i2t;      /* self_attn, cross_attn_token_to_image, cross_attn_image_to_token */
+    const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b, *n4_w, *n4_b, *m1_w, *m1_b, *m2_w, *m2_b;      /* norm1..4, mlp.lin1, mlp.lin2 */
+} psam_twoway_layer_weights_t;
+typedef struct {
+    int32_t depth, dim, heads, mlp, downsample;      /* 2, 256, 8, 2048, 2 in every reference config */
+    float eps;
+    const psam_twoway_layer_weights_t* layers;       /* [depth] (host array) */
+    psam_attn_weights_t final_attn;                  /* final_attn_token_to_image */
+    const float *nf_w, *nf_b;                        /* norm_final_attn */
+} psam_twoway_weights_t;
+typedef struct {
+    psam_twoway_weights_t weights;
+    psam_twoway_layer_weights_t layers[PSAM_TWOWAY_MAX_DEPTH];
+    int64_t o_packed[14 * PSAM_TWOWAY_MAX_DEPTH + 4], o_scales[14 * PSAM_TWOWAY_MAX_DEPTH + 4];
+} psam_twoway_plan_t;
+size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample);
+int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* weights, psam_twoway_plan_t* plan, void* prepared, size_t prepared_bytes, psam_stream_t stream);
+size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, int32_t dim, int32_t mlp);
+/* tokens [Z*T, dim] (= query_pe), keys [Z*G, dim] in / out (src -> the transformer's second output), pos [Z / rep, G, dim] -> queries [Z*T, dim] */
+int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void* prepared, const float* tokens, float* keys, const float* pos, int32_t rep, int64_t Z,
+                            int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, psam_stream_t stream);
+
 /* Token side of one TwoWayAttentionBlock in ONE launch (csrc/twoway.hip): self-attention + norm1, token -> image attention + norm2, the MLP
  * + norm3 on the Z * T <= 64 output-token rows, and the k / v projections of the image -> token attention that follows -- what
  * pc_sam/model/transformer.py:144-175 does for `queries`; mode 1: only the token -> image attention + LayerNorm of :91-99

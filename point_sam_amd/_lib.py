@@ -59,6 +59,10 @@ SIGNATURES = {
     "psam_upscale_masks_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_upscale_masks_ws_bytes": (size_t, [i64, i32, i32, i32, i32]),
     "psam_upscale_masks": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, i32, i64, i32, i32, i32, ptr, ptr, size_t, ptr]),
+    "psam_twoway_decoder_prepared_bytes": (size_t, [i32, i32, i32, i32]),
+    "psam_twoway_decoder_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
+    "psam_twoway_decoder_ws_bytes": (size_t, [i64, i32, i32, i32, i32]),
+    "psam_twoway_decoder": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i64, i32, i32, ptr, ptr, size_t, ptr]),
     "psam_twoway_tokens_ws_floats": (i64, [i32]),
     "psam_twoway_tokens": (i32, [ptr, ptr]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
@@ -129,6 +133,32 @@ class UpscaleWeights(ctypes.Structure):
 class UpscalePlan(ctypes.Structure):
     """psam_upscale_plan_t (include/pointsam_hip.h)."""
     _fields_ = [("dim", i32), ("eps", f32)] + [(n, ptr) for n in ("u0_w", "u0_b", "u1_w", "u1_b", "u3_b")] + [(n, i64) for n in ("o_w0", "o_s0", "o_w3", "o_s3")]
+
+
+class AttnWeights(ctypes.Structure):
+    """psam_attn_weights_t (include/pointsam_hip.h)."""
+    _fields_ = [(n, ptr) for n in ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b")]
+
+
+class TwoWayLayerW(ctypes.Structure):
+    """psam_twoway_layer_weights_t."""
+    _fields_ = [("self_attn", AttnWeights), ("t2i", AttnWeights), ("i2t", AttnWeights)] + [(n, ptr) for n in (
+        "n1_w", "n1_b", "n2_w", "n2_b", "n3_w", "n3_b", "n4_w", "n4_b", "m1_w", "m1_b", "m2_w", "m2_b")]
+
+
+TWOWAY_MAX_DEPTH = 4
+
+
+class TwoWayWeights(ctypes.Structure):
+    """psam_twoway_weights_t."""
+    _fields_ = [(n, i32) for n in ("depth", "dim", "heads", "mlp", "downsample")] + [("eps", f32), ("layers", ctypes.POINTER(TwoWayLayerW)),
+                                                                                      ("final_attn", AttnWeights), ("nf_w", ptr), ("nf_b", ptr)]
+
+
+class TwoWayPlan(ctypes.Structure):
+    """psam_twoway_plan_t."""
+    _fields_ = [("weights", TwoWayWeights), ("layers", TwoWayLayerW * TWOWAY_MAX_DEPTH), ("o_packed", i64 * (14 * TWOWAY_MAX_DEPTH + 4)),
+                ("o_scales", i64 * (14 * TWOWAY_MAX_DEPTH + 4))]
 
 
 class TwoWayTokens(ctypes.Structure):

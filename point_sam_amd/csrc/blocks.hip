@@ -396,3 +396,160 @@ PSAM_API int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void*
     if (rc || planes <= 1) return rc;
     return psam_sum_planes(parts, planes, count, count, masks, stream);
 }
+
+// ================================================================================================================================
+// psam_twoway_decoder: TwoWayTransformer.forward (pc_sam/model/transformer.py:61-100; blocks :144-176, Attention :214-236) -- the decoder's
+// transformer over the patch tokens (`keys`, Z*G rows) and the output / prompt tokens (Z*T rows) -- sequenced by the library exactly as the Python
+// host sequences it: per nn.Linear the kernel the host would pick (<= 64 rows: psam_linear_skinny; >= 256 rows and N, K >= 128: the packed-operand
+// "f16x3" GEMM on a weight packed at prepare time; otherwise psam_linear), psam_attention_small for every attention, psam_layernorm with the
+// residual folded in, psam_add_bcast for the positional additions.  (The one-launch token-side kernel psam_twoway_tokens is slower than these
+// launches, DESIGN.md 4.4, so it is not used here.)
+// ================================================================================================================================
+namespace {
+struct TwLin { const float* w; const float* b; const float* packed; const float* scales; int N, K; };
+
+int64_t tw_count_linears(int depth) { return (int64_t)depth * 14 + 4; }
+
+// y [M, N] = act(x W^T + b): the host's dispatch (point_sam_amd/ops.py linear)
+int32_t tw_lin(const TwLin& l, const float* x, int64_t M, float* y, int act, float* pack_buf, float* scale_buf, hipStream_t stream) {
+    if (M >= 256 && l.packed) {
+        const int kp = kpad(l.K);
+        int32_t rc = psam_scale_pack_rows_g8(x, l.K, (int32_t)M, l.K, pack_buf, kp, scale_buf, stream);
+        if (rc) return rc;
+        return psam_gemm_f16x3p_ex(pack_buf, kp, scale_buf, l.packed, kp, l.scales, y, l.N, l.b, nullptr, 0, nullptr, 0, 0, (int32_t)M, l.N, kp, 1.f, act, nullptr, stream);
+    }
+    if (M <= 64 && (l.K & 15) == 0) return psam_linear_skinny(x, l.K, l.w, l.K, l.b, nullptr, 0, y, l.N, (int32_t)M, l.N, l.K, act, stream);
+    return psam_linear(x, l.K, l.w, l.K, l.b, nullptr, 0, y, l.N, (int32_t)M, l.N, l.K, act, stream);
+}
+}  // namespace
+
+PSAM_API size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample) {
+    if (depth <= 0 || dim <= 0 || mlp <= 0 || downsample <= 0) return 0;
+    const int64_t E = dim, IX = dim / downsample;
+    auto one = [](int64_t n, int64_t k) { return align256(n * kpad((int)k) * 4) + align256(n * 4); };
+    const int64_t self_attn = 4 * one(E, E), cross = 3 * one(IX, E) + one(E, IX), mlpb = one(mlp, E) + one(E, mlp);
+    return (size_t)(depth * (self_attn + 2 * cross + mlpb) + cross);
+}
+
+PSAM_API int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* wt, psam_twoway_plan_t* plan, void* prepared, size_t prepared_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(wt && plan && prepared && wt->layers, PSAM_EINVAL, "psam_twoway_decoder_prepare: null pointer");
+    PSAM_REQUIRE(wt->depth > 0 && wt->depth <= PSAM_TWOWAY_MAX_DEPTH && wt->dim > 0 && wt->dim % 32 == 0 && wt->heads > 0 && wt->mlp > 0 && wt->mlp % 32 == 0 && wt->downsample > 0 &&
+                     wt->dim % wt->downsample == 0 && (wt->dim / wt->downsample) % wt->heads == 0 && wt->dim % wt->heads == 0,
+                 PSAM_EINVAL, "psam_twoway_decoder_prepare: bad dimensions");
+    PSAM_REQUIRE(prepared_bytes >= psam_twoway_decoder_prepared_bytes(wt->depth, wt->dim, wt->mlp, wt->downsample), PSAM_EWORKSPACE,
+                 "psam_twoway_decoder_prepare: prepared buffer too small");
+    std::memset(plan, 0, sizeof(*plan));
+    plan->weights = *wt;
+    for (int i = 0; i < wt->depth; ++i) plan->layers[i] = wt->layers[i];
+    plan->weights.layers = nullptr;      // the plan carries its own copy of the per-layer pointer blocks
+    const int E = wt->dim, IX = wt->dim / wt->downsample;
+    Carve cv(prepared);
+    int32_t rc = PSAM_OK;
+    int slot = 0;
+    auto pack = [&](const float* w, int n, int k) {
+        float* p = cv.take<float>((int64_t)n * kpad(k)); float* s = cv.take<float>(n);
+        plan->o_packed[slot] = (char*)p - cv.base; plan->o_scales[slot] = (char*)s - cv.base; ++slot;
+        if (rc || !w) { if (!w && !rc) { psam_set_error("psam_twoway_decoder_prepare: null weight pointer"); rc = PSAM_EINVAL; } return; }
+        rc = psam_row_scale_f16(w, k, n, k, s, stream);
+        if (!rc) rc = psam_pack_rows_f16x2_g8(w, k, s, n, k, p, kpad(k), stream);
+    };
+    auto pack_attn = [&](const psam_attn_weights_t& a, int inner) { pack(a.q_w, inner, E); pack(a.k_w, inner, E); pack(a.v_w, inner, E); pack(a.o_w, E, inner); };
+    for (int i = 0; i < wt->depth; ++i) {
+        const psam_twoway_layer_weights_t& L = wt->layers[i];
+        pack_attn(L.self_attn, E); pack_attn(L.t2i, IX); pack(L.m1_w, wt->mlp, E); pack(L.m2_w, E, wt->mlp); pack_attn(L.i2t, IX);
+    }
+    pack_attn(wt->final_attn, IX);
+    if (!rc && hipStreamSynchronize(stream) != hipSuccess) { psam_set_error("psam_twoway_decoder_prepare: packing failed"); rc = PSAM_EINVAL; }
+    return rc;
+}
+
+PSAM_API size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, int32_t dim, int32_t mlp) {
+    if (Z <= 0 || T <= 0 || G <= 0 || dim <= 0 || mlp <= 0) return 0;
+    const int64_t R = Z * T, I = Z * G, E = dim, big = R > I ? R : I, wide = mlp > E ? mlp : E;
+    return (size_t)(6 * align256(R * E * 4) + align256(R * mlp * 4) + 6 * align256(I * E * 4) + align256(big * kpad((int)wide) * 4) + align256(big * 4));
+}
+
+// tokens [Z*T, dim] (output tokens + sparse prompt embeddings = the point embedding `query_pe`), keys [Z*G, dim] (src = image embedding + dense
+// prompt; UPDATED IN PLACE to the transformer's second output), pos [Z / rep, G, dim] (image positional encoding, shared by the rep prompt sets of
+// a cloud) -> queries [Z*T, dim] (the transformer's first output)
+PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void* prepared, const float* tokens, float* keys, const float* pos, int32_t rep,
+                                     int64_t Z, int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, hipStream_t stream) {
+    PSAM_REQUIRE(plan && prepared && tokens && keys && pos && queries && ws, PSAM_EINVAL, "psam_twoway_decoder: null pointer");
+    const psam_twoway_weights_t& W = plan->weights;
+    const int E = W.dim, IX = W.dim / W.downsample, H = W.heads, mlp = W.mlp;
+    const int64_t R = Z * T, I = Z * G;
+    PSAM_REQUIRE(rep > 0 && Z > 0 && Z % rep == 0 && T > 0 && G > 0 && R < ((int64_t)1 << 31) && I < ((int64_t)1 << 31), PSAM_EINVAL, "psam_twoway_decoder: bad shape");
+    PSAM_REQUIRE(ws_bytes >= psam_twoway_decoder_ws_bytes(Z, T, G, E, mlp), PSAM_EWORKSPACE, "psam_twoway_decoder: workspace too small");
+    const char* pb = static_cast<const char*>(prepared);
+    int slot = 0;
+    auto L = [&](const float* w, const float* b, int n, int k) {
+        TwLin l{w, b, nullptr, nullptr, n, k};
+        if (n >= 128 && k >= 128) { l.packed = reinterpret_cast<const float*>(pb + plan->o_packed[slot]); l.scales = reinterpret_cast<const float*>(pb + plan->o_scales[slot]); }
+        ++slot;
+        return l;
+    };
+    Carve cv(ws);
+    float* q = cv.take<float>(R * E); float* pq = cv.take<float>(R * E); float* pk = cv.take<float>(R * E); float* pv = cv.take<float>(R * E);
+    float* ta = cv.take<float>(R * E); float* ty = cv.take<float>(R * E); float* tm = cv.take<float>(R * mlp);
+    float* k = cv.take<float>(I * E); float* ik = cv.take<float>(I * E); float* iv = cv.take<float>(I * E); float* iq = cv.take<float>(I * E);
+    float* ia = cv.take<float>(I * E); float* iy = cv.take<float>(I * E);
+    float* pack_buf = cv.take<float>((R > I ? R : I) * kpad(mlp > E ? mlp : E)); float* scale_buf = cv.take<float>(R > I ? R : I);
+    int32_t rc = PSAM_OK;
+#define TWCK(call) do { rc = (call); if (rc) return rc; } while (0)
+    // Attention.forward up to out_proj: projections + softmax(q k^T / sqrt(hd)) v
+    auto attn = [&](const TwLin& lq, const TwLin& lk, const TwLin& lv, const float* q_in, int64_t Mq, const float* k_in, const float* v_in, int64_t Mk, float* oq, float* ok,
+                    float* ov, float* out, int Lq, int Lk) -> int32_t {
+        int32_t r = tw_lin(lq, q_in, Mq, oq, 0, pack_buf, scale_buf, stream);
+        if (!r) r = tw_lin(lk, k_in, Mk, ok, 0, pack_buf, scale_buf, stream);
+        if (!r) r = tw_lin(lv, v_in, Mk, ov, 0, pack_buf, scale_buf, stream);
+        const int inner = lq.N, hd = inner / H;
+        if (!r) r = psam_attention_small(oq, inner, (int64_t)Lq * inner, ok, inner, (int64_t)Lk * inner, ov, inner, (int64_t)Lk * inner, out, inner, (int64_t)Lq * inner, Z, H, Lq,
+                                         Lk, hd, 1.0f / std::sqrt((float)hd), stream);
+        return r;
+    };
+    const float* cur = tokens;      // queries start as the tokens themselves (transformer.py:84)
+    for (int i = 0; i < W.depth; ++i) {
+        const psam_twoway_layer_weights_t& Lw = plan->layers[i];
+        const TwLin sq = L(Lw.self_attn.q_w, Lw.self_attn.q_b, E, E), sk = L(Lw.self_attn.k_w, Lw.self_attn.k_b, E, E), sv = L(Lw.self_attn.v_w, Lw.self_attn.v_b, E, E),
+                    so = L(Lw.self_attn.o_w, Lw.self_attn.o_b, E, E);
+        const TwLin cq = L(Lw.t2i.q_w, Lw.t2i.q_b, IX, E), ck = L(Lw.t2i.k_w, Lw.t2i.k_b, IX, E), cvl = L(Lw.t2i.v_w, Lw.t2i.v_b, IX, E), co = L(Lw.t2i.o_w, Lw.t2i.o_b, E, IX);
+        const TwLin m1 = L(Lw.m1_w, Lw.m1_b, mlp, E), m2 = L(Lw.m2_w, Lw.m2_b, E, mlp);
+        const TwLin jq = L(Lw.i2t.q_w, Lw.i2t.q_b, IX, E), jk = L(Lw.i2t.k_w, Lw.i2t.k_b, IX, E), jv = L(Lw.i2t.v_w, Lw.i2t.v_b, IX, E), jo = L(Lw.i2t.o_w, Lw.i2t.o_b, E, IX);
+        // self-attention of the tokens (the first layer without positional encoding and without residual: skip_first_layer_pe)
+        if (i == 0) {
+            TWCK(attn(sq, sk, sv, cur, R, cur, cur, R, pq, pk, pv, ta, T, T));
+            TWCK(tw_lin(so, ta, R, ty, 0, pack_buf, scale_buf, stream));
+            TWCK(psam_layernorm(ty, E, nullptr, 0, Lw.n1_w, Lw.n1_b, queries, E, R, E, W.eps, 0, stream));
+        } else {
+            TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+            TWCK(attn(sq, sk, sv, q, R, q, queries, R, pq, pk, pv, ta, T, T));
+            TWCK(tw_lin(so, ta, R, ty, 0, pack_buf, scale_buf, stream));
+            TWCK(psam_layernorm(ty, E, queries, E, Lw.n1_w, Lw.n1_b, queries, E, R, E, W.eps, 0, stream));
+        }
+        cur = queries;
+        // tokens attend to the patch tokens
+        TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+        TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
+        TWCK(attn(cq, ck, cvl, q, R, k, keys, I, pq, ik, iv, ta, T, G));
+        TWCK(tw_lin(co, ta, R, ty, 0, pack_buf, scale_buf, stream));
+        TWCK(psam_layernorm(ty, E, queries, E, Lw.n2_w, Lw.n2_b, queries, E, R, E, W.eps, 0, stream));
+        // token MLP
+        TWCK(tw_lin(m1, queries, R, tm, PSAM_ACT_RELU, pack_buf, scale_buf, stream));
+        TWCK(tw_lin(m2, tm, R, ty, 0, pack_buf, scale_buf, stream));
+        TWCK(psam_layernorm(ty, E, queries, E, Lw.n3_w, Lw.n3_b, queries, E, R, E, W.eps, 0, stream));
+        // patch tokens attend to the tokens
+        TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+        TWCK(attn(jq, jk, jv, k, I, q, queries, R, iq, pk, pv, ia, G, T));
+        TWCK(tw_lin(jo, ia, I, iy, 0, pack_buf, scale_buf, stream));
+        TWCK(psam_layernorm(iy, E, keys, E, Lw.n4_w, Lw.n4_b, keys, E, I, E, W.eps, 0, stream));
+    }
+    const TwLin fq = L(W.final_attn.q_w, W.final_attn.q_b, IX, E), fk = L(W.final_attn.k_w, W.final_attn.k_b, IX, E), fv = L(W.final_attn.v_w, W.final_attn.v_b, IX, E),
+                fo = L(W.final_attn.o_w, W.final_attn.o_b, E, IX);
+    TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+    TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
+    TWCK(attn(fq, fk, fv, q, R, k, keys, I, pq, ik, iv, ta, T, G));
+    TWCK(tw_lin(fo, ta, R, ty, 0, pack_buf, scale_buf, stream));
+    TWCK(psam_layernorm(ty, E, queries, E, W.nf_w, W.nf_b, queries, E, R, E, W.eps, 0, stream));
+#undef TWCK
+    return PSAM_OK;
+}

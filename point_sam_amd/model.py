@@ -217,6 +217,8 @@ class PointCloudSAM:
                     self.c_patch[prefix] = ops.CPatchEncoder(w, prefix, cfg.ln_eps)
             if cfg.embed_dim == 256 and "mask_decoder.output_upscaling.0.weight" in w:
                 self.c_upscale = ops.CUpscale(w, cfg.ln_eps)
+            self.c_twoway = ops.CTwoWay(w, "mask_decoder.transformer", cfg.dec_depth, cfg.embed_dim, cfg.dec_heads, cfg.dec_mlp, cfg.dec_downsample, cfg.ln_eps) \
+                if cfg.dec_depth <= 4 and cfg.embed_dim % 32 == 0 else None
             if cfg.vit.swiglu and ops.EvaBlock.supported(D, cfg.vit.heads, cfg.vit.mlp_hidden):
                 for blk in self.blocks:     # the library's own packing of the block (psam_eva_block_prepare)
                     blk.c_block = ops.EvaBlock(w, blk.p, D, cfg.vit.heads, cfg.vit.mlp_hidden, cfg.vit.ln_eps)
@@ -451,6 +453,8 @@ class PointCloudSAM:
         """TwoWayTransformer.forward (transformer.py:61-100).  src [Z*G,E] (overwritten), pos [B,G,E], tokens [Z*T,E]."""
         cfg, E, eps = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps
         P = "mask_decoder.transformer"
+        if self.c_blocks and getattr(self, "c_twoway", None) is not None and ops.GEMM_MODE == "f16x3" and not self.fuse_tokens:
+            return self.c_twoway.run(tokens, src, pos, rep, Z, T, G)      # psam_twoway_decoder: the same launches, sequenced by the library
         if self.fuse_tokens and ops.TwoWayLayerWeights.supported(E, self.w[P + ".layers.0.cross_attn_token_to_image.q_proj.weight"].shape[0], cfg.dec_heads, Z, T, G):
             return self._two_way_fused(src, pos, tokens, Z, G, T, rep)
         queries, keys = tokens, src

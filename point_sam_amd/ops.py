@@ -630,6 +630,56 @@ class CUpscale:
         return masks
 
 
+class CTwoWay:
+    """The decoder's TwoWayTransformer prepared for psam_twoway_decoder (csrc/blocks.hip; transformer.py:61-100).  w: name -> fp32 tensor."""
+
+    def __init__(self, w, prefix: str, depth: int, dim: int, heads: int, mlp: int, downsample: int, eps: float):
+        import ctypes
+        L = _lib.load()
+        if depth > _lib.TWOWAY_MAX_DEPTH:
+            raise ValueError("psam_twoway_decoder: depth > PSAM_TWOWAY_MAX_DEPTH")
+        self.keep = []
+
+        def P(name):
+            t = w[name]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"{name}: contiguous fp32 expected")
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def attn(dst, p):
+            for slot, n in (("q", "q_proj"), ("k", "k_proj"), ("v", "v_proj"), ("o", "out_proj")):
+                setattr(dst, slot + "_w", P(f"{p}.{n}.weight")); setattr(dst, slot + "_b", P(f"{p}.{n}.bias"))
+
+        self.layers = (_lib.TwoWayLayerW * depth)()
+        for i in range(depth):
+            lp, lw = f"{prefix}.layers.{i}", self.layers[i]
+            attn(lw.self_attn, lp + ".self_attn"); attn(lw.t2i, lp + ".cross_attn_token_to_image"); attn(lw.i2t, lp + ".cross_attn_image_to_token")
+            for j in (1, 2, 3, 4):
+                setattr(lw, f"n{j}_w", P(f"{lp}.norm{j}.weight")); setattr(lw, f"n{j}_b", P(f"{lp}.norm{j}.bias"))
+            lw.m1_w, lw.m1_b, lw.m2_w, lw.m2_b = P(lp + ".mlp.lin1.weight"), P(lp + ".mlp.lin1.bias"), P(lp + ".mlp.lin2.weight"), P(lp + ".mlp.lin2.bias")
+        wt = _lib.TwoWayWeights()
+        wt.depth, wt.dim, wt.heads, wt.mlp, wt.downsample, wt.eps = depth, dim, heads, mlp, downsample, float(eps)
+        wt.layers = ctypes.cast(self.layers, ctypes.POINTER(_lib.TwoWayLayerW))
+        attn(wt.final_attn, prefix + ".final_attn_token_to_image")
+        wt.nf_w, wt.nf_b = P(prefix + ".norm_final_attn.weight"), P(prefix + ".norm_final_attn.bias")
+        self.dim, self.mlp = dim, mlp
+        self.plan = _lib.TwoWayPlan()
+        self.blob = torch.empty(int(L.psam_twoway_decoder_prepared_bytes(depth, dim, mlp, downsample)), dtype=torch.uint8, device=self.keep[0].device)
+        check(L.psam_twoway_decoder_prepare(ctypes.byref(wt), ctypes.byref(self.plan), self.blob.data_ptr(), self.blob.numel(), _stream()), "psam_twoway_decoder_prepare")
+
+    def run(self, tokens, keys, pos, rep, Z, T, G):
+        """tokens [Z*T, E], keys [Z*G, E] (updated in place), pos [Z/rep, G, E] -> queries [Z*T, E]."""
+        import ctypes
+        lib = _lib.load()
+        _chk(tokens); _chk(keys); _chk(pos)
+        queries = torch.empty(Z * T, self.dim, dtype=torch.float32, device=tokens.device)
+        ws = torch.empty(int(lib.psam_twoway_decoder_ws_bytes(Z, T, G, self.dim, self.mlp)), dtype=torch.uint8, device=tokens.device)
+        check(lib.psam_twoway_decoder(ctypes.byref(self.plan), self.blob.data_ptr(), tokens.data_ptr(), keys.data_ptr(), pos.data_ptr(), rep, Z, T, G, queries.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _stream()), "psam_twoway_decoder")
+        return queries, keys
+
+
 class TwoWayLayerWeights:
     """The weight pointers of one TwoWayAttentionBlock's token side (or of the final token -> image attention: final=True) as a
     psam_twoway_tokens_t skeleton (csrc/twoway.hip); keeps the tensors alive.  w: name -> fp32 tensor; prefix: e.g.
