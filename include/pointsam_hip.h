@@ -133,7 +133,7 @@ int32_t psam_row_scale_f16(const float* X, int64_t ldx, int32_t rows, int32_t co
  * consecutive k: [hi k0..k7 (8 x fp16) | lo k0..k7] in the same 32-bit-per-element container -- so that one 16-byte chunk is one
  * matrix-instruction operand and a K slab moves global -> LDS by LDS-DMA with no staging registers or arithmetic.  K % 32 == 0 (pack
  * pads with zeros up to the next multiple of 32: ldp >= that), K >= 128, packed rows 32-byte aligned.  Replaces the same reference
- * call sites as psam_gemm_f32 (every nn.Linear of pc_sam/model/*.py and of the timm Eva blocks). */
+ * call sites as psam_gemm_f32 (every nn.Linear of pc_sam/model/ *.py and of the timm Eva blocks). */
 int32_t psam_pack_rows_f16x2_g8(const float* X, int64_t ldx, const float* scale, int32_t rows, int32_t K, void* P, int64_t ldp, psam_stream_t stream);
 int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const void* W, int64_t ldw, const float* scaleW, float* C, int64_t ldc,
                          const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,
