@@ -637,14 +637,13 @@ class PointCloudSAM:
         if pred_logits is None:  # from_error_region=True: mask = fn | fp = gt
             idx = pi
         else:
+            # per mask: the false-negative candidate if it lies deeper inside its region than the false-positive one, else the false-positive
+            # one, else (no error region at all: distance -1) a point of the ground truth (common.py:424-437) -- selected on the device, so the
+            # only host synchronisation of an iteration is the emptiness check below
             ni, nd = ops.border_farthest(coords, fp)
-            pd_h, nd_h = pd.cpu(), nd.cpu()  # the reference branches on these per mask too (common.py:424-437)
-            take_p = pd_h > nd_h
-            none = (~take_p) & (nd_h == -1)
-            idx = torch.where(take_p.to(self.device), pi, ni)
-            if bool(none.any()):
-                gi, _ = ops.border_farthest(coords, gt)
-                idx = torch.where(none.to(self.device), gi, idx)
+            gi, _ = ops.border_farthest(coords, gt)
+            take_p = pd > nd
+            idx = torch.where(take_p, pi, torch.where(nd == -1, gi, ni))
         if bool((idx < 0).any()):
             raise ValueError("empty ground-truth / error region: no click can be sampled (the reference fails in torch.stack, common.py:439)")
         return self._gather_clicks(coords, gt, idx, M)
