@@ -269,7 +269,8 @@ int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* prepared, 
 
 /* PatchEncoder.forward on kNN groups in one call (csrc/blocks.hip): the mini-PointNet of the patch embedding (features = rgb) and of the mask
  * encoder (features = mask logits) -- pc_sam/model/common.py:477-506 after the gather of :99-120 / :126-187 -- "f16x3", fused as the Python host
- * runs it (six launches; both max-pools inside GEMM epilogues).  hidden_dims[0] == 128, group size 32 or 64, B * rep * G * K % 256 == 0.
+ * runs it (six launches; both max-pools inside GEMM epilogues -- for group sizes above 64 as 64-row parts + psam_group_max over the parts).
+ * hidden_dims[0] == 128, group size 32 or a multiple of 64, B * rep * G * K % 256 == 0.
  * Weights: the reference's conv1.{0,1,3} / conv2.{0,1,3} tensors ([out, in] fp32 device pointers); the plan keeps pointers to the small ones. */
 typedef struct {
     const float *c10_w, *c10_b, *c11_w, *c11_b, *c13_w, *c13_b, *c20_w, *c20_b, *c21_w, *c21_b, *c23_w, *c23_b;

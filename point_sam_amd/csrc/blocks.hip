@@ -227,7 +227,8 @@ PSAM_API int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* p
 // :99-120 / :126-187) -- the mini-PointNet of the patch embedding (features = rgb) and of the mask encoder (features = mask logits) -- as the
 // Python host runs it in "f16x3": gather + Linear + LayerNorm + GELU in one kernel (packed rows) | conv1.3 GEMM with the group maximum and a
 // packed output in its epilogue | the pooled half of conv2.0 once per group | conv2.0 on the rows with that as a row bias | LayerNorm + GELU
-// (packed) | conv2.3 GEMM whose epilogue keeps only the group maximum.  hidden_dims[0] == 128, group size 32 or 64, rows % 256 == 0.
+// (packed) | conv2.3 GEMM whose epilogue keeps only the group maximum.  hidden_dims[0] == 128, group size 32 or a multiple of 64
+// (above 64: the epilogues pool 64-row parts, psam_group_max pools the parts), rows % 256 == 0.
 // ================================================================================================================================
 PSAM_API size_t psam_patch_encoder_prepared_bytes(int32_t h0, int32_t h1, int32_t cout) {
     if (h0 <= 0 || h1 <= 0 || cout <= 0) return 0;
@@ -289,8 +290,9 @@ PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const
     PSAM_REQUIRE(plan && prepared && xyz && feats && centers && knn_idx && out && ws, PSAM_EINVAL, "psam_patch_encoder: null pointer");
     const int h0 = plan->h0, h1 = plan->h1, cout = plan->cout, a = kpad(h0), b = kpad(h1);
     const int64_t groups = (int64_t)B * rep * G, rows = groups * K;
-    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && (K == 32 || K == 64) && rows % 256 == 0 && rows < ((int64_t)1 << 31), PSAM_EINVAL,
-                 "psam_patch_encoder: group size must be 32 or 64 and B * rep * G * K a multiple of 256");
+    PSAM_REQUIRE(B > 0 && rep > 0 && N > 0 && G > 0 && (K == 32 || (K > 0 && K % 64 == 0)) && rows % 256 == 0 && rows < ((int64_t)1 << 31), PSAM_EINVAL,
+                 "psam_patch_encoder: group size must be 32 or a multiple of 64, and B * rep * G * K a multiple of 256");
+    const int Kp = K <= 64 ? K : 64, parts = K / Kp;      // the GEMM epilogues pool 64-row parts of a larger group; psam_group_max pools the parts
     PSAM_REQUIRE(plan->cin == 3 + C * (center_idx ? 2 : 1), PSAM_EINVAL, "psam_patch_encoder: feature channels do not match the first Linear");
     PSAM_REQUIRE(ws_bytes >= psam_patch_encoder_ws_bytes(rows, groups, h0, h1), PSAM_EWORKSPACE, "psam_patch_encoder: workspace too small");
     const char* pb = static_cast<const char*>(prepared);
@@ -301,16 +303,23 @@ PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const
     float* y1 = cv.take<float>(groups * a); float* y1p = cv.take<float>(groups * a); float* sy = cv.take<float>(groups);
     float* g1 = cv.take<float>(groups * h1);
     float* x3 = cv.take<float>(rows * b);
+    float* part1 = parts > 1 ? x3 : y1;                     // [groups * parts, h0] partial maxima of conv1.3 (x3 is free until conv2.0 writes it)
+    float* part2 = parts > 1 ? x1 : out;                    // [groups * parts, cout] partial maxima of conv2.3 (x1 is free after conv1.3)
+    PSAM_REQUIRE(parts == 1 || ((int64_t)groups * parts * h0 <= rows * b && (int64_t)groups * parts * cout <= rows * a), PSAM_EINVAL,
+                 "psam_patch_encoder: partial maxima do not fit the workspace");
     int32_t rc = psam_patch_l1_ex(xyz, feats, centers, knn_idx, center_idx, plan->c10_w, plan->c10_b, plan->c11_w, plan->c11_b, plan->eps, B, rep, N, G, K, C, radius, x1, s1, stream);
     if (rc) return rc;
     psam_gemm_fuse_t f;
     std::memset(&f, 0, sizeof(f));
-    f.pack_out = 1; f.out_scale = s2; f.out_k1 = plan->k1; f.out_k2 = plan->k2; f.gmax_out = y1; f.gmax_ld = h0; f.gmax_k = K;
+    f.pack_out = 1; f.out_scale = s2; f.out_k1 = plan->k1; f.out_k2 = plan->k2; f.gmax_out = part1; f.gmax_ld = h0; f.gmax_k = Kp;
     rc = psam_gemm_f16x3p_ex(x1, a, s1, P(plan->o_w13), a, P(plan->o_s13), x2, a, plan->c13_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, h0, a, 1.f, 0, &f, stream);
     if (rc) return rc;
+    if (parts > 1) { rc = psam_group_max(part1, h0, y1, h0, groups, parts, h0, stream); if (rc) return rc; }
     if (groups >= 256) {      // the pooled half of conv2.0, one row per group
         rc = psam_scale_pack_rows_g8(y1, h0, (int32_t)groups, h0, y1p, a, sy, stream);
         if (!rc) rc = psam_gemm_f16x3p_ex(y1p, a, sy, P(plan->o_w20m), a, P(plan->o_s20m), g1, h1, plan->c20_b, nullptr, 0, nullptr, 0, 0, (int32_t)groups, h1, a, 1.f, 0, nullptr, stream);
+    } else if (groups <= 64) {      // the host's dispatch (point_sam_amd/ops.py linear): a handful of rows -> the skinny kernel
+        rc = psam_linear_skinny(y1, h0, plan->c20_w, 2 * h0, plan->c20_b, nullptr, 0, g1, h1, (int32_t)groups, h1, h0, 0, stream);
     } else {
         rc = psam_linear(y1, h0, plan->c20_w, 2 * h0, plan->c20_b, nullptr, 0, g1, h1, (int32_t)groups, h1, h0, 0, stream);
     }
@@ -320,8 +329,10 @@ PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const
     rc = psam_layernorm_ex(x3, h1, nullptr, 0, plan->c21_w, plan->c21_b, x3, b, rows, h1, plan->eps, PSAM_ACT_GELU, rs, 1, stream);
     if (rc) return rc;
     std::memset(&f, 0, sizeof(f));
-    f.gmax_out = out; f.gmax_ld = cout; f.gmax_k = K; f.no_store = 1;
-    return psam_gemm_f16x3p_ex(x3, b, rs, P(plan->o_w23), b, P(plan->o_s23), out, cout, plan->c23_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, cout, b, 1.f, 0, &f, stream);
+    f.gmax_out = part2; f.gmax_ld = cout; f.gmax_k = Kp; f.no_store = 1;
+    rc = psam_gemm_f16x3p_ex(x3, b, rs, P(plan->o_w23), b, P(plan->o_s23), out, cout, plan->c23_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, cout, b, 1.f, 0, &f, stream);
+    if (rc || parts == 1) return rc;
+    return psam_group_max(part2, cout, out, cout, groups, parts, cout, stream);
 }
 
 // ================================================================================================================================
@@ -383,6 +394,8 @@ PSAM_API int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void*
     if (Z * G >= 256) {
         rc = psam_scale_pack_rows_g8(keys, E, (int32_t)(Z * G), E, kp, a, sk, stream);
         if (!rc) rc = psam_gemm_f16x3p_ex(kp, a, sk, P(plan->o_w0), a, P(plan->o_s0), k1, E, plan->u0_b, nullptr, 0, nullptr, 0, 0, (int32_t)(Z * G), E, a, 1.f, 0, nullptr, stream);
+    } else if (Z * G <= 64) {
+        rc = psam_linear_skinny(keys, E, plan->u0_w, E, plan->u0_b, nullptr, 0, k1, E, (int32_t)(Z * G), E, E, 0, stream);
     } else {
         rc = psam_linear(keys, E, plan->u0_w, E, plan->u0_b, nullptr, 0, k1, E, (int32_t)(Z * G), E, E, 0, stream);
     }

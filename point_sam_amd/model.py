@@ -247,7 +247,8 @@ class PointCloudSAM:
         rows = feats.shape[0] * knn_idx.shape[1] * K
         l1 = (w[prefix + ".conv1.0.weight"], w[prefix + ".conv1.0.bias"], w[prefix + ".conv1.1.weight"], w[prefix + ".conv1.1.bias"], eps)
         w2a = w[prefix + ".conv2.0.weight"]
-        fused = (self.precision == "f16x3" and self.fuse_patch and K in (32, 64) and ops.fuse_supported(rows, 128) and prefix in self.pe_bound
+        # group sizes 32 / 64: the GEMM epilogues pool whole groups; multiples of 64 (cfg #3: 256): they pool 64-row parts, a small pass pools the parts
+        fused = (self.precision == "f16x3" and self.fuse_patch and (K in (32, 64) or K % 64 == 0) and ops.fuse_supported(rows, 128) and prefix in self.pe_bound
                  and all((prefix + n) in self.fw for n in (".conv1.3.weight", ".conv2.0.weight#x", ".conv2.3.weight")))
         if fused and self.c_blocks and prefix in getattr(self, "c_patch", {}) and ops.GEMM_MODE == "f16x3":
             return self.c_patch[prefix].run(coords, feats, centers, knn_idx, radius=radius, center_idx=center_idx)      # psam_patch_encoder: the same six launches
@@ -259,18 +260,22 @@ class PointCloudSAM:
             h1 = ops.patch_l1(coords, feats, centers, knn_idx, *l1, radius=radius, center_idx=center_idx, scale_out=s1)
             h2 = torch.empty(rows, h0, dtype=torch.float32, device=coords.device)          # g8-packed container
             s2 = torch.empty(rows, dtype=torch.float32, device=coords.device)
-            y1 = torch.empty(groups, h0, dtype=torch.float32, device=coords.device)
+            Kp = K if K <= 64 else 64             # rows pooled per epilogue group
+            parts = K // Kp
+            y1 = torch.empty(groups * parts, h0, dtype=torch.float32, device=coords.device)
             k1, k2 = self.pe_bound[prefix]
-            self._lin(prefix + ".conv1.3", h1, x_scale=s1, x_packed=True, out=h2, pack_out=(s2, k1, k2), group_max_out=y1, group_max_k=K)
+            self._lin(prefix + ".conv1.3", h1, x_scale=s1, x_packed=True, out=h2, pack_out=(s2, k1, k2), group_max_out=y1, group_max_k=Kp)
+            if parts > 1:
+                y1 = ops.group_max(y1, parts)
             del h1
             g1 = ops.linear(y1, self.fw.get(prefix + ".conv2.0.weight#max", w2a[:, :h0]), w[prefix + ".conv2.0.bias"])
             h3 = ops.linear(h2, self.fw[prefix + ".conv2.0.weight#x"], None, rowbias=g1, rowgroup=K, x_scale=s2, x_packed=True)
             del h2
             pk, rs = self._ln_feeds_gemm(h3, prefix + ".conv2.3")
             self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3, scale_out=rs, pack=pk)
-            emb = torch.empty(groups, self.w[prefix + ".conv2.3.weight"].shape[0], dtype=torch.float32, device=coords.device)
-            self._lin(prefix + ".conv2.3", h3, x_scale=rs, x_packed=pk, group_max_out=emb, group_max_k=K, no_store=True)
-            return emb
+            emb = torch.empty(groups * parts, self.w[prefix + ".conv2.3.weight"].shape[0], dtype=torch.float32, device=coords.device)
+            self._lin(prefix + ".conv2.3", h3, x_scale=rs, x_packed=pk, group_max_out=emb, group_max_k=Kp, no_store=True)
+            return ops.group_max(emb, parts) if parts > 1 else emb
         h1 = ops.patch_l1(coords, feats, centers, knn_idx, *l1, radius=radius, center_idx=center_idx)
         h2 = self._lin(prefix + ".conv1.3", h1)
         del h1

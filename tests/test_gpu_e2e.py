@@ -284,15 +284,16 @@ def test_fused_mlp_matches_unfused_model(gpu):
 
 def test_fused_patch_encoder_matches_unfused(gpu):
     """Mini-PointNet with packed hand-overs and the two max-pools inside GEMM epilogues vs the separate-kernel sequence, for the point
-    patch encoder (6 input channels) and the mask encoder (4 channels, second click), groups of 64 and of 32."""
-    for G, K in ((128, 64), (256, 32)):
+    patch encoder (6 input channels) and the mask encoder (4 channels, second click), groups of 64 and of 32, and of 128 / 256 (pooled as 64-row
+    parts in the epilogues + a small pass over the parts: cfg #3's group size); the fused form through psam_patch_encoder and sequenced by the host."""
+    for G, K, c_blocks in ((128, 64, True), (256, 32, True), (64, 128, True), (32, 256, False), (32, 256, True)):
         cfg = get_config("tiny", G, K)
         sd = random_state_dict(cfg, seed=3)
         xyz, rgb, prompt, labels = O.synthetic_batch(2, 9000, seed=4)
         outs = []
         for fuse in (True, False):
             model = gpu(cfg, sd, precision="f16x3")
-            model.fuse_patch = fuse
+            model.fuse_patch, model.c_blocks = fuse, c_blocks
             st = model.encode(xyz.cuda(), rgb.cuda())
             m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
             m2, i2 = model.decode(st, prompt.cuda(), labels.cuda(), m1[:, 0].contiguous(), False)
