@@ -112,3 +112,31 @@ def test_mlp3_weight_stack_and_ln_bound():
     y = torch.nn.functional.layer_norm(x.double(), (256,), gam.double(), bet.double(), 1e-5)
     assert y.abs().max().item() <= ops.row_ln_bound(gam, bet) * (1 + 1e-6)
     assert y[0].abs().max().item() > 0.9 * (255 ** 0.5) * gam[7].abs().item() - bet.abs().max().item()
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every struct of include/pointsam_hip.h that the Python host mirrors with ctypes has the same size (and, for the ones with mixed field
+    types, the same offsets of a few late fields) as the C compiler gives it: an edit to one side without the other fails here, not on the GPU."""
+    import ctypes
+    import shutil
+    import subprocess
+    from point_sam_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    pairs = [("psam_gemm_fuse_t", _lib.GemmFuse, "out_bound"), ("psam_twoway_tokens_t", _lib.TwoWayTokens, "ws_floats"),
+             ("psam_eva_block_weights_t", _lib.EvaBlockWeights, "eps"), ("psam_eva_block_plan_t", _lib.EvaBlockPlan, "o_lnd"),
+             ("psam_patch_encoder_weights_t", _lib.PatchEncoderWeights, "eps"), ("psam_patch_encoder_plan_t", _lib.PatchEncoderPlan, "o_s23"),
+             ("psam_upscale_weights_t", _lib.UpscaleWeights, "eps"), ("psam_upscale_plan_t", _lib.UpscalePlan, "o_s3"),
+             ("psam_attn_weights_t", _lib.AttnWeights, "o_b"), ("psam_twoway_layer_weights_t", _lib.TwoWayLayerW, "m2_b"),
+             ("psam_twoway_weights_t", _lib.TwoWayWeights, "nf_b"), ("psam_twoway_plan_t", _lib.TwoWayPlan, "o_scales")]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "pointsam_hip.h"', 'int main(void) {']
+    for name, _, field in pairs:
+        src.append(f'    printf("{name} %zu %zu\\n", sizeof({name}), offsetof({name}, {field}));')
+    src += ['    return 0;', '}']
+    c = tmp_path / "sizes.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = dict((l.split()[0], (int(l.split()[1]), int(l.split()[2]))) for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, cls, field in pairs:
+        assert out[name] == (ctypes.sizeof(cls), getattr(cls, field).offset), (name, out[name], ctypes.sizeof(cls), getattr(cls, field).offset)
