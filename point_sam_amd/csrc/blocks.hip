@@ -11,10 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
-#include "common.h"
-#pragma GCC visibility push(default)
-#include "../../include/pointsam_hip.h"
-#pragma GCC visibility pop
+#include "common.h"      // brings in include/pointsam_hip.h
 
 namespace {
 constexpr int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }

@@ -11,6 +11,12 @@
 
 #define PSAM_API extern "C" __attribute__((visibility("default")))
 
+// The public header is part of every translation unit: a definition whose signature drifts from its declaration in include/pointsam_hip.h is a
+// compile error (C linkage cannot be overloaded), and the structs that cross the ABI exist once.
+#pragma GCC visibility push(default)
+#include "../../include/pointsam_hip.h"
+#pragma GCC visibility pop
+
 void psam_set_error(const char* msg);
 
 #define PSAM_REQUIRE(cond, code, msg)                 \

@@ -432,22 +432,7 @@ static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
-// Optional fused extras of psam_gemm_f16x3p_ex (include/pointsam_hip.h: psam_gemm_fuse_t).
-struct psam_gemm_fuse_t {
-    float* out_scale; float out_k1, out_k2; int32_t pack_out;       // g8-packed output rows with a bound-derived scale
-    float* stats; int32_t stat_cols;                                // LayerNorm partials of the SwiGLU-gated rows: [M, segs, 2]
-    const float* ln_mean; const float* ln_rstd; const float* ln_c;  // LayerNorm of the A rows folded into this GEMM
-    float* gmax_out; int64_t gmax_ld; int32_t gmax_k; int32_t no_store;   // per-column max over groups of gmax_k (32 | 64) rows; C not written
-    // N == 256 only (a wave owns whole rows): LayerNorm of the output row before the activation;
-    // hyper-network dot products masks[z, c, n] = <hyper[z, c, :], out[z * hyper_rows + n, :]> (c < hyper_c <= 4)
-    const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
-    const float* hyper; float* masks; int32_t hyper_c; int32_t hyper_rows;
-    int64_t hyper_pstride;      // elements between the partial planes of `masks` (psam_gemm_f16x3p_hyper_planes of them)
-    // split-K (few tiles, long K: one cloud through a wide encoder): `splitk` workgroups per tile write partial products to the planes of
-    // splitk_ws (splitk_plane >= M * N floats apart), a second kernel adds them in a fixed order and applies bias / activation / residual
-    float* splitk_ws; int64_t splitk_plane; int32_t splitk;
-    const float* out_bound;     // pack_out: out_scale[row] = f16_row_scale(out_bound[row]) (a bound per row, e.g. from psam_layernorm_ex2)
-};
+// Optional fused extras of psam_gemm_f16x3p_ex: psam_gemm_fuse_t, include/pointsam_hip.h (part of this translation unit through common.h).
 
 // partial planes the hyper products of an N-column GEMM are delivered in: 1 with the row-LayerNorm (full-row) epilogue, N / 64 otherwise
 PSAM_API int32_t psam_gemm_f16x3p_hyper_planes(int32_t N, int32_t with_row_ln) { return with_row_ln ? 1 : N / 64; }

@@ -25,18 +25,6 @@
 #include <cstdlib>
 #include "common.h"
 
-struct psam_twoway_tokens_t {
-    int32_t Z, T, G, heads, mlp, mode, skip_pe, reserved;     // mode 0: full layer; 1: cross attention + LayerNorm only (final_attn_token_to_image)
-    float eps;
-    float* queries; const float* pe;                          // [Z*T, 256] in / out; [Z*T, 256]
-    const float* kimg; int64_t ldk, sk; const float* vimg; int64_t ldv, sv;      // [Z, G, 128] views: rows ld* apart, prompt sets s* apart
-    const float *sq_w, *sq_b, *sk_w, *sk_b, *sv_w, *sv_b, *so_w, *so_b, *n1_g, *n1_b;      // self_attn, norm1
-    const float *cq_w, *cq_b, *co_w, *co_b, *n2_g, *n2_b;                                  // cross_attn_token_to_image (q, out), norm2
-    const float *m1_w, *m1_b, *m2_w, *m2_b, *n3_g, *n3_b;                                  // mlp, norm3
-    const float *ik_w, *ik_b, *iv_w, *iv_b;                                                // cross_attn_image_to_token k / v projections
-    float *ktok, *vtok;                                                                     // [Z*T, 128] out
-    float* ws; int64_t ws_floats;                                                           // workspace, psam_twoway_tokens_ws_floats()
-};
 
 namespace {
 constexpr int TW_E = 256, TW_IX = 128, TW_CH = 8;
