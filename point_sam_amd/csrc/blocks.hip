@@ -56,6 +56,7 @@ PSAM_API int32_t psam_eva_block_prepare(const psam_eva_block_weights_t* wt, psam
     const float* ptrs[] = {wt->norm1_w, wt->norm1_b, wt->q_w, wt->q_b, wt->k_w, wt->v_w, wt->v_b, wt->proj_w, wt->proj_b, wt->norm2_w, wt->norm2_b,
                            wt->fc1_g_w, wt->fc1_g_b, wt->fc1_x_w, wt->fc1_x_b, wt->mlp_norm_w, wt->mlp_norm_b, wt->fc2_w, wt->fc2_b};
     for (const float* p : ptrs) PSAM_REQUIRE(p, PSAM_EINVAL, "psam_eva_block_prepare: null weight pointer");
+    PSAM_REQUIRE(hipStreamSynchronize(stream) == hipSuccess, PSAM_EINVAL, "psam_eva_block_prepare: stream error");      // the weights may still be arriving on `stream`
 
     auto fetch = [&](const float* dev, int64_t n) { std::vector<float> h((size_t)n); return hipMemcpy(h.data(), dev, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? h : std::vector<float>(); };
 #define FETCH(name, dev, n) std::vector<float> name = fetch(dev, n); PSAM_REQUIRE((int64_t)name.size() == (int64_t)(n), PSAM_EINVAL, "psam_eva_block_prepare: cannot read a weight tensor")
@@ -243,6 +244,7 @@ PSAM_API int32_t psam_patch_encoder_prepare(const psam_patch_encoder_weights_t* 
                  PSAM_EINVAL, "psam_patch_encoder_prepare: null weight pointer");
     PSAM_REQUIRE(prepared_bytes >= psam_patch_encoder_prepared_bytes(h0, h1, cout), PSAM_EWORKSPACE, "psam_patch_encoder_prepare: prepared buffer too small");
     std::vector<float> w13((size_t)h0 * h0), b13(h0);
+    PSAM_REQUIRE(hipStreamSynchronize(stream) == hipSuccess, PSAM_EINVAL, "psam_patch_encoder_prepare: stream error");      // the weights may still be arriving on `stream`
     PSAM_REQUIRE(hipMemcpy(w13.data(), wt->c13_w, w13.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(b13.data(), wt->c13_b, b13.size() * 4, hipMemcpyDeviceToHost) == hipSuccess,
                  PSAM_EINVAL, "psam_patch_encoder_prepare: cannot read conv1.3");
     double nmax = 0.0, bmax = 0.0;

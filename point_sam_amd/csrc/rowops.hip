@@ -412,7 +412,8 @@ __global__ void scatter_amax_kernel(const float* __restrict__ x, int64_t ldx, co
     const int c = (int)(t % C);
     const int64_t set = r / rows_per_set, within = r - set * rows_per_set;
     const int64_t dest = idx[(set / idx_rep) * rows_per_set + within] + set * set_stride;
-    const float v = x[r * ldx + c];
+    const float raw = x[r * ldx + c];
+    const float v = raw == 0.f ? 0.f : raw;      // -0.0 -> +0.0: as an integer pattern -0.0 is INT_MIN and would lose against every negative value
     float* o = out + dest * C + c;
     if (v >= 0.f) atomicMax(reinterpret_cast<int*>(o), __float_as_int(v));
     else atomicMin(reinterpret_cast<unsigned*>(o), __float_as_uint(v));

@@ -123,6 +123,7 @@ def test_scatter_amax_and_group_feats_kernels(build):
     g = torch.Generator().manual_seed(5)
     B, N, G, C = 3, 777, 40, 33
     x = torch.randn(B * N, C, generator=g) - 0.5
+    x[::7, ::5] = -0.0                                           # negative zeros must still beat negative values
     idx = torch.randint(0, G - 3, (B, N), generator=g)          # the last three cells stay empty
     want = x.view(B, N, C).new_zeros(B, G, C).scatter_reduce(1, idx.unsqueeze(-1).expand(B, N, C), x.view(B, N, C), "amax", include_self=False)
     got = ops.scatter_amax(x.cuda(), idx.cuda(), B * G, rows_per_set=N, set_stride=G, include_self=False)
