@@ -140,3 +140,23 @@ def test_ctypes_structs_match_the_header(tmp_path):
     out = dict((l.split()[0], (int(l.split()[1]), int(l.split()[2]))) for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
     for name, cls, field in pairs:
         assert out[name] == (ctypes.sizeof(cls), getattr(cls, field).offset), (name, out[name], ctypes.sizeof(cls), getattr(cls, field).offset)
+
+
+def test_host_side_planning_functions_without_a_gpu():
+    """Host logic of the library that needs no device: the split-K factor per shape, workspace / prepared-blob sizes of the coarse entry points."""
+    from point_sam_amd import _lib
+    lib = _lib.load()
+    sk = lib.psam_gemm_f16x3p_splitk
+    assert sk(512, 1408, 6144, 0) == 4 and sk(512, 1408, 1408, 1) in (3, 4)      # fc2 / proj of the giant encoder at one cloud: few tiles, long K
+    assert sk(4096, 1024, 1024, 0) == 1                                          # a batch of clouds: never (M > 2048)
+    assert sk(512, 6144, 1408, 0) == 1 and sk(512, 1408, 6144, 3) == 1 and sk(512, 1408, 512, 0) == 1      # enough tiles / SwiGLU / short K
+    for M in (256, 4096):
+        a, b = lib.psam_eva_block_ws_bytes(M, 1024, 2730), lib.psam_eva_block_ws_bytes(2 * M, 1024, 2730)
+        assert 0 < a < b and a % 256 == 0
+    assert lib.psam_eva_block_prepared_bytes(1024, 2730) > 4 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 2752 * 1024 + 1024 * 2752)
+    assert lib.psam_eva_block_ws_bytes(0, 1024, 2730) == 0 and lib.psam_eva_block_prepared_bytes(0, 1) == 0
+    assert lib.psam_patch_encoder_ws_bytes(8 * 512 * 64, 8 * 512, 128, 512) > 4 * 8 * 512 * 64 * (128 + 128 + 512)
+    assert lib.psam_twoway_decoder_prepared_bytes(2, 256, 2048, 2) > 4 * 2 * (4 * 256 * 256 + 8 * 128 * 256 + 2 * 2048 * 256)
+    assert lib.psam_twoway_decoder_ws_bytes(8, 6, 512, 256, 2048) > 4 * 6 * 8 * 512 * 256
+    assert lib.psam_upscale_masks_ws_bytes(8, 32768, 512, 3, 256) > 4 * 8 * 32768 * 256
+    assert lib.psam_twoway_tokens_ws_floats(2048) == 64 * (5 * 256 + 2048) + 64
