@@ -36,6 +36,7 @@ def _stale(out, deps):
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]   # every header: an edit to any rebuilds all objects
+    hdrs.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "pointsam_hip.h"))   # the public ABI header is part of every translation unit (common.h)
     jobs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)

@@ -518,3 +518,37 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
     if constexpr (TM > 3) stripe(std::integral_constant<int, 3>{});
     static_assert(TM <= 4, "stripes instantiated for TM <= 4");
 }
+
+// Wide wave tiles (one wave owns TN > 4 column tiles of 32 -- the right-sized 256x224 / 256x192 ping-pong configurations, whose waves span the
+// whole tile width): the epilogue runs per CHUNK of two column tiles, the shape every fused extra (packed output, row statistics, SwiGLU pairs,
+// folded LayerNorm) is written for: 8.5 KiB of LDS per wave instead of 32 x (TN * 32 + 4) floats, and the accumulators of a chunk are dead
+// once it is stored.  The chunks are instantiated one after the other (compile-time accumulator indices; a rolled loop selecting the chunk's
+// registers at run time kept all TN tiles live beside the pass loop's own registers and spilled ~150 VGPRs); inside a chunk the pass loop stays
+// rolled and specialised, so what runs per chunk is one short instruction stream.  A chunk whose second tile lies outside N (N % 64 == 32, or
+// the odd last tile of an odd TN) runs the one-tile instance; chunks entirely outside N are skipped.
+template <int TM, int TN, bool SCALED = false, bool EXT = false, typename ArgsT>
+__device__ __forceinline__ void gemm_store_tile_chunked(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], float* __restrict__ lw, int row_base, int col_base,
+                                                        int lane, float* __restrict__ C, const float* __restrict__ R) {
+    auto chunk = [&](auto c_c) {
+        constexpr int c = decltype(c_c)::value;
+        if constexpr (2 * c < TN) {
+            const int cb = col_base + c * 64;
+            if (cb >= p.N) return;                              // wave-uniform
+            const bool single = (2 * c + 1 >= TN) || (cb + 32 >= p.N);
+            if (single) {
+                ep_f32x16 sub[TM][1];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) sub[i][0] = acc[i][2 * c];
+                gemm_store_tile<TM, 1, SCALED, EXT>(p, sub, lw, row_base, cb, lane, C, R, nullptr);
+            } else if constexpr (2 * c + 1 < TN) {
+                ep_f32x16 sub[TM][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { sub[i][0] = acc[i][2 * c]; sub[i][1] = acc[i][2 * c + 1]; }
+                gemm_store_tile<TM, 2, SCALED, EXT>(p, sub, lw, row_base, cb, lane, C, R, nullptr);
+            }
+        }
+    };
+    using std::integral_constant;
+    chunk(integral_constant<int, 0>{}); chunk(integral_constant<int, 1>{}); chunk(integral_constant<int, 2>{}); chunk(integral_constant<int, 3>{});
+    static_assert(TN <= 8, "chunks instantiated for TN <= 8");
+}

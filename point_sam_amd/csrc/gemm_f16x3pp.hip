@@ -39,8 +39,12 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
     constexpr int ROWB = 64;                        // bytes per row per ring unit: one k16 step = [hi k0-7 | lo k0-7 | hi k8-15 | lo k8-15]
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, UNIT = A_BYTES + W_BYTES;
     constexpr int NBLK = UNIT / 1024, A_BLK = A_BYTES / 1024;       // 1 KiB DMA pieces: 16 rows x 64 B
-    static_assert(NBLK % 8 == 0, "pieces divide among the eight waves");
-    constexpr int NL = NBLK / 8;                    // DMA instructions per wave per step
+    // Pieces of a unit are dealt to the eight waves round-robin: NL per wave, except that with NBLK % 8 != 0 (the right-sized 256x224 / 256x192
+    // tiles) the waves NFULL .. 7 carry one piece less -- their counted vmcnt waits use NL - 1 per step (PP_WAITV: a wave-uniform branch over
+    // two immediates), nothing is loaded twice.
+    constexpr int NL = (NBLK + 7) / 8;              // DMA instructions per wave per step (waves < NFULL)
+    constexpr int NFULL = NBLK - 8 * (NL - 1);      // 8 when the pieces divide evenly
+    constexpr bool CHUNKED = TN > 4;                // wide wave tiles: epilogue per chunk of two column tiles (gemm_store_tile_chunked)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // ---- tile of this workgroup (tile order: gemm_f16x3p.hip)
@@ -59,6 +63,12 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
     const int grp = wave >> 2, wg = wave & 3;       // waves 0-3: group 0, 4-7: group 1 (consecutive waves go to different SIMDs)
     const int wm = grp * GWM + wg / WN, wn = wg % WN;
     const int r32 = lane & 31, h = lane >> 5;
+    const bool shortw = NFULL < 8 && wave >= NFULL;      // wave-uniform
+#define PP_WAITV(k)                                                                                   \
+    do {                                                                                              \
+        if (shortw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((k) * (NL - 1)) : "memory");             \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((k) * NL) : "memory");                          \
+    } while (0)
 
     // ---- DMA source offsets: piece b = wave + 8 i covers rows 16b .. 16b+15 of the unit (A rows, then W rows); lane -> (row 16b + lane/4,
     // slot lane%4), which must receive chunk slot ^ swz(row) of that row's 64 bytes, swz(r) = (r >> 2) & 3: the rows of a ds_read_b128
@@ -77,6 +87,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
         voff[i] = (int)((int64_t)rc * (isw ? p.ldw : p.lda) * 4) + chunk * 16;
     }
     auto issue_one = [&](int i, int step, int unit) {
+        if (NFULL < 8 && i == NL - 1 && shortw) return;
         const int b = wave + i * 8;
         unsigned char* dst = smem + unit * UNIT + b * 1024;
         if (b >= A_BLK) P_DMA16(rsW, dst, voff[i], step * ROWB);
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
     // the epilogue's operands (per-row inverse A scales / folded-LayerNorm statistics, the lane's column constants): loaded here, consumed
     // after the K loop
     // (not with two-step phases of the 128x64 wave tile: 128 accumulator + 96 fragment registers leave no room for them through the loop)
-    constexpr bool PREFETCH_EPI = !(P == 2 && TM * TN >= 8);
+    constexpr bool PREFETCH_EPI = !(P == 2 && TM * TN >= 8) && !CHUNKED;
     EpPre<TM> epre;
     if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
     pf16x8 fa[P][TM][2], fw[P][TN][2];
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) issue_one(i, u, u);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - P) * NL) : "memory");
+    PP_WAITV(S - P);
     asm volatile("s_barrier" ::: "memory");
     if (grp == 1) asm volatile("s_barrier" ::: "memory");      // the stagger: group 1 runs one interval behind
     if (PRIO == 2 && grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (MI355X_MICROARCH.md, item 4)
@@ -127,10 +138,10 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
         int last = (q - 1) * P + S - 1;
         last = last < nsteps - 1 ? last : nsteps - 1;
         const int later = last - (q * P + P - 1);        // 0 .. S - 2P
-        if (later >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NL) : "memory");
-        else if (later == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL) : "memory");
-        else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NL) : "memory");
+        if (later >= 4) PP_WAITV(4);
+        else if (later == 3) PP_WAITV(3);
+        else if (later == 2) PP_WAITV(2);
+        else if (later == 1) PP_WAITV(1);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grp == 1) {
-                if (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2 * P) * NL) : "memory");
+                if (STEADY) PP_WAITV(S - 2 * P);
                 else if (ph + 1 < nph) wait_phase(ph + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
             }
             if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
             if (grp == 0) {
-                if (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2 * P) * NL) : "memory");
+                if (STEADY) PP_WAITV(S - 2 * P);
                 else if (ph + 1 < nph) wait_phase(ph + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -229,21 +240,27 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
         if (sum == 123.456f) p.C[0] = sum;
         return;
     }
-    if (ABL & 32) {     // everything of the epilogue except the global stores of C
-        F16PArgs q = p;
-        q.no_store = 1;
-        gemm_store_tile<TM, TN, true, true>(q, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+    if constexpr (CHUNKED) {
+        gemm_store_tile_chunked<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<2>(), m0 + wm * TM * 32,
+                                                    n0 + wn * TN * 32, lane, p.C, p.residual);
+    } else {
+        if (ABL & 32) {     // everything of the epilogue except the global stores of C
+            F16PArgs q = p;
+            q.no_store = 1;
+            gemm_store_tile<TM, TN, true, true>(q, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+                                                n0 + wn * TN * 32, lane, p.C, p.residual, PREFETCH_EPI ? &epre : nullptr);
+            return;
+        }
+        gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
                                             n0 + wn * TN * 32, lane, p.C, p.residual, PREFETCH_EPI ? &epre : nullptr);
-        return;
     }
-    gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
-                                        n0 + wn * TN * 32, lane, p.C, p.residual, PREFETCH_EPI ? &epre : nullptr);
+#undef PP_WAITV
 }
 
 template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0>
 static int32_t launch_pp(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = 2 * GWM * TM * 32, BN = WN * TN * 32;
-    constexpr int ring = S * (BM + BN) * 64, epi = 8 * gemm_epilogue_lds_floats_per_wave<TN>() * 4;
+    constexpr int ring = S * (BM + BN) * 64, epi = 8 * (TN > 4 ? gemm_epilogue_lds_floats_per_wave<2>() : gemm_epilogue_lds_floats_per_wave<TN>()) * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (TN % 2 != 0 && p.act == 3) {
@@ -271,9 +288,10 @@ bool f16x3pp_supports(int cfg, int act, bool stats, bool gmax, bool hyper) {
         case 53: tm = 2; tn = 4; break;
         case 55: case 56: tm = 2; tn = 2; break;
         case 57: case 58: tm = 1; tn = 2; break;
+        case 62: case 63: case 64: tm = 1; tn = 2; break;      // wide wave tiles run the two-tile epilogue chunk by chunk (odd widths: no SwiGLU, checked at launch)
         default: return false;
     }
-    if (act == 3 && (tn & 1)) return false;
+    if (act == 3 && ((tn & 1) || cfg == 62)) return false;      // SwiGLU pairs column tiles (2q, 2q+1): even widths only (cfg 62 is seven tiles wide)
     if ((stats || hyper) && tn != 2) return false;
     if (gmax && tm < 2) return false;
     return true;
@@ -291,6 +309,25 @@ int f16x3pp_pick(int M, int N, int K, int act) {
     if (mode < 0) { const char* e = getenv("PSAM_GEMM_PP"); mode = e ? atoi(e) : 0; }
     if (mode == 0 || K < 128 || (K & 31)) return -1;
     if (M >= 32768) return (N >= 256 && (N & 127) == 0 && K >= 512) ? 51 : -1;      // mini-PointNet conv2.3: 256x256 tiles, many rounds
+    if (mode == 4) {
+        // right-sized tiles: among the 256-row ping-pong tiles (256x256 / 256x224 / 256x192; SwiGLU pairs need an even number of column tiles)
+        // the width whose tile count fills whole rounds of #CU - 8 workgroup slots best -- wide GEMMs only (N >= 1536: with 128-column tiles
+        // and one workgroup per CU the narrow ones leave half of the chip idle, the lock-step kernel keeps them)
+        if (M < 2048 || (M & 255) || (N & 127) || N < 1536) return -1;
+        static int ncu = 0;
+        if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+        const int slots = ncu > 16 ? ncu - 8 : ncu;
+        int best = -1; double best_cost = 1e300;
+        const int cfgs[3] = {51, 62, 63}, widths[3] = {256, 224, 192};
+        for (int i = 0; i < 3; ++i) {
+            if (act == 3 && (widths[i] / 32) % 2) continue;
+            const int64_t tiles = (int64_t)(M / 256) * ((N + widths[i] - 1) / widths[i]);
+            const double rounds = (double)((tiles + slots - 1) / slots);
+            const double cost = rounds * widths[i] * (1.0 + 24.0 / widths[i]);      // per-round time ~ tile width + a fixed part (prologue, epilogue ramp)
+            if (cost < best_cost) { best_cost = cost; best = cfgs[i]; }
+        }
+        return best;
+    }
     if (M >= 2048 && (M & 255) == 0 && (N & 127) == 0) {
         if (act == 3) return 55;                                                     // fc1 (SwiGLU): 256x128 tiles
         if (mode == 3) return (N & 255) == 0 ? 51 : 55;
@@ -329,6 +366,10 @@ int32_t launch_f16x3pp(int cfg, F16PArgs& p, hipStream_t stream) {
         case 56: return launch_pp<2, 2, 2, 2, 6, 1, 1>(p, stream);      //   one-step phases (12 MFMAs)
         case 57: return launch_pp<2, 2, 1, 2, 8, 2, 1>(p, stream);      // 128x128, waves of 32x64, 8 units (128 KiB), two-step phases (12 MFMAs)
         case 58: return launch_pp<2, 2, 1, 2, 4, 2, 1>(p, stream);      //   4 units (64 KiB): two workgroups per CU
+        // right-sized tiles (round 4): eight waves of 32 rows x the whole tile width, so that a launch's tiles fill #CU - 8 workgroup slots in whole rounds
+        case 62: return launch_pp<4, 1, 1, 7, 5, 1, 1>(p, stream);      // 256x224 (150 KiB): qkv 4096x3072 = 224 tiles, one round
+        case 63: return launch_pp<4, 1, 1, 6, 5, 1, 1>(p, stream);      // 256x192 (140 KiB): fc1 4096x5504 = 464 tiles, two rounds
+        case 64: return launch_pp<4, 1, 1, 8, 5, 1, 1>(p, stream);      // 256x256 with the same wave layout (160 KiB)
         default: break;
     }
     psam_set_error("psam_gemm_f16x3p: unknown ping-pong config");
