@@ -139,6 +139,10 @@ int32_t psam_gemm_f16x3p(const void* A, int64_t lda, const float* scaleA, const 
                          const float* bias, const float* residual, int64_t ldr, const float* rowbias, int64_t ldrb, int32_t rowgroup, int32_t M,
                          int32_t N, int32_t K, float alpha, int32_t act, psam_stream_t stream);
 void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring configuration index, -1 = auto */
+/* Epilogue of the packed-operand GEMMs: 1 = register-only epilogue on transposed accumulator tiles (csrc/gemm_epilogue_t.h) wherever the
+ * launch's options allow it, 0 = always the LDS-transposition epilogue (csrc/gemm_epilogue.h), -1 = default (environment PSAM_GEMM_TR, else 1).
+ * Both give the same bits; the hook exists for A/B measurements and the bitwise test. */
+void psam_gemm_f16x3p_force_epilogue(int32_t mode);
 /* The same GEMM with fused extras (all optional; M % 256 == 0 and N % 128 == 0 required when any is used) -- what lets the EVA02 MLP
  * `fc2(LayerNorm(SiLU(fc1_g x) * fc1_x x))` (timm SwiGLU with scale_mlp) run as two GEMMs and nothing in between:
  *   pack_out : C receives the g8-packed output rows (the next GEMM's A operand), scaled per row by out_scale[row] (written here) =

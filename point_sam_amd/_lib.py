@@ -43,6 +43,7 @@ SIGNATURES = {
     "psam_pack_rows_f16x2_g8": (i32, [ptr, i64, ptr, i32, i32, ptr, i64, ptr]),
     "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3p_force_config": (None, [i32]),
+    "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
     "psam_gemm_f16x3p_splitk": (i32, [i32, i32, i32, i32]),
     "psam_nn_group_feats": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, i64, ptr]),

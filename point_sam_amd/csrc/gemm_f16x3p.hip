@@ -26,14 +26,16 @@
 #include "common.h"
 #include "gemm_f16x3p_args.h"
 #include "gemm_epilogue.h"
+#include "gemm_epilogue_t.h"
 
 // ABL (measurement builds only, -DPSAM_GEMM_ABLATE): 1 = no epilogue, 2 = no DMA after the prologue, 4 = no MFMA, 8 = every tile loads the
 // operand panels of tile (0, 0) (perfect L2 sharing), 16 = no fragment reads after the first slab.
 // PF (where the DMA of a slab is issued): 0 = behind the fragment reads of the slab S-1 earlier, one per MFMA slot; 1 = all of it right
 // after that slab's barrier; 2 (S = 2 only) = a second barrier per slab once every wave holds its step-1 fragments frees the stage half
 // a slab early: the DMA of slab t+2 is issued in the middle of slab t (1.5 slab times ahead instead of 1).
-template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArgs p) {
+// TR = 1: MFMA operands swapped (accumulator tiles transposed: one output row per lane) + the register-only epilogue of gemm_epilogue_t.h.
+template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0, int TR = 0>
+__global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void gemm_f16x3p_kernel(const F16PArgs p) {      // TR, four waves: two workgroups per CU must fit (<= 256 registers)
     constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int ROWB = 128;                                   // bytes per row per slab (32 k x 4 B)
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
 
     // the epilogue's operands (per-row scalars, column constants): in flight from here on for the wave tiles that have the registers to hold
     // them through the K loop (gemm_epilogue.h)
-    constexpr bool PREFETCH_EPI = TM * TN >= 4 && TN <= 4;
+    constexpr bool PREFETCH_EPI = TM * TN >= 4 && TN <= 4 && !TR;
     EpPre<TM> epre;
     float* const Cout = p.C + (int64_t)split * p.plane;
     if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, Cout, p.residual);
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         constexpr int PA[3] = {0, 1, 0}, PW[3] = {1, 0, 0};
         const int term = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
         if (ABL & 4) asm volatile("" ::"v"(fa[i][PA[term]]), "v"(fw[j][PW[term]]));
+        else if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j][PW[term]], fa[i][PA[term]], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[term]], fw[j][PW[term]], acc[i][j], 0, 0, 0);
     };
 
@@ -241,8 +244,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3p_kernel(const F16PArg
         if (sum == 123.456f) p.C[0] = sum;
         return;
     }
-    gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
-                                  n0 + wn * TN * 32, lane, Cout, p.residual, PREFETCH_EPI ? &epre : nullptr);
+    if constexpr (TR) gemm_store_tile_t<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, Cout, p.residual);
+    else gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
+                                             n0 + wn * TN * 32, lane, Cout, p.residual, PREFETCH_EPI ? &epre : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- row scales
@@ -367,6 +371,22 @@ PSAM_API int32_t psam_scale_pack_rows_g8(const float* X, int64_t ldx, int32_t ro
 // ---------------------------------------------------------------------------------------------- host
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
+// Epilogue of the packed-operand GEMMs: 1 = the register-only epilogue on transposed accumulator tiles (gemm_epilogue_t.h) wherever the launch's
+// options allow it, 0 = always the LDS-transposition epilogue (gemm_epilogue.h), -1 = the default (environment PSAM_GEMM_TR, else 1).
+static int g_f16x3p_tr = -1;
+PSAM_API void psam_gemm_f16x3p_force_epilogue(int32_t mode) { g_f16x3p_tr = mode; }
+bool f16x3p_use_register_epilogue(const F16PArgs& p) {
+    int mode = g_f16x3p_tr;
+    if (mode < 0) {
+        static int env = -2;
+        if (env == -2) { const char* e = getenv("PSAM_GEMM_TR"); env = e ? atoi(e) : 1; }
+        mode = env;
+    }
+    if (mode <= 0) return false;
+    if (p.rowbias || p.gmax_out || p.hyper || p.row_ln_g || p.no_store) return false;      // options only gemm_epilogue.h implements
+    if ((((uintptr_t)p.scaleW | (uintptr_t)p.bias | (uintptr_t)p.ln_c) & 15) != 0) return false;      // float4 loads of the column constants
+    return true;
+}
 
 // Tile configuration for a shape.  Measured per-CU rates of the configurations are within ~15 % of each other once a CU is busy
 // (profiles/r02_gemm_p_sweep_*.log; the kernel is power-limited, profiles/r02_gemm_power_limit.txt); what differs is how many rounds
@@ -410,10 +430,10 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
     return best;
 }
 
-template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0>
+template <int WM, int WN, int TM, int TN, int S, int LA, int ABL = 0, int PF = 0, int TR = 0>
 static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
-    constexpr int ring = S * (BM + BN) * 128, epi = NW * gemm_epilogue_lds_floats_per_wave<TN>() * 4;
+    constexpr int ring = S * (BM + BN) * 128, epi = TR ? 0 : NW * gemm_epilogue_lds_floats_per_wave<TN>() * 4;
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (TN % 2 != 0 && p.act == 3) {      // the SwiGLU gate pairs accumulator tiles (2q, 2q+1)
@@ -424,11 +444,11 @@ static int32_t launch_f16x3p(F16PArgs& p, hipStream_t stream) {
     p.tiles_n = (int)psam_cdiv(p.N, BN);
     p.panel = f16x3p_panel(p.tiles_m, p.tiles_n, BM, BN, p.K);
     static unsigned long long attr_done = 0;   // per device (bit = device id)
-    if (!f16x3p_reserve_lds(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>, lds, attr_done)) {
+    if (!f16x3p_reserve_lds(&gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF, TR>, lds, attr_done)) {
         psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
         return PSAM_EINVAL;
     }
-    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF>), dim3((unsigned)(p.tiles_m * p.tiles_n * p.ksplit)), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16x3p_kernel<WM, WN, TM, TN, S, LA, ABL, PF, TR>), dim3((unsigned)(p.tiles_m * p.tiles_n * p.ksplit)), dim3(64 * NW), lds, stream, p);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
@@ -632,7 +652,8 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         case 9: return launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);            // 128x128, 8 waves of 32x64, 4 stages + look-ahead fragments (128 KiB)
         case 12: return launch_f16x3p<4, 2, 2, 3, 2, 0>(p, stream);           // 256x192, 8 waves of 64x96, 2 stages (112 KiB); no SwiGLU epilogue
         case 14: return launch_f16x3p<4, 2, 2, 4, 2, 0>(p, stream);           // 256x256, 8 waves of 64x128, 2 stages (128 KiB)
-        case 21: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 4 waves, mid-slab stage release
+        case 21: return f16x3p_use_register_epilogue(p) ? launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2, 1>(p, stream)
+                                                        : launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 4 waves, mid-slab stage release
         case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);     // 256x192, mid-slab stage release
         case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 8 waves of 32x64, 2 stages, mid-slab release (70 KiB): 2 per CU
         // 30 / 31: three workgroups per CU.  Alone they win on the short launches (proj 38.4 -> 32.3 us, up.3 233 -> 205 us), in the pipelined

@@ -28,10 +28,11 @@
 #include "common.h"
 #include "gemm_f16x3p_args.h"
 #include "gemm_epilogue.h"
+#include "gemm_epilogue_t.h"
 
 // ABL (measurement builds, -DPSAM_GEMM_ABLATE): 1 = no epilogue, 2 = no DMA after the prologue, 4 = no MFMA, 16 = no fragment reads after
 // the first phase.
-template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0>
+template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0, int TR = 0>
 __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
     static_assert(GWM * WN == 4, "four waves per group");
     static_assert((P == 1 || P == 2) && S >= 2 * P && S - 2 * P <= 4, "phase = one or two k16 steps; ring of at least two phases");
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
     // the epilogue's operands (per-row inverse A scales / folded-LayerNorm statistics, the lane's column constants): loaded here, consumed
     // after the K loop
     // (not with two-step phases of the 128x64 wave tile: 128 accumulator + 96 fragment registers leave no room for them through the loop)
-    constexpr bool PREFETCH_EPI = !(P == 2 && TM * TN >= 8) && !CHUNKED;
+    constexpr bool PREFETCH_EPI = !(P == 2 && TM * TN >= 8) && !CHUNKED && !TR;
     EpPre<TM> epre;
     if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
     pf16x8 fa[P][TM][2], fw[P][TN][2];
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             if (ABL & 4) asm volatile("" ::"v"(fa[s][i][PA[term]]), "v"(fw[s][j][PW[term]]));
+                            else if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[s][j][PW[term]], fa[s][i][PA[term]], acc[i][j], 0, 0, 0);
                             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][i][PA[term]], fw[s][j][PW[term]], acc[i][j], 0, 0, 0);
                         }
             }
@@ -240,7 +242,9 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
         if (sum == 123.456f) p.C[0] = sum;
         return;
     }
-    if constexpr (CHUNKED) {
+    if constexpr (TR) {
+        gemm_store_tile_t<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
+    } else if constexpr (CHUNKED) {
         gemm_store_tile_chunked<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<2>(), m0 + wm * TM * 32,
                                                     n0 + wn * TN * 32, lane, p.C, p.residual);
     } else {
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
 #undef PP_WAITV
 }
 
-template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0>
+template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0, int TR = 0>
 static int32_t launch_pp(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = 2 * GWM * TM * 32, BN = WN * TN * 32;
     constexpr int ring = S * (BM + BN) * 64, epi = 8 * (TN > 4 ? gemm_epilogue_lds_floats_per_wave<2>() : gemm_epilogue_lds_floats_per_wave<TN>()) * 4;
@@ -271,11 +275,11 @@ static int32_t launch_pp(F16PArgs& p, hipStream_t stream) {
     p.tiles_n = (int)psam_cdiv(p.N, BN);
     p.panel = f16x3p_panel(p.tiles_m, p.tiles_n, BM, BN, p.K);
     static unsigned long long attr_done = 0;
-    if (!f16x3p_reserve_lds(&gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL>, lds, attr_done)) {
+    if (!f16x3p_reserve_lds(&gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL, TR>, lds, attr_done)) {
         psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
         return PSAM_EINVAL;
     }
-    hipLaunchKernelGGL((gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL, TR>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
@@ -356,15 +360,17 @@ int32_t launch_f16x3pp(int cfg, F16PArgs& p, hipStream_t stream) {
 #endif
     switch (cfg) {
         case 50: return launch_pp<1, 4, 4, 2, 5, 1, 1>(p, stream);      // 256x256, waves of 128x64, 5 units (160 KiB), priority around the MFMAs
-        case 51: return launch_pp<1, 4, 4, 2, 5, 1, 0>(p, stream);      //   no priority changes
+        case 51: return f16x3p_use_register_epilogue(p) ? launch_pp<1, 4, 4, 2, 5, 1, 0, 0, 1>(p, stream) : launch_pp<1, 4, 4, 2, 5, 1, 0>(p, stream);      //   no priority changes
         case 52: return launch_pp<1, 4, 4, 2, 5, 1, 2>(p, stream);      //   static priority for group 1
         case 59: return launch_pp<1, 4, 4, 2, 4, 1, 1>(p, stream);      //   4 units (128 KiB)
         case 60: return launch_pp<1, 4, 4, 2, 5, 2, 0>(p, stream);      //   two-step phases (48 MFMAs between barriers), 5 units
         case 61: return launch_pp<1, 4, 4, 2, 4, 2, 0>(p, stream);      //   two-step phases, 4 units
         case 53: return launch_pp<2, 2, 2, 4, 5, 1, 1>(p, stream);      // 256x256, waves of 64x128
-        case 55: return launch_pp<2, 2, 2, 2, 6, 2, 1>(p, stream);      // 256x128, waves of 64x64, 6 units (144 KiB), two-step phases (24 MFMAs)
+        case 55: return f16x3p_use_register_epilogue(p) ? launch_pp<2, 2, 2, 2, 6, 2, 1, 0, 1>(p, stream)
+                                                        : launch_pp<2, 2, 2, 2, 6, 2, 1>(p, stream);      // 256x128, waves of 64x64, 6 units (144 KiB), two-step phases (24 MFMAs)
         case 56: return launch_pp<2, 2, 2, 2, 6, 1, 1>(p, stream);      //   one-step phases (12 MFMAs)
-        case 57: return launch_pp<2, 2, 1, 2, 8, 2, 1>(p, stream);      // 128x128, waves of 32x64, 8 units (128 KiB), two-step phases (12 MFMAs)
+        case 57: return f16x3p_use_register_epilogue(p) ? launch_pp<2, 2, 1, 2, 8, 2, 1, 0, 1>(p, stream)
+                                                        : launch_pp<2, 2, 1, 2, 8, 2, 1>(p, stream);      // 128x128, waves of 32x64, 8 units (128 KiB), two-step phases (12 MFMAs)
         case 58: return launch_pp<2, 2, 1, 2, 4, 2, 1>(p, stream);      //   4 units (64 KiB): two workgroups per CU
         // right-sized tiles (round 4): eight waves of 32 rows x the whole tile width, so that a launch's tiles fill #CU - 8 workgroup slots in whole rounds
         case 62: return launch_pp<4, 1, 1, 7, 5, 1, 1>(p, stream);      // 256x224 (150 KiB): qkv 4096x3072 = 224 tiles, one round
