@@ -171,9 +171,11 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
                 const float mean = nv > 0 ? sm / (float)nv : 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    s[g] = 0.f;
+                    float d[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = (ocol + 8 * g + e < p.stat_cols) ? v[g][e] - mean : 0.f; s[g] = __builtin_fmaf(d, d, s[g]); }
+                    for (int e = 0; e < 4; ++e) d[e] = (ocol + 8 * g + e < p.stat_cols) ? v[g][e] - mean : 0.f;
+                    // the order hipcc gives gemm_epilogue.h's `m2 += d * d` chain (contraction on): d1^2 first, then fused adds of d0^2, d2^2, d3^2
+                    s[g] = __builtin_fmaf(d[3], d[3], __builtin_fmaf(d[2], d[2], __builtin_fmaf(d[0], d[0], d[1] * d[1])));
                 }
                 const float m2 = ept_segment_sum(s[0], s[1], s[2], s[3]);
                 if (h == 0) {
