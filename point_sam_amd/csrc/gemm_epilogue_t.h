@@ -16,7 +16,8 @@
 //
 // Options covered (what the encoder / decoder hot path launches): bias, alpha, GELU / ReLU, SwiGLU gate (act == 3, column tiles (2q, 2q+1)),
 // residual, folded LayerNorm (ln_c / ln_mean / ln_rstd), packed output (pack_out with out_k1 / out_k2 or out_bound), row statistics (stats).
-// Not covered (the host keeps gemm_epilogue.h for those launches): rowbias, group maximum, hyper products, full-row LayerNorm, no_store.
+// hyper products of 64-column wave tiles (TN == 2; N / 64 partial planes) with or without storing the activation (no_store).
+// Not covered (the host keeps gemm_epilogue.h for those launches): rowbias, group maximum, full-row LayerNorm / full-row hyper products.
 // Store pattern: a wave instruction writes 32 rows x 2 x 16 B (32 B contiguous per row for fp32 outputs, 2 x 16 B 32 B apart for packed
 // ones); the four instructions of a tile complete each row's 128-byte line in L2.
 #pragma once
@@ -93,6 +94,15 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
     }
     const bool o_lnc = F < 0 ? p.ln_c != nullptr : bool(F & EP_LNC), o_pack = F < 0 ? p.pack_out != 0 : bool(F & EP_PACK);
     const bool o_bnd = F < 0 ? (o_pack && !o_lnc && p.out_bound != nullptr) : bool(F & EP_BND), o_stats = swiglu && (F < 0 ? p.stats != nullptr : bool(F & EP_STATS));
+    // hyper-network products (mask_decoder.py:171-176): masks[z, c, n] = sum_e hyper[z, c, e] out[z * hyper_rows + n, e] over this wave's TN * 32 columns -> plane
+    // col_base / (TN * 32) of the partial sums (psam_sum_planes adds the planes in a fixed order).  A row lives in a lane pair (lane, lane + 32): in-lane
+    // fused multiply-adds in column order of the lane's runs, ONE half-wave exchange per product.  hyper_rows % 32 == 0: one z per 32-row tile.
+    const bool o_hyper = !swiglu && (F < 0 ? p.hyper != nullptr : bool(F & EP_HYPER)), o_nostore = F < 0 ? p.no_store != 0 : bool(F & EP_NOSTORE);
+    float dot[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) dot[i][cc] = 0.f;
     // ---- per-row operands: the lane's own rows
     float rsq[TM], lmean[TM], lrstd[TM], so[TM];
 #pragma unroll
@@ -187,6 +197,21 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
 #pragma unroll
                 for (int g = 0; g < 4; ++g) v[g] += res[g];
             }
+            if (o_hyper) {
+                const int z = (row_base + i * 32) / p.hyper_rows;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    if (cc < p.hyper_c) {
+                        const float* hb = p.hyper + ((int64_t)z * p.hyper_c + cc) * p.N + pcol;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const ep_f32x4 hv = ep_load4(hb + 8 * g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dot[i][cc] = __builtin_fmaf(v[g][e], hv[e], dot[i][cc]);
+                        }
+                    }
+            }
+            if (o_nostore) continue;
             if (o_pack) {
                 // runs (2 g', 2 g' + 1) of the two half-waves -> column groups 8 (2 g' + h) .. + 7 of this lane: [hi x 8 | lo x 8] = 32 contiguous bytes
 #pragma unroll
@@ -208,6 +233,19 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
             }
         }
     }
+    if (o_hyper) {
+        float* mk = p.masks + (int64_t)(col_base / (TN * 32)) * p.hyper_pstride;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = row_base + i * 32, z = row0 / p.hyper_rows, n0 = row0 - z * p.hyper_rows;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float a = dot[i][cc], b = dot[i][cc];
+                ept_swap32f(a, b);                               // a = {lo: own, hi: lower half's}, b = {lo: upper half's, hi: own}
+                if (cc < p.hyper_c && h == 0) mk[((int64_t)z * p.hyper_c + cc) * p.hyper_rows + n0 + r32] = a + b;
+            }
+        }
+    }
 }
 
 // Dispatch on the launch's option set (wave-uniform): the combinations the model's GEMMs use run a specialised instance.
@@ -217,7 +255,8 @@ __device__ __forceinline__ void gemm_store_tile_t(const ArgsT& p, ep_f32x16 (&ac
     const bool interior = gemm_epilogue_interior<TM, TN>(p, row_base, col_base, C, R);      // wave-uniform
     const bool swiglu = (TN % 2 == 0) && p.act == 3;
     const int opt = (swiglu ? EP_SWIGLU : 0) | ((R && !swiglu) ? EP_RES : 0) | (!swiglu && p.act == 1 ? EP_GELU : 0) | (!swiglu && p.act == 2 ? EP_RELU : 0) |
-                    ((swiglu && p.stats) ? EP_STATS : 0) | (p.pack_out ? EP_PACK : 0) | (p.ln_c ? EP_LNC : 0) | ((p.pack_out && !p.ln_c && p.out_bound) ? EP_BND : 0);
+                    ((swiglu && p.stats) ? EP_STATS : 0) | (p.pack_out ? EP_PACK : 0) | (p.ln_c ? EP_LNC : 0) | ((p.pack_out && !p.ln_c && p.out_bound) ? EP_BND : 0) |
+                    ((p.hyper && !swiglu) ? EP_HYPER : 0) | (p.no_store ? EP_NOSTORE : 0);
     using std::integral_constant;
 #define EPT_CASE(Fv) if (opt == (Fv)) return gemm_store_tile_t_impl<TM, TN, (Fv)>(p, acc, row_base, col_base, lane, C, R, interior)
     if (interior) {
@@ -226,6 +265,7 @@ __device__ __forceinline__ void gemm_store_tile_t(const ArgsT& p, ep_f32x16 (&ac
         EPT_CASE(EP_PACK);                                      // qkv, packed for the attention kernel
         EPT_CASE(EP_LNC | EP_RES);                              // fc2 with the folded LayerNorm
         EPT_CASE(EP_GELU);
+        if constexpr (TN == 2) { EPT_CASE(EP_GELU | EP_HYPER | EP_NOSTORE); }      // last Linear of the upscaling MLP + the hyper products
         if constexpr (TN % 2 == 0) {
             EPT_CASE(EP_SWIGLU | EP_STATS | EP_PACK | EP_BND);  // fc1 of the fused EVA02 MLP
             EPT_CASE(EP_SWIGLU | EP_STATS | EP_PACK);

@@ -565,6 +565,70 @@ def test_fused_mlp_bitwise_stable_beside_other_streams(ops):
             L.psam_gemm_f16x3p_force_config(-1)
 
 
+def test_gemm_f16x3_register_epilogue_bitwise(ops):
+    """The register-only GEMM epilogue (csrc/gemm_epilogue_t.h: MFMA operands swapped, one output row per lane, no LDS transposition, no lane
+    shuffles) must give the SAME BITS as the LDS-transposition epilogue (csrc/gemm_epilogue.h) for every fused option set of the encoder's
+    GEMMs at the benchmark's size -- packed q|k|v, projection + residual, fc1 (SwiGLU gate + row statistics + packed output), fc2 with the
+    folded LayerNorm -- and for ragged shapes (edge tiles); the hyper-network products (different summation order) agree to rounding and
+    with fp64 (mask_decoder.py:171-176).  timm Eva block shapes as restated in oracle/pointsam_oracle.py (pc_encoder.py:138-139)."""
+    L = ops._lib.load()
+    g = torch.Generator().manual_seed(0)
+    M, D, H = 4096, 1024, 2730
+    Hp = (H + 31) // 32 * 32
+    h = torch.randn(M, D, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))
+    W1 = torch.randn(2 * Hp, D, generator=g) / 32
+    b1 = cu(torch.randn(2 * Hp, generator=g) * 0.1)
+    w2g = torch.randn(D, Hp, generator=g) / 52
+    ln_c, ln_d, res = cu(w2g.sum(1)), cu(torch.randn(D, generator=g) * 0.1), cu(torch.randn(M, D, generator=g))
+    k1, k2 = float(2.0 ** 15 * math.sqrt(D) * W1.double().norm(dim=1).max()), float(b1.abs().max())
+    fw1, fw2g = ops.F16Weight(cu(W1)), ops.F16Weight(cu(w2g))
+    wq, bq = ops.F16Weight(cu(torch.randn(3 * D, D, generator=g) / 32)), cu(torch.randn(3 * D, generator=g) * 0.1)
+    wp = ops.F16Weight(cu(torch.randn(D, D, generator=g) / 32))
+    xr, wr, br, rr = cu(torch.randn(777, 260, generator=g)), ops.F16Weight(cu(torch.randn(392, 260, generator=g) / 16)), cu(torch.randn(392, generator=g)), cu(torch.randn(777, 392, generator=g))
+    # upscaling MLP tail: Linear + GELU + hyper products over [Z * N, 256]
+    Z, Npts, C, E = 2, 4096, 3, 256
+    u1 = torch.randn(Z * Npts, E, generator=g)
+    w3, b3, hyper = torch.randn(E, E, generator=g) / 16, torch.randn(E, generator=g) * 0.1, torch.randn(Z, C, E, generator=g)
+    fw3 = ops.F16Weight(cu(w3))
+    want_masks = torch.einsum("zce,zne->zcn", hyper.double(), F.gelu(u1.double() @ w3.double().T + b3.double()).view(Z, Npts, E))
+    out = {}
+    try:
+        with ops.gemm_mode("f16x3"):
+            hp, sh = ops.scale_pack_rows_g8(cu(h))
+            u1p, s1 = ops.scale_pack_rows_g8(cu(u1))
+            for ep in (0, 1):
+                L.psam_gemm_f16x3p_force_epilogue(ep)
+                up = torch.empty(M, Hp, device="cuda"); su = torch.empty(M, device="cuda"); st = torch.empty(M, ops.stat_segs(2 * Hp), 2, device="cuda")
+                ops.linear(hp, fw1, b1, act=ops.ACT_SWIGLU, x_scale=sh, x_packed=True, out=up, pack_out=(su, k1, k2), stats=(st, H))
+                o = dict(up=up, su=su, st=st[:, :(H + 31) // 32].contiguous())
+                if ep == 0:
+                    up0, su0 = up, su
+                    mean0, rstd0 = ops.ln_stats_finalize(st, H, 1e-6)
+                o["fc2"] = ops.linear(up0, fw2g, ln_d, residual=res, x_scale=su0, x_packed=True, ln_fold=(mean0, rstd0, ln_c))
+                sq = torch.empty(M, device="cuda"); qo = torch.empty(M, 3 * D, device="cuda")
+                ops.linear(hp, wq, bq, x_scale=sh, x_packed=True, out=qo, pack_out=(sq, 0.0, 50.0))
+                o["qkv_packed"], o["qkv_scale"] = qo, sq
+                o["proj"] = ops.linear(hp, wp, bq[:D].contiguous(), residual=res, x_scale=sh, x_packed=True)
+                o["gelu"] = ops.linear(hp, wp, bq[:D].contiguous(), act=ops.ACT_GELU, x_scale=sh, x_packed=True)
+                o["ragged_gelu_res"] = ops.linear(xr, wr, br, act=ops.ACT_GELU, residual=rr)
+                o["ragged_plain"] = ops.linear(xr, wr, None)
+                masks = torch.empty(Z, C, Npts, device="cuda")
+                ops.linear(u1p, fw3, cu(b3), act=ops.ACT_GELU, x_scale=s1, x_packed=True, hyper=(cu(hyper), masks, Npts), no_store=True)
+                o["masks"] = masks
+                out[ep] = o
+            torch.cuda.synchronize()
+    finally:
+        L.psam_gemm_f16x3p_force_epilogue(-1)
+    for k in out[0]:
+        a, b = out[0][k], out[1][k]
+        if k == "masks":
+            for t in (a, b):
+                assert ((t.cpu().double() - want_masks).abs().max() / want_masks.abs().max()).item() < 2e-6
+            assert ((a - b).abs().max() / a.abs().max()).item() < 2e-6
+        else:
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{k}: {(a.view(torch.int32) != b.view(torch.int32)).sum().item()} words differ"
+
+
 def test_gemm_row_epilogues_upscaling_chain(ops):
     """The decoder's upscaling MLP inside GEMM epilogues (N = 256: a wave owns whole rows): Linear -> LayerNorm -> GELU with the result
     packed against the LayerNorm's bound, then Linear -> GELU -> hyper-network dot products, against fp64 (mask_decoder.py:53-59,164-176)."""
