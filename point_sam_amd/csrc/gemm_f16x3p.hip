@@ -580,7 +580,10 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         PSAM_REQUIRE(((uintptr_t)fuse->hyper & 15) == 0, PSAM_EALIGN, "psam_gemm_f16x3p_ex: 16-byte alignment");
         p.hyper = fuse->hyper; p.masks = fuse->masks; p.hyper_c = fuse->hyper_c; p.hyper_rows = fuse->hyper_rows; p.hyper_pstride = fuse->hyper_pstride;
         p.no_store = fuse->no_store;
-        if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
+        // The register epilogue sums a row's products in another order than the LDS epilogue (same accuracy, other rounding): ONE configuration for every
+        // M, so that a cloud's logits do not depend on how many clouds share the launch (tests/test_gpu_e2e.py::test_properties_full_size).
+        if (g_f16x3p_cfg < 0 && f16x3p_use_register_epilogue(p)) cfg = 21;
+        else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
     } else if (fuse && (fuse->row_ln_g || fuse->hyper)) {
         // full-row epilogues: a wave owns whole rows of N == 256 columns (128x256 tiles, four waves of 32 rows)
         PSAM_REQUIRE(N == 256 && (M & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm / hyper products need N == 256, M % 128 == 0");

@@ -37,7 +37,21 @@ class TokenizerState:
     extra: Optional[dict] = None  # model variants (point_sam_amd/variants.py): e.g. the hier model's level-1 groups
 
     def tensors(self):
-        return (self.fps_idx, self.centers, self.knn_idx, self.interp_index, self.interp_weight)
+        """Every device tensor of the state (for stream bookkeeping): the fixed fields that are present plus the tensors inside `extra`
+        (nested tuples / lists included)."""
+        out = [t for t in (self.fps_idx, self.centers, self.knn_idx, self.interp_index, self.interp_weight) if t is not None]
+
+        def walk(v):
+            if isinstance(v, torch.Tensor):
+                out.append(v)
+            elif isinstance(v, (tuple, list)):
+                for u in v:
+                    walk(u)
+            elif isinstance(v, dict):
+                for u in v.values():
+                    walk(u)
+        walk(self.extra)
+        return tuple(out)
 
 
 @dataclass
@@ -406,7 +420,8 @@ class PointCloudSAM:
         pc_emb = self._lin("pc_encoder.out_proj", h).view(B, G, E)
         pc_pe = torch.empty(B, G, E, device=self.device)
         ops.fourier_pe(centers, w["point_encoder.pe_layer.positional_encoding_gaussian_matrix"], pc_pe, G, G * E, flag=self._flag)
-        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1), tok.interp_index, tok.interp_weight, tok.extra)
+        return EncoderState(coords, features, pc_emb, pc_pe, centers, knn_idx, fps_idx, emb.view(B, G, -1), tok.interp_index, tok.interp_weight,
+                            dict(tok.extra) if tok.extra is not None else None)      # the state owns its copy: a variant's encode() adds entries (level-1 embeddings)
 
     def _patch_tokens(self, coords, features, tok):
         """PatchEmbed.forward after the grouping (pc_encoder.py:36-41) -> [B*G, patch_out]; the model variants override this."""

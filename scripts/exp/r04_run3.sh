@@ -2,7 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider > $O/r04_pytest_gpu_a.log 2>&1; echo "pytest exit $?"
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/r04_pytest_gpu_a.log 2>&1; echo "pytest exit $?"
 tail -15 $O/r04_pytest_gpu_a.log
 for m in 0 1; do
   PSAM_GEMM_TR=$m timeout 300 python bench.py --no-cpu-baseline --sustained-steps 100 > $O/r04_bench3_tr${m}.json 2> $O/r04_bench3_tr${m}.err; echo "bench tr$m exit $?"

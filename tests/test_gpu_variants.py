@@ -142,3 +142,39 @@ def test_scatter_amax_and_group_feats_kernels(build):
     logits = torch.randn(B * 2, N, generator=g)
     m = ops.nn_group_feats(xyz.cuda(), centers.cuda(), nn.cuda(), logits=logits.cuda(), width=8).cpu().view(B * 2, N, 8)
     torch.testing.assert_close(m[..., :5], torch.cat([logits.unsqueeze(-1), nbr.repeat_interleave(2, 0), dist.repeat_interleave(2, 0)], -1), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("dense_streams", [1, 2])
+@pytest.mark.parametrize("name", ["tiny_hier", "tiny_voronoi"])
+def test_variants_through_batch_pipeline(build, name, dense_streams):
+    """The variants through BatchPipeline (tokenizer on its own stream, several batches in flight): results bit-identical to predict_masks.
+    The hier tokenizer state carries its level-1 tensors in `extra` and leaves the interpolation fields empty (TokenizerState.tensors must
+    cover the first and skip the second); an EncoderState owns its own copy of `extra` (a later encode() on the same tokenizer state must
+    not replace the level-1 embeddings an earlier state decodes with)."""
+    from point_sam_amd.model import BatchPipeline
+    cfg = get_config(name)
+    model = build(cfg, random_state_dict(cfg, seed=5), "cuda", precision="f16x3")
+    batches = []
+    for i in range(5):
+        xyz, rgb, prompt, labels = O.synthetic_batch(2, 1500 + 300 * i, seed=60 + i)
+        batches.append(tuple(t.cuda() for t in (xyz, rgb, prompt, labels)))
+    want = [model.predict_masks(*b) for b in batches]
+    pipe = BatchPipeline(model, dense_streams=dense_streams)
+    got = []
+    for k in range(min(pipe.depth, len(batches))):
+        pipe.submit(*batches[k])
+    for k in range(len(batches)):
+        if k + pipe.depth < len(batches):
+            pipe.submit(*batches[k + pipe.depth])
+        got.append(pipe.next())
+    torch.cuda.synchronize()
+    for k, ((m1, i1), (m2, i2)) in enumerate(zip(want, got)):
+        assert torch.equal(m1, m2) and torch.equal(i1, i2), (k, _err(m1, m2), _err(i1, i2))
+    # two encoder states from ONE tokenizer state: the first keeps decoding with its own level-1 embeddings
+    xyz, rgb, prompt, labels = batches[0]
+    tok = model.tokenize(xyz)
+    st1 = model.encode(xyz, rgb, tok)
+    ref = model.decode(st1, prompt, labels, None, True)
+    model.encode(xyz, rgb.flip(0).contiguous(), tok)          # different features through the same tokenizer state
+    again = model.decode(st1, prompt, labels, None, True)
+    assert torch.equal(ref[0], again[0]) and torch.equal(ref[1], again[1])
