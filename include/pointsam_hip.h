@@ -143,6 +143,9 @@ void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring con
  * launch's options allow it, 0 = always the LDS-transposition epilogue (csrc/gemm_epilogue.h), -1 = default (environment PSAM_GEMM_TR, else 1).
  * Both give the same bits; the hook exists for A/B measurements and the bitwise test. */
 void psam_gemm_f16x3p_force_epilogue(int32_t mode);
+/* 1 when psam_gemm_f16x3p_ex accepts psam_gemm_fuse_t.row_ln_* for N output columns (Linear -> LayerNorm -> activation in one GEMM; common.py:493-496,
+ * mask_decoder.py:53-59): N == 256 always, N == 512 with the register epilogue (packed output scaled by the a-priori bound out_k2, out_k1 == 0). */
+int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N);
 /* The same GEMM with fused extras (all optional; M % 256 == 0 and N % 128 == 0 required when any is used) -- what lets the EVA02 MLP
  * `fc2(LayerNorm(SiLU(fc1_g x) * fc1_x x))` (timm SwiGLU with scale_mlp) run as two GEMMs and nothing in between:
  *   pack_out : C receives the g8-packed output rows (the next GEMM's A operand), scaled per row by out_scale[row] (written here) =
@@ -283,7 +286,7 @@ typedef struct {
 } psam_patch_encoder_weights_t;
 typedef struct {
     int32_t cin, h0, h1, cout;
-    float eps, k1, k2;
+    float eps, k1, k2, ln21_bound;      /* ln21_bound >= max |gamma| sqrt(h1) + max |beta| of conv2.1: scale of the rows the fused conv2.0 GEMM packs */
     const float *c10_w, *c10_b, *c11_w, *c11_b, *c13_b, *c20_w, *c20_b, *c21_w, *c21_b, *c23_b;
     int64_t o_w13, o_s13, o_w20m, o_s20m, o_w20x, o_s20x, o_w23, o_s23;
 } psam_patch_encoder_plan_t;

@@ -44,6 +44,7 @@ SIGNATURES = {
     "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
+    "psam_gemm_f16x3p_fused_row_ln": (i32, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
     "psam_gemm_f16x3p_splitk": (i32, [i32, i32, i32, i32]),
     "psam_nn_group_feats": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, i64, ptr]),
@@ -121,7 +122,7 @@ class PatchEncoderWeights(ctypes.Structure):
 
 class PatchEncoderPlan(ctypes.Structure):
     """psam_patch_encoder_plan_t (include/pointsam_hip.h)."""
-    _fields_ = ([(n, i32) for n in ("cin", "h0", "h1", "cout")] + [(n, f32) for n in ("eps", "k1", "k2")] +
+    _fields_ = ([(n, i32) for n in ("cin", "h0", "h1", "cout")] + [(n, f32) for n in ("eps", "k1", "k2", "ln21_bound")] +
                 [(n, ptr) for n in ("c10_w", "c10_b", "c11_w", "c11_b", "c13_b", "c20_w", "c20_b", "c21_w", "c21_b", "c23_b")] +
                 [(n, i64) for n in ("o_w13", "o_s13", "o_w20m", "o_s20m", "o_w20x", "o_s20x", "o_w23", "o_s23")])
 

@@ -253,6 +253,14 @@ PSAM_API int32_t psam_patch_encoder_prepare(const psam_patch_encoder_weights_t* 
     plan->cin = cin; plan->h0 = h0; plan->h1 = h1; plan->cout = cout; plan->eps = wt->eps;
     plan->k1 = (float)(32768.0 * std::sqrt((double)h0) * nmax);      // |conv1.3 row| <= k1 / scale(input row) + k2 (psam_gemm_fuse_t)
     plan->k2 = (float)bmax;
+    {   // conv2.1's LayerNorm output: |(x - mean) rstd gamma + beta| <= max |gamma| sqrt(h1) + max |beta| (GELU only shrinks it)
+        std::vector<float> g21(h1), b21(h1);
+        PSAM_REQUIRE(hipMemcpy(g21.data(), wt->c21_w, (size_t)h1 * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(b21.data(), wt->c21_b, (size_t)h1 * 4, hipMemcpyDeviceToHost) == hipSuccess,
+                     PSAM_EINVAL, "psam_patch_encoder_prepare: cannot read conv2.1");
+        double gm = 0.0, bm = 0.0;
+        for (int n = 0; n < h1; ++n) { gm = std::fmax(gm, std::fabs((double)g21[n])); bm = std::fmax(bm, std::fabs((double)b21[n])); }
+        plan->ln21_bound = (float)(1.001 * (gm * std::sqrt((double)h1) + bm) + 1e-30);
+    }
     plan->c10_w = wt->c10_w; plan->c10_b = wt->c10_b; plan->c11_w = wt->c11_w; plan->c11_b = wt->c11_b; plan->c13_b = wt->c13_b; plan->c20_w = wt->c20_w;
     plan->c20_b = wt->c20_b; plan->c21_w = wt->c21_w; plan->c21_b = wt->c21_b; plan->c23_b = wt->c23_b;
     Carve cv(prepared);
@@ -323,10 +331,18 @@ PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const
         rc = psam_linear(y1, h0, plan->c20_w, 2 * h0, plan->c20_b, nullptr, 0, g1, h1, (int32_t)groups, h1, h0, 0, stream);
     }
     if (rc) return rc;
-    rc = psam_gemm_f16x3p_ex(x2, a, s2, P(plan->o_w20x), a, P(plan->o_s20x), x3, h1, nullptr, nullptr, 0, g1, h1, K, (int32_t)rows, h1, a, 1.f, 0, nullptr, stream);
-    if (rc) return rc;
-    rc = psam_layernorm_ex(x3, h1, nullptr, 0, plan->c21_w, plan->c21_b, x3, b, rows, h1, plan->eps, PSAM_ACT_GELU, rs, 1, stream);
-    if (rc) return rc;
+    if (h1 == 512 && rows % 128 == 0 && psam_gemm_f16x3p_fused_row_ln(h1)) {
+        // conv2.0 -> LayerNorm -> GELU in ONE GEMM on full-row 128x512 tiles (register epilogue): packed rows out, scaled by the LayerNorm's a-priori bound
+        std::memset(&f, 0, sizeof(f));
+        f.row_ln_g = plan->c21_w; f.row_ln_b = plan->c21_b; f.row_ln_eps = plan->eps; f.pack_out = 1; f.out_scale = rs; f.out_k1 = 0.f; f.out_k2 = plan->ln21_bound;
+        rc = psam_gemm_f16x3p_ex(x2, a, s2, P(plan->o_w20x), a, P(plan->o_s20x), x3, b, nullptr, nullptr, 0, g1, h1, K, (int32_t)rows, h1, a, 1.f, PSAM_ACT_GELU, &f, stream);
+        if (rc) return rc;
+    } else {
+        rc = psam_gemm_f16x3p_ex(x2, a, s2, P(plan->o_w20x), a, P(plan->o_s20x), x3, h1, nullptr, nullptr, 0, g1, h1, K, (int32_t)rows, h1, a, 1.f, 0, nullptr, stream);
+        if (rc) return rc;
+        rc = psam_layernorm_ex(x3, h1, nullptr, 0, plan->c21_w, plan->c21_b, x3, b, rows, h1, plan->eps, PSAM_ACT_GELU, rs, 1, stream);
+        if (rc) return rc;
+    }
     std::memset(&f, 0, sizeof(f));
     f.gmax_out = part2; f.gmax_ld = cout; f.gmax_k = Kp; f.no_store = 1;
     rc = psam_gemm_f16x3p_ex(x3, b, rs, P(plan->o_w23), b, P(plan->o_s23), out, cout, plan->c23_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, cout, b, 1.f, 0, &f, stream);

@@ -275,3 +275,132 @@ __device__ __forceinline__ void gemm_store_tile_t(const ArgsT& p, ep_f32x16 (&ac
 #undef EPT_CASE
     gemm_store_tile_t_impl<TM, TN, -1>(p, acc, row_base, col_base, lane, C, R, interior);
 }
+
+// Full-row variant for workgroup tiles that span ALL N columns (N = WN * TN * 32: the 128x512 ping-pong tile of PatchEncoder's conv2.0): the
+// epilogue applies `Linear -> LayerNorm -> activation` (common.py:493-496: conv2.0 -> conv2.1 LayerNorm -> GELU) to whole rows and writes them
+// g8-packed for the next GEMM, so the [rows, N] fp32 activation (537 MB at the benchmark's size) and the separate LayerNorm pass over it never
+// exist.  A row lives in one lane pair per wave and in the WN waves of its row band: two-pass statistics (mean, then centred squares) with
+// in-lane sums, one half-wave exchange and a WN-way exchange through `red` (LDS, 2 * WN * BM floats; the K loop's ring is dead by now), each in a
+// fixed order.  Options: bias, row bias per group of rows (rowgroup % 32 == 0: one bias row per 32-row tile), GELU / ReLU / none, packed output
+// with the a-priori scale f16_row_scale(out_k2) (out_k2 >= max |gamma| sqrt(N) + max |beta| bounds every LayerNorm output, hence its GELU).
+// Interior tiles only (M % BM == 0; the host checks).  Every wave of the workgroup must call it (two __syncthreads).
+template <int TM, int TN, int WN, typename ArgsT>
+__device__ __forceinline__ void gemm_store_tile_t_rowln(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], float* __restrict__ red, int BM, int row_base, int tile_row,
+                                                        int wn, int lane, float* __restrict__ C) {
+#pragma clang fp contract(off)
+    const int r32 = lane & 31, h = lane >> 5;
+    const int col_base = wn * TN * 32;
+    float rsq[TM], sum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { rsq[i] = inv_pow2(p.scaleA[row_base + i * 32 + r32]); sum[i] = 0.f; }
+    // ---- pass A: finished pre-LayerNorm values in place, row sums
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pcol = col_base + j * 32 + 4 * h;
+        ep_f32x4 m[4], b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const ep_f32x4 sw = ep_load4(p.scaleW + pcol + 8 * g);
+            b[g] = p.bias ? ep_load4(p.bias + pcol + 8 * g) : ep_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[g][e] = p.alpha * inv_pow2(sw[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ep_f32x4 rb[4];
+            if (p.rowbias) {
+                const float* rbp = p.rowbias + (int64_t)((row_base + i * 32) / p.rowgroup) * p.ldrb + pcol;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rb[g] = ep_load4(rbp + 8 * g);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(acc[i][j][4 * g + e] * rsq[i], m[g][e], b[g][e]);
+                    if (p.rowbias) a += rb[g][e];
+                    acc[i][j][4 * g + e] = a;
+                    sum[i] += a;
+                }
+        }
+    }
+    // row totals: lane pair, then the WN waves of the row band (fixed order)
+    float* red2 = red + WN * BM;
+    float mean[TM], rstd[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float a = sum[i], b = sum[i];
+        ept_swap32f(a, b);
+        sum[i] = h == 0 ? a + b : b + a;                         // lower half's partial + upper half's, in both halves
+        if (h == 0) red[wn * BM + tile_row + i * 32 + r32] = sum[i];
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)(WN * TN * 32);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) t += red[w * BM + tile_row + i * 32 + r32];
+        mean[i] = t * inv_n;
+    }
+    // ---- pass B: centred squares
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[i][j][r] - mean[i]; q = __builtin_fmaf(d, d, q); }
+        float a = q, b = q;
+        ept_swap32f(a, b);
+        q = h == 0 ? a + b : b + a;
+        if (h == 0) red2[wn * BM + tile_row + i * 32 + r32] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) t += red2[w * BM + tile_row + i * 32 + r32];
+        rstd[i] = 1.0f / sqrtf(t * inv_n + p.row_ln_eps);
+    }
+    // ---- pass C: normalise, activate, pack, store
+    const float so = f16_row_scale(p.out_k2);
+    if (h == 0 && wn == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) p.out_scale[row_base + i * 32 + r32] = so;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pcol = col_base + j * 32 + 4 * h;
+        ep_f32x4 gm[4], bt[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gm[g] = ep_load4(p.row_ln_g + pcol + 8 * g); bt[g] = ep_load4(p.row_ln_b + pcol + 8 * g); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = row_base + i * 32 + r32;
+            ep_f32x4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[g][e] = ep_act(__builtin_fmaf((acc[i][j][4 * g + e] - mean[i]) * rstd[i], gm[g][e], bt[g][e]), p.act);
+            if (p.pack_out) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned xh[2], xl[2], yh[2], yl[2];
+                    psam_split2_f16(v[2 * gp][0], v[2 * gp][1], so, xh[0], xl[0]);
+                    psam_split2_f16(v[2 * gp][2], v[2 * gp][3], so, xh[1], xl[1]);
+                    psam_split2_f16(v[2 * gp + 1][0], v[2 * gp + 1][1], so, yh[0], yl[0]);
+                    psam_split2_f16(v[2 * gp + 1][2], v[2 * gp + 1][3], so, yh[1], yl[1]);
+                    ept_swap32(xh[0], yh[0]); ept_swap32(xh[1], yh[1]); ept_swap32(xl[0], yl[0]); ept_swap32(xl[1], yl[1]);
+                    unsigned* dst = reinterpret_cast<unsigned*>(C) + (int64_t)row * p.ldc + col_base + j * 32 + 16 * gp + 8 * h;
+                    *reinterpret_cast<ept_u32x4*>(dst) = ept_u32x4{xh[0], xh[1], yh[0], yh[1]};
+                    *reinterpret_cast<ept_u32x4*>(dst + 4) = ept_u32x4{xl[0], xl[1], yl[0], yl[1]};
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<ep_f32x4*>(C + (int64_t)row * p.ldc + pcol + 8 * g) = v[g];
+            }
+        }
+    }
+}

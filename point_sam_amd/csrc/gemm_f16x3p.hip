@@ -375,6 +375,18 @@ PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
 // options allow it, 0 = always the LDS-transposition epilogue (gemm_epilogue.h), -1 = the default (environment PSAM_GEMM_TR, else 1).
 static int g_f16x3p_tr = -1;
 PSAM_API void psam_gemm_f16x3p_force_epilogue(int32_t mode) { g_f16x3p_tr = mode; }
+static int f16x3p_epilogue_mode() {
+    int mode = g_f16x3p_tr;
+    if (mode < 0) {
+        static int env = -2;
+        if (env == -2) { const char* e = getenv("PSAM_GEMM_TR"); env = e ? atoi(e) : 1; }
+        mode = env;
+    }
+    return mode;
+}
+// Whether psam_gemm_f16x3p_ex takes psam_gemm_fuse_t.row_ln_* (Linear -> LayerNorm -> activation in one GEMM) for N output columns: 256 always
+// (full-row wave tiles, LDS epilogue), 512 with the register epilogue (128x512 workgroup tiles).
+PSAM_API int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N) { return N == 256 || (N == 512 && f16x3p_epilogue_mode() > 0) ? 1 : 0; }
 bool f16x3p_use_register_epilogue(const F16PArgs& p) {
     int mode = g_f16x3p_tr;
     if (mode < 0) {
@@ -584,6 +596,20 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         // M, so that a cloud's logits do not depend on how many clouds share the launch (tests/test_gpu_e2e.py::test_properties_full_size).
         if (g_f16x3p_cfg < 0 && f16x3p_use_register_epilogue(p)) cfg = 21;
         else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
+    } else if (fuse && fuse->row_ln_g && N == 512) {
+        // full-row tile 128x512 on the ping-pong kernel with the register epilogue: Linear (+ row bias per group) -> LayerNorm -> activation -> packed rows
+        PSAM_REQUIRE(psam_gemm_f16x3p_fused_row_ln(N), PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm over N == 512 needs the register epilogue (psam_gemm_f16x3p_fused_row_ln)");
+        PSAM_REQUIRE((M & 127) == 0 && act != 3 && fuse->row_ln_b && !fuse->hyper && !fuse->stats && !fuse->ln_c && !fuse->gmax_out && !fuse->no_store && !residual, PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: row LayerNorm over N == 512 needs M % 128 == 0 and combines only with bias / rowbias / activation / packed output");
+        PSAM_REQUIRE(!rowbias || ((p.rowgroup & 31) == 0 && (ldrb & 3) == 0 && ((uintptr_t)rowbias & 15) == 0), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: row LayerNorm over N == 512: rowbias needs rowgroup % 32 == 0 and 16-byte aligned rows");
+        PSAM_REQUIRE(!fuse->pack_out || (fuse->out_scale && fuse->out_k1 == 0.f && fuse->out_k2 > 0.f && (ldc & 7) == 0 && ((uintptr_t)C & 31) == 0), PSAM_EINVAL,
+                     "psam_gemm_f16x3p_ex: packed output after a row LayerNorm takes the a-priori bound in out_k2 (out_k1 == 0) and 32-byte aligned rows");
+        PSAM_REQUIRE((((uintptr_t)fuse->row_ln_g | (uintptr_t)fuse->row_ln_b | (uintptr_t)scaleW | (uintptr_t)bias | (uintptr_t)C) & 15) == 0 && (ldc & 3) == 0, PSAM_EALIGN,
+                     "psam_gemm_f16x3p_ex: 16-byte alignment");
+        p.row_ln_g = fuse->row_ln_g; p.row_ln_b = fuse->row_ln_b; p.row_ln_eps = fuse->row_ln_eps;
+        p.pack_out = fuse->pack_out; p.out_scale = fuse->out_scale; p.out_k1 = 0.f; p.out_k2 = fuse->out_k2;
+        return launch_f16x3pp(70, p, stream);
     } else if (fuse && (fuse->row_ln_g || fuse->hyper)) {
         // full-row epilogues: a wave owns whole rows of N == 256 columns (128x256 tiles, four waves of 32 rows)
         PSAM_REQUIRE(N == 256 && (M & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm / hyper products need N == 256, M % 128 == 0");

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
         if (sum == 123.456f) p.C[0] = sum;
         return;
     }
-    if constexpr (TR) {
+    if constexpr (TR == 2) {       // full-row tile (tiles_n == 1): Linear -> LayerNorm -> activation -> packed rows (gemm_epilogue_t.h)
+        gemm_store_tile_t_rowln<TM, TN, WN>(p, acc, reinterpret_cast<float*>(smem), BM, m0 + wm * TM * 32, wm * TM * 32, wn, lane, p.C);
+    } else if constexpr (TR) {
         gemm_store_tile_t<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
     } else if constexpr (CHUNKED) {
         gemm_store_tile_chunked<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<2>(), m0 + wm * TM * 32,
@@ -376,6 +378,7 @@ int32_t launch_f16x3pp(int cfg, F16PArgs& p, hipStream_t stream) {
         case 62: return launch_pp<4, 1, 1, 7, 5, 1, 1>(p, stream);      // 256x224 (150 KiB): qkv 4096x3072 = 224 tiles, one round
         case 63: return launch_pp<4, 1, 1, 6, 5, 1, 1>(p, stream);      // 256x192 (140 KiB): fc1 4096x5504 = 464 tiles, two rounds
         case 64: return launch_pp<4, 1, 1, 8, 5, 1, 1>(p, stream);      // 256x256 with the same wave layout (160 KiB)
+        case 70: return launch_pp<1, 4, 2, 4, 3, 1, 1, 0, 2>(p, stream);      // 128x512 full-row tile, waves of 64x128, 3 units (120 KiB): row LayerNorm epilogue (N == 512)
         default: break;
     }
     psam_set_error("psam_gemm_f16x3p: unknown ping-pong config");

@@ -160,6 +160,7 @@ class PointCloudSAM:
         # here, and owned by this model (fw: name -> ops.F16Weight; launches below the split thresholds use its fp32 original)
         self.fw = {}
         self.pe_bound = {}
+        self.ln_bound = {}       # prefix -> a-priori bound of the conv2.1 LayerNorm's output (packed output of the fused conv2.0 GEMM)
         if self.precision == "f16x3":
             h0 = cfg.patch_hidden[0]
             for name, t in w.items():
@@ -283,10 +284,22 @@ class PointCloudSAM:
                 y1 = ops.group_max(y1, parts)
             del h1
             g1 = ops.linear(y1, self.fw.get(prefix + ".conv2.0.weight#max", w2a[:, :h0]), w[prefix + ".conv2.0.bias"])
-            h3 = ops.linear(h2, self.fw[prefix + ".conv2.0.weight#x"], None, rowbias=g1, rowgroup=K, x_scale=s2, x_packed=True)
-            del h2
-            pk, rs = self._ln_feeds_gemm(h3, prefix + ".conv2.3")
-            self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3, scale_out=rs, pack=pk)
+            hd1 = w2a.shape[0]
+            if ops.fused_row_ln(hd1) and hd1 == 512 and (prefix + ".conv2.3.weight") in self.fw and rows % 128 == 0:
+                # conv2.0 -> LayerNorm -> GELU as ONE GEMM on full-row tiles: the [rows, 512] fp32 activation and the LayerNorm pass over it never exist
+                h3 = torch.empty(rows, hd1, dtype=torch.float32, device=coords.device)     # g8-packed container
+                rs, pk = torch.empty(rows, dtype=torch.float32, device=coords.device), True
+                bound = self.ln_bound.get(prefix)
+                if bound is None:
+                    bound = self.ln_bound.setdefault(prefix, 1.001 * ops.row_ln_bound(w[prefix + ".conv2.1.weight"], w[prefix + ".conv2.1.bias"]) + 1e-30)
+                ops.linear(h2, self.fw[prefix + ".conv2.0.weight#x"], None, act=ACT_GELU, rowbias=g1, rowgroup=K, x_scale=s2, x_packed=True, out=h3,
+                           row_ln=(w[prefix + ".conv2.1.weight"], w[prefix + ".conv2.1.bias"], eps), pack_out=(rs, 0.0, bound))
+                del h2
+            else:
+                h3 = ops.linear(h2, self.fw[prefix + ".conv2.0.weight#x"], None, rowbias=g1, rowgroup=K, x_scale=s2, x_packed=True)
+                del h2
+                pk, rs = self._ln_feeds_gemm(h3, prefix + ".conv2.3")
+                self._ln(prefix + ".conv2.1", h3, eps, act=ACT_GELU, out=h3, scale_out=rs, pack=pk)
             emb = torch.empty(groups * parts, self.w[prefix + ".conv2.3.weight"].shape[0], dtype=torch.float32, device=coords.device)
             self._lin(prefix + ".conv2.3", h3, x_scale=rs, x_packed=pk, group_max_out=emb, group_max_k=Kp, no_store=True)
             return ops.group_max(emb, parts) if parts > 1 else emb

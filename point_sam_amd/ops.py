@@ -319,6 +319,11 @@ def row_ln_bound(gamma, beta) -> float:
     return float((n - 1) ** 0.5 * gamma.abs().max().item() + beta.abs().max().item())
 
 
+def fused_row_ln(N: int) -> bool:
+    """Whether linear(..., row_ln=...) exists for N output columns (psam_gemm_f16x3p_fused_row_ln): 256 always, 512 with the register epilogue."""
+    return bool(_lib.load().psam_gemm_f16x3p_fused_row_ln(int(N)))
+
+
 def stat_segs(N: int) -> int:
     return (N // 2 + 31) // 32
 
