@@ -26,6 +26,13 @@
 typedef unsigned ept_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned ept_u32x2 __attribute__((ext_vector_type(2)));
 
+// Scheduling fence between the tiles of an epilogue: without it the pre-RA scheduler hoists every tile's constant / residual loads to the top
+// (latency hiding the epilogue does not need at two waves per SIMD) and the 128-register accumulator tiles of the ping-pong kernels spill.
+__device__ __forceinline__ void ept_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 // lanes 32-63 of a <-> lanes 0-31 of b
 __device__ __forceinline__ void ept_swap32(unsigned& a, unsigned& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -121,6 +128,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
     for (int j0 = 0; j0 < TN; ++j0) {
         if (swiglu && (j0 & 1)) continue;
         const int j = j0;
+        ept_fence();
         const int pcol = col_base + j * 32 + 4 * h;                 // run g starts at pcol + 8 g
         const int ocol = swiglu ? (col_base >> 1) + (j >> 1) * 32 + 4 * h : pcol;
         // column constants of the tile (and of its partner tile when gated)
@@ -142,6 +150,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (i > 0) ept_fence();
             const int row = row_base + i * 32 + r32;
             ep_f32x4 res[4];
             if (o_res) {
@@ -296,6 +305,7 @@ __device__ __forceinline__ void gemm_store_tile_t_rowln(const ArgsT& p, ep_f32x1
     // ---- pass A: finished pre-LayerNorm values in place, row sums
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        ept_fence();
         const int pcol = col_base + j * 32 + 4 * h;
         ep_f32x4 m[4], b[4];
 #pragma unroll
@@ -307,6 +317,7 @@ __device__ __forceinline__ void gemm_store_tile_t_rowln(const ArgsT& p, ep_f32x1
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (i > 0) ept_fence();
             ep_f32x4 rb[4];
             if (p.rowbias) {
                 const float* rbp = p.rowbias + (int64_t)((row_base + i * 32) / p.rowgroup) * p.ldrb + pcol;
@@ -372,12 +383,14 @@ __device__ __forceinline__ void gemm_store_tile_t_rowln(const ArgsT& p, ep_f32x1
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        ept_fence();
         const int pcol = col_base + j * 32 + 4 * h;
         ep_f32x4 gm[4], bt[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) { gm[g] = ep_load4(p.row_ln_g + pcol + 8 * g); bt[g] = ep_load4(p.row_ln_b + pcol + 8 * g); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (i > 0) ept_fence();
             const int row = row_base + i * 32 + r32;
             ep_f32x4 v[4];
 #pragma unroll

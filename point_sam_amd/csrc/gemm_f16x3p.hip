@@ -386,7 +386,16 @@ static int f16x3p_epilogue_mode() {
 }
 // Whether psam_gemm_f16x3p_ex takes psam_gemm_fuse_t.row_ln_* (Linear -> LayerNorm -> activation in one GEMM) for N output columns: 256 always
 // (full-row wave tiles, LDS epilogue), 512 with the register epilogue (128x512 workgroup tiles).
-PSAM_API int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N) { return N == 256 || (N == 512 && f16x3p_epilogue_mode() > 0) ? 1 : 0; }
+// N == 512 is OFF by default (environment PSAM_GEMM_ROWLN512=1 turns it on): measured SLOWER than the two launches it replaces at the benchmark's
+// size -- PatchEncoder 1.27 ms against 1.05 ms (profiles/r04_rowln512.txt): one 8-wave workgroup per CU runs its K loop (8 steps), the three row
+// passes (128 erf-GELUs per lane) and 256 KiB of stores back to back with nothing to overlap them, where GEMM + LayerNorm kernel overlap across
+// many resident workgroups.  Kept reachable, parity-tested (tests/test_gpu_kernels.py::test_gemm_row_ln_512).
+PSAM_API int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N) {
+    if (N == 256) return 1;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_GEMM_ROWLN512"); on = e ? atoi(e) : 0; }
+    return N == 512 && on > 0 && f16x3p_epilogue_mode() > 0 ? 1 : 0;
+}
 bool f16x3p_use_register_epilogue(const F16PArgs& p) {
     int mode = g_f16x3p_tr;
     if (mode < 0) {
@@ -598,7 +607,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
     } else if (fuse && fuse->row_ln_g && N == 512) {
         // full-row tile 128x512 on the ping-pong kernel with the register epilogue: Linear (+ row bias per group) -> LayerNorm -> activation -> packed rows
-        PSAM_REQUIRE(psam_gemm_f16x3p_fused_row_ln(N), PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm over N == 512 needs the register epilogue (psam_gemm_f16x3p_fused_row_ln)");
+        PSAM_REQUIRE(f16x3p_epilogue_mode() > 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm over N == 512 needs the register epilogue (psam_gemm_f16x3p_force_epilogue)");
         PSAM_REQUIRE((M & 127) == 0 && act != 3 && fuse->row_ln_b && !fuse->hyper && !fuse->stats && !fuse->ln_c && !fuse->gmax_out && !fuse->no_store && !residual, PSAM_EINVAL,
                      "psam_gemm_f16x3p_ex: row LayerNorm over N == 512 needs M % 128 == 0 and combines only with bias / rowbias / activation / packed output");
         PSAM_REQUIRE(!rowbias || ((p.rowgroup & 31) == 0 && (ldrb & 3) == 0 && ((uintptr_t)rowbias & 15) == 0), PSAM_EINVAL,

@@ -629,6 +629,40 @@ def test_gemm_f16x3_register_epilogue_bitwise(ops):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{k}: {(a.view(torch.int32) != b.view(torch.int32)).sum().item()} words differ"
 
 
+def test_gemm_row_ln_512(ops):
+    """Linear (+ per-group row bias) -> LayerNorm -> GELU -> packed rows as ONE GEMM on full-row 128x512 tiles (register epilogue, two-pass row
+    statistics across the row band's waves): PatchEncoder's conv2.0 / conv2.1 (common.py:493-496).  Against fp64; the packed rows decode to
+    fp32-grade values under the a-priori LayerNorm bound.  (Off in the model by default: measured slower, profiles/r04_rowln512.txt.)"""
+    L = ops._lib.load()
+    g = torch.Generator().manual_seed(5)
+    M, N, K, grp = 1024, 512, 128, 64
+    x = torch.randn(M, K, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    rb = torch.randn(M // grp, N, generator=g)
+    gam, bet = 1 + 0.3 * torch.randn(N, generator=g), 0.2 * torch.randn(N, generator=g)
+    eps = 1e-6
+    pre = x.double() @ W.double().T + rb.double().repeat_interleave(grp, 0)
+    want = F.gelu(F.layer_norm(pre, (N,), gam.double(), bet.double(), eps))
+    fw = ops.F16Weight(cu(W))
+    bound = 1.001 * ops.row_ln_bound(cu(gam), cu(bet))
+    L.psam_gemm_f16x3p_force_epilogue(1)
+    try:
+        with ops.gemm_mode("f16x3"):
+            xp, sx = ops.scale_pack_rows_g8(cu(x))
+            out = torch.empty(M, N, device="cuda"); so = torch.empty(M, device="cuda")
+            ops.linear(xp, fw, None, act=ops.ACT_GELU, rowbias=cu(rb), rowgroup=grp, x_scale=sx, x_packed=True, out=out,
+                       row_ln=(cu(gam), cu(bet), eps), pack_out=(so, 0.0, bound))
+            plain = ops.linear(xp, fw, None, act=ops.ACT_GELU, rowbias=cu(rb), rowgroup=grp, x_scale=sx, x_packed=True, row_ln=(cu(gam), cu(bet), eps))
+    finally:
+        L.psam_gemm_f16x3p_force_epilogue(-1)
+    dec = _unpack_g8(out, so, N).cpu().double()
+    assert (torch.log2(so) == torch.log2(so).round()).all() and (want.abs().max(1).values * so.cpu().double() < 2.0 ** 15).all()
+    e_pack = ((dec - want).abs().max() / want.abs().max()).item()
+    e_plain = ((plain.cpu().double() - want).abs().max() / want.abs().max()).item()
+    print(f"\n[row LN 512] rel err vs fp64: packed {e_pack:.2e}, fp32 {e_plain:.2e}")
+    assert e_pack < 3e-6 and e_plain < 3e-6
+
+
 def test_gemm_row_epilogues_upscaling_chain(ops):
     """The decoder's upscaling MLP inside GEMM epilogues (N = 256: a wave owns whole rows): Linear -> LayerNorm -> GELU with the result
     packed against the LayerNorm's bound, then Linear -> GELU -> hyper-network dot products, against fp64 (mask_decoder.py:53-59,164-176)."""
