@@ -22,6 +22,7 @@ SOURCES = [
     ("gemm_split.hip", []),
     ("gemm_f16x3p.hip", []),
     ("gemm_f16x3pp.hip", []),
+    ("gemm_f16x3q.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("twoway.hip", []),

@@ -671,6 +671,16 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
             if (pp >= 0 && shape_ok && f16x3pp_supports(pp, act, w_stats, w_gmax, w_hyper)) cfg = pp;
         }
     }
+    {   // unit-ring kernel (gemm_f16x3q.hip): a forced configuration 80 .., or the environment's choice for the large encoder GEMMs
+        int q = (g_f16x3p_cfg >= 80 && g_f16x3p_cfg < 90) ? g_f16x3p_cfg : 0;
+        if (!q && g_f16x3p_cfg < 0) {
+            static int envq = -1;
+            if (envq < 0) { const char* e = getenv("PSAM_GEMM_Q"); envq = e ? atoi(e) : 0; }
+            if (envq >= 80 && M >= 2048 && N >= 1024 && K >= 512) q = (envq == 84 && (act == 3 || N % 192 != 0)) ? 80 : envq;
+        }
+        if (q && f16x3q_supports(q, p)) return launch_f16x3q(q, p, stream);
+        if (cfg >= 80 && cfg < 90) cfg = f16x3p_pick(M, N, K, act, true);
+    }
     if (cfg >= 50 && (cfg < 100 || cfg >= 200)) return launch_f16x3pp(cfg, p, stream);
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2

@@ -14,9 +14,10 @@ NAMES = {0: "128x128 4w S2", 1: "128x128 4w S3", 2: "128x128 4w S3 LA", 3: "128x
          27: "256x128 S2 PF2", 28: "128x128 8w S2 PF2", 29: "128x128 8w S4 LA PF1",
          # ping-pong kernel (gemm_f16x3pp.hip): one 8-wave workgroup per CU, two wave groups one barrier interval apart
          50: "pp 256x256 (128x64) S5 prio", 51: "pp 256x256 no prio", 52: "pp 256x256 static prio", 53: "pp 256x256 (64x128)", 59: "pp 256x256 S4", 60: "pp 256x256 S5 P2", 61: "pp 256x256 S4 P2",
+         80: "q 128x256 4w(64x128) S3", 81: "q 128x128 S3", 82: "q 128x128 S4", 83: "q 128x256 4w(32x256)", 84: "q 128x192 4w(64x96)",
          62: "pp 256x224 (32x224)", 63: "pp 256x192 (32x192)", 64: "pp 256x256 (32x256)",
          55: "pp 256x128 S6 P2", 56: "pp 256x128 S6 P1", 57: "pp 128x128 S8 P2", 58: "pp 128x128 S4 P2"}
-ODD_TN = (12, 23, 30, 62)
+ODD_TN = (12, 23, 30, 62, 84)
 # per-shape configuration maps for the two-stream layer loop (qkv, proj, fc1, fc2)
 COMBOS = {"all c0": (0, 0, 0, 0), "all c4": (4, 4, 4, 4), "all c14": (14, 14, 14, 14), "c12 c4 c14 c4": (12, 4, 14, 4), "c12 c9 c14 c9": (12, 9, 14, 9),
           "c14 c4 c14 c4": (14, 4, 14, 4), "c12 c4 c4 c4": (12, 4, 4, 4), "c13 c0 c13 c0": (13, 0, 13, 0), "c12 c16 c14 c16": (12, 16, 14, 16),
@@ -27,7 +28,8 @@ COMBOS = {"all c0": (0, 0, 0, 0), "all c4": (4, 4, 4, 4), "all c14": (14, 14, 14
           "c50 c21 c50 c21": (50, 21, 50, 21), "c55 c57 c50 c57": (55, 57, 50, 57), "all c55": (55, 55, 55, 55), "all c50": (50, 50, 50, 50),
           "c21 c57 c21 c57": (21, 57, 21, 57), "all c60": (60, 60, 60, 60), "c60 c57 c60 c57": (60, 57, 60, 57), "c60 c57 c55 c57": (60, 57, 55, 57), "c60 c21 c60 c21": (60, 21, 60, 21), "c21 c57 c55 c57": (21, 57, 55, 57),
           "c62 c21 c63 c21": (62, 21, 63, 21), "c62 c57 c63 c57": (62, 57, 63, 57), "c62 c21 c21 c21": (62, 21, 21, 21), "c21 c21 c63 c21": (21, 21, 63, 21),
-          "c64 c21 c64 c21": (64, 21, 64, 21)}
+          "c64 c21 c64 c21": (64, 21, 64, 21), "all c80": (80, 80, 80, 80), "c80 c21 c80 c21": (80, 21, 80, 21), "c84 c21 c80 c21": (84, 21, 80, 21),
+          "all c82": (82, 82, 82, 82), "all c83": (83, 83, 83, 83), "c80 c82 c80 c82": (80, 82, 80, 82)}
 
 
 def half_chip_streams():
