@@ -34,6 +34,15 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16
 TRAFFIC_FILES = {"f16x3": ("r03_traffic.json", "r02_traffic.json"), "bf16x6": ("r01_v6_traffic.json",), "f32": ("r01_v6_traffic.json",)}
 
 
+# BASELINE.json `configs` that fit one GPU (config #4 is cfg2 across 8 GPUs: --gpus 8; config #1 is the CPU plumbing case of the tests)
+WORKLOADS = {
+    "cfg2": dict(config="large", points=32768, groups=512, group_size=64, batch=8, clicks=1),
+    "cfg3": dict(config="large", points=131072, groups=2048, group_size=256, batch=1, clicks=1),
+    "cfg5": dict(config="giant", points=32768, groups=512, group_size=64, batch=1, clicks=5),
+}
+CLICK_LABELS = (1, 1, 0, 1, 0, 1, 1, 0)      # labels of a session's clicks (positive first; the pattern of tests/test_gpu_e2e.py's config-#5 case)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +66,21 @@ def parse_args(argv=None):
     ap.add_argument("--no-stage-times", action="store_true", help="skip the per-stage timing pass after the timed region")
     ap.add_argument("--sustained-steps", type=int, default=400, help="steps of the second, long timed region (0 = skip); reported under `sustained`")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo run of this file's control flow with a stand-in pipeline (tests)
-    return ap.parse_args(argv)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="BASELINE.json configuration: cfg2 = ViT-L N=32768 512x64 batch 8 (the metric's configuration, default); cfg3 = ViT-L N=131072 2048x256 "
+                         "batch 1 (large scene); cfg5 = ViT-giant N=32768 512x64 batch 1, 5-click session (encoder cached, decoder-only loop).  Sets --config / "
+                         "--points / --groups / --group-size / --batch / --clicks unless those are given explicitly")
+    ap.add_argument("--clicks", type=int, default=None, help="clicks per cloud: > 1 = interactive session (click t decodes with clicks 0..t and the previous best mask)")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "ply"],
+                    help="synthetic: uniform clouds in the unit ball; ply: the reference's six demo clouds tiled / jittered to N points (SURVEY.md 8(d))")
+    args = ap.parse_args(argv)
+    given = {a.split("=")[0] for a in (argv if argv is not None else sys.argv[1:]) if a.startswith("--")}
+    for key, val in WORKLOADS[args.workload].items():      # the workload's geometry, unless the flag was given explicitly
+        if "--" + key.replace("_", "-") not in given:
+            setattr(args, key, val)
+    if args.clicks is None:
+        args.clicks = 1
+    return args
 
 
 # ------------------------------------------------------------------------------------------ launching the ranks
@@ -117,13 +140,23 @@ class HipHarness:
         self.sd = random_state_dict(self.cfg, seed=42)
         self.model = PointCloudSAM(self.cfg, self.sd, self.dev, precision=args.precision)
         self.seed = 42 + rank
-        self.batch = tuple(t.to(self.dev) for t in synthetic_batch(args.batch, args.points, seed=self.seed))
+        self.session = args.clicks > 1
+        if args.data == "ply":
+            from point_sam_amd.synthetic import ply_batch
+            batch = ply_batch(args.batch, args.points, seed=self.seed, num_prompts=args.clicks)
+        else:
+            batch = synthetic_batch(args.batch, args.points, seed=self.seed, num_prompts=args.clicks)
+        if self.session:
+            labels = torch.tensor([CLICK_LABELS[t % len(CLICK_LABELS)] for t in range(args.clicks)], dtype=torch.int64).repeat(args.batch, 1)
+            batch = (batch[0], batch[1], batch[2], labels)
+        self.batch = tuple(t.to(self.dev) for t in batch)
         self.use_graphs = args.graphs and not args.no_pipeline
-        self.pipe = BatchPipeline(self.model, dense_streams=args.streams) if not args.no_pipeline else None
-        self.gpipe = GraphPipeline(self.model, *self.batch, None, True, slots=args.slots, dense_streams=args.streams) if self.use_graphs else None
+        # a session (several decodes on one cached encoder state) runs as a captured graph or inline; the eager stream pipeline issues single decodes
+        self.pipe = BatchPipeline(self.model, dense_streams=args.streams) if (not args.no_pipeline and not (self.session and not self.use_graphs)) else None
+        self.gpipe = GraphPipeline(self.model, *self.batch, None, True, slots=args.slots, dense_streams=args.streams, session=self.session) if self.use_graphs else None
         self.main_stream = torch.cuda.current_stream(self.dev)
         self.depth = self.gpipe.depth if self.use_graphs else (self.pipe.depth if self.pipe is not None else 1)
-        self.inline = self.pipe is None
+        self.inline = self.pipe is None and not self.use_graphs
         self.prof = None
 
     def sync(self):
@@ -140,6 +173,9 @@ class HipHarness:
 
     def next(self):
         if self.inline:
+            if self.session:
+                xyz, rgb, clicks, labels = self.batch
+                return self.model.click_session(self.model.encode(xyz, rgb), clicks, labels)[-1]
             return self.model.predict_masks(*self.batch, None, True, validate=False)
         return (self.gpipe if self.use_graphs else self.pipe).next()
 
@@ -161,6 +197,7 @@ class HipHarness:
             from point_sam_amd.model import BatchPipeline
             pipe = BatchPipeline(self.model, dense_streams=1)
         xyz, rgb, prompt, labels = self.batch
+        prompt, labels = prompt[:, :1].contiguous(), labels[:, :1].contiguous()      # a session's first click: the sampled launches are the encoder's
         n = 2
         c_blocks, self.model.c_blocks = self.model.c_blocks, False      # the sampler wraps the launches the Python host issues: this pass sequences the
         for k in range(n):                                              # blocks' kernels itself (the same launches psam_eva_block issues in the timed region)
@@ -185,7 +222,25 @@ class HipHarness:
     def stage_times(self):
         from point_sam_amd.profiling import stage_times, tokenizer_metrics
         a = self.args
-        st = stage_times(self.model, *self.batch, passes=3, warmup=1)
+        xyz, rgb, prompt, labels = self.batch
+        st = stage_times(self.model, xyz, rgb, prompt[:, :1].contiguous(), labels[:, :1].contiguous(), passes=3, warmup=1)
+        if self.session:      # the decoder-only loop on the cached state: ms per click after the first
+            enc = self.model.encode(xyz, rgb)
+            self.model.click_session(enc, prompt, labels)
+            per = []
+            for _ in range(3):
+                outs, best, N = [], None, xyz.shape[1]
+                m, i = self.model.decode(enc, prompt[:, :1].contiguous(), labels[:, :1].contiguous(), None, True)
+                best = torch.gather(m, 1, i.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for t in range(1, prompt.shape[1]):
+                    m, i = self.model.decode(enc, prompt[:, : t + 1].contiguous(), labels[:, : t + 1].contiguous(), best, False)
+                    best = m[:, 0]
+                e1.record(); torch.cuda.synchronize()
+                per.append(e0.elapsed_time(e1) / (prompt.shape[1] - 1))
+            st["ms_per_additional_click"] = round(sorted(per)[1], 3)
+            st["ms_per_additional_click_note"] = "eager launches, HIP events around clicks 2..T on the cached encoder state, median of 3"
         return st, tokenizer_metrics(st, a.batch, a.points, a.groups, a.group_size)
 
     def cpu_baseline(self, out, iters=3):
@@ -194,10 +249,15 @@ class HipHarness:
         (`parity`).  Reported next to the GPU number; never the thing measured above."""
         from oracle import pointsam_oracle as O
         a = self.args
-        xyz, rgb, prompt, labels = (t[:1] for t in O.synthetic_batch(a.batch, a.points, seed=self.seed))
+        full = tuple(t.cpu() for t in self.batch)      # the very tensors the timed region ran on
+        xyz, rgb, prompt, labels = (t[:1] for t in full)
         cores = torch.get_num_threads()
         O.fps(xyz[:, :4096], 16)  # build/load the C library outside the timed region
-        run = lambda: O.predict_masks(self.sd, self.cfg, xyz, rgb, prompt, labels, None, True, mode="reference")
+        if self.session:
+            oracle_one = lambda b: O.click_loop(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1])[-1]
+        else:
+            oracle_one = lambda b: O.predict_masks(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1], None, True, mode="reference")
+        run = lambda: oracle_one(0)
         want = run()
         ts = []
         for _ in range(iters):
@@ -208,14 +268,21 @@ class HipHarness:
         dt = ts[len(ts) // 2]
         base = {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port", "iterations": iters,
                 "seconds_per_cloud": {"median": round(dt, 3), "min": round(ts[0], 3), "max": round(ts[-1], 3)},
-                "sample": f"cloud 0 of the timed batch (ViT-{a.config}, N={a.points}, {a.groups}x{a.group_size}, 1 prompt), oracle mode='reference' (torch.cdist+topk), "
+                "sample": f"cloud 0 of the timed batch (ViT-{a.config}, N={a.points}, {a.groups}x{a.group_size}, {a.clicks} click(s)), oracle "
+                          + ("click loop, " if self.session else "mode='reference' (torch.cdist+topk), ") +
                           f"1 warm-up + {iters} timed runs, median {dt:.1f} s; torch {torch.__version__}, {cores} threads"}
         masks, iou = out
-        em = float((masks[:1].float().cpu() - want[0]).abs().max())
-        ei = float((iou[:1].float().cpu() - want[1]).abs().max())
-        parity = {"checked": "cloud 0 of the last timed step's output (the graph/stream pipeline's own result) vs the oracle on the same inputs and weights",
-                  "max_abs_err_mask_logits": em, "max_abs_err_iou": ei, "tolerance": 1e-3, "ok": bool(em < 1e-3 and ei < 1e-3),
-                  "logit_scale": float(want[0].abs().max())}
+        masks, iou = masks.float().cpu(), iou.float().cpu()
+        per_cloud, scale = [], 0.0
+        for b in range(masks.shape[0]):      # EVERY cloud of the timed batch against the oracle (clouds 1.. : one untimed oracle run each)
+            w = want if b == 0 else oracle_one(b)
+            per_cloud.append((float((masks[b:b + 1] - w[0]).abs().max()), float((iou[b:b + 1] - w[1]).abs().max())))
+            scale = max(scale, float(w[0].abs().max()))
+        em, ei = max(e for e, _ in per_cloud), max(e for _, e in per_cloud)
+        parity = {"checked": f"all {masks.shape[0]} cloud(s) of the last timed step's output (the graph/stream pipeline's own result"
+                             + (", last click of the session" if self.session else "") + ") vs the oracle on the same inputs and weights",
+                  "max_abs_err_mask_logits": em, "max_abs_err_iou": ei, "per_cloud_max_abs_err_mask_logits": [round(e, 9) for e, _ in per_cloud],
+                  "tolerance": 1e-3, "ok": bool(em < 1e-3 and ei < 1e-3), "logit_scale": scale}
         return base, parity
 
 
@@ -335,10 +402,14 @@ def worker(args):
         t_enq = time.perf_counter() - t0           # host time to issue every launch of the region (no sync inside)
         fence()
         el = time.perf_counter() - t0
+        per_rank = [el]
         if world > 1:
             t = torch.tensor([el], device=H.dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t.item())
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(allt, t)      # every rank's own time between the fences: a straggler shows
+            per_rank = [float(x.item()) for x in allt]
+            el = max(per_rank)                          # the contract's figure: MAX over ranks
+        timed.per_rank = per_rank
         return out, el, t_enq
 
     if args.warmup:
@@ -347,6 +418,7 @@ def worker(args):
     step_events = []
     # timed region: exactly --steps passes
     out, elapsed, t_enqueued = timed(args.steps, step_events)
+    rank_times = list(timed.per_rank)
     H.finalize()
     assert torch.isfinite(out[0]).all()
     keep = (out[0][:B].clone(), out[1][:B].clone()) if world == 1 else (out[0][rank * B:(rank + 1) * B].clone(), out[1][rank * B:(rank + 1) * B].clone())
@@ -383,7 +455,10 @@ def worker(args):
             h = side_gather.start(keep, total)
             side_gather.finish(h)
         fence()
-        rccl = {"ranks_seen": int(torch.unique(ids.cpu()).numel()), "gather_ms": round((time.perf_counter() - t0) / reps * 1e3, 4),
+        seen = int(torch.unique(ids.cpu()).numel())
+        if seen != world:      # a rank missing from the collective: the run does not count
+            raise SystemExit(f"rccl: {seen} distinct ranks in the gathered results, expected {world}")
+        rccl = {"ranks_seen": seen, "gather_ms": round((time.perf_counter() - t0) / reps * 1e3, 4),
                 "gather_bytes_per_rank": int(keep[0].numel() * 4 + keep[1].numel() * 4), "backend": torch.distributed.get_backend(),
                 "note": "all_gather_into_tensor of one step's [B,3,N] logits + [B,3] IoU on the side stream, 10 back-to-back, host-timed between barriers"}
 
@@ -403,13 +478,20 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (fp32 in/out/accumulate; large GEMMs as exact 3-way bf16 split x 6 MFMA products)",
                       "f16x3": "f32 (fp32 in/out/accumulate; large GEMMs as row-scaled 2-way fp16 split x 3 MFMA products, fp32-grade error)"}[a.precision],
-            "data": "synthetic",
-            "config": {"workload": f"ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={B}/GPU 1 point prompt multimask",
+            "data": "synthetic" if a.data == "synthetic" else "reference demo clouds tiled/jittered to N (synthetic weights)",
+            "config": {"workload": f"{a.workload}: ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={B}/GPU "
+                                   + (f"{a.clicks}-click session (encoder cached)" if a.clicks > 1 else "1 point prompt multimask") + f", {a.data} clouds",
                        "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": not a.no_pipeline,
                        "batches_in_flight": H.depth, "dense_streams": a.streams, "hip_graphs": bool(H.use_graphs),
                        "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "gemm_precision": a.precision, "weights": "seeded random init (no checkpoint offline)"},
             "roofline": roofline, "step_ms": step_stats, "stage_ms": stage_ms, "tokenizer": tok, "sustained": sustained, "rccl": rccl,
+            "per_rank": {"ranks": [{"rank": r, "value": round(B * a.steps / t, 3), "ms_per_step": round(t / a.steps * 1e3, 3)} for r, t in enumerate(rank_times)],
+                         "min_value": round(B * a.steps / max(rank_times), 3), "max_value": round(B * a.steps / min(rank_times), 3),
+                         "note": "each rank's own clouds/s between the fences of the timed region; `value` uses the slowest rank's time"},
         }
+        if a.clicks > 1:
+            res["config"]["clicks"] = a.clicks
+            res["ms_per_additional_click"] = (stage_ms or {}).get("ms_per_additional_click")
         if args.stub:
             res["config"]["stub"] = dict(checks, taken=H.taken)
             res["data"] = "stub"

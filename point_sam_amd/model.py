@@ -647,6 +647,20 @@ class PointCloudSAM:
             self.check_coordinate_range()
         return masks, iou
 
+    @torch.no_grad()
+    def click_session(self, st: "EncoderState", clicks, labels):
+        """The interactive loop on a cached encoder state (pc_sam.py:139-194 with given clicks; BASELINE config #5): click t decodes with clicks
+        0 .. t and the previous step's best mask as the mask prompt -- multimask output and the highest-IoU candidate after the first click,
+        single-mask output afterwards.  clicks [B, T, 3], labels [B, T].  Returns the list of (masks, iou) per click.  No host
+        synchronisation (the best candidate is selected on the device): the loop can be captured in a HIP graph."""
+        N = st.coords.shape[1]
+        outs, best = [], None
+        for t in range(clicks.shape[1]):
+            masks, iou = self.decode(st, clicks[:, : t + 1].contiguous(), labels[:, : t + 1].contiguous(), best, best is None)
+            outs.append((masks, iou))
+            best = torch.gather(masks, 1, iou.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0] if t == 0 else masks[:, 0]
+        return outs
+
     # ------------------------------------------------------------------------------------------ evaluation protocol
     @torch.no_grad()
     def sample_prompts(self, coords, gt_masks, pred_logits=None, is_eval=True):
@@ -816,9 +830,16 @@ class GraphPipeline:
     copy them before `slots` further submits.  Coordinates outside [-1, 1] are still recorded in the model's device flag."""
 
     def __init__(self, model: PointCloudSAM, coords, features, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, slots: int = 3,
-                 dense_streams: int = 2):
+                 dense_streams: int = 2, session: bool = False):
+        """session=True: prompt_coords [B, T, 3] / prompt_labels [B, T] are the T clicks of an interactive session; the dense graph is encode +
+        PointCloudSAM.click_session (T decodes on the cached state) and next() returns the LAST click's (masks, iou)."""
         from collections import deque
         self.model, self.depth, self.count = model, max(1, slots), 0
+        self.session = bool(session)
+        if session and prompt_masks is not None:
+            raise ValueError("GraphPipeline(session=True) feeds each click's best mask forward itself: prompt_masks must be None")
+        dense_body = (lambda st_, tok_: model.click_session(model.encode(st_.coords, st_.features, tok_), st_.pc, st_.pl)[-1]) if session else \
+                     (lambda st_, tok_: model.decode(model.encode(st_.coords, st_.features, tok_), st_.pc, st_.pl, st_.pm, multimask_output))
         self.queue = deque()
         dev = model.device
         self.tok_stream = torch.cuda.Stream(device=dev, priority=-1)
@@ -838,14 +859,14 @@ class GraphPipeline:
                 tok = model.tokenize(st.coords, with_interp=True)
             ds.wait_stream(self.tok_stream)
             with torch.cuda.stream(ds):
-                model.decode(model.encode(st.coords, st.features, tok), st.pc, st.pl, st.pm, multimask_output)
+                dense_body(st, tok)
             torch.cuda.synchronize(dev)
             st.g_tok = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st.g_tok, stream=self.tok_stream):
                 st.tok = model.tokenize(st.coords, with_interp=True)
             st.g_dense = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st.g_dense, stream=ds):
-                st.out = model.decode(model.encode(st.coords, st.features, st.tok), st.pc, st.pl, st.pm, multimask_output)
+                st.out = dense_body(st, st.tok)
             st.tok_done, st.done = torch.cuda.Event(), torch.cuda.Event()
             self.slots.append(st)
         # what the graphs were captured for: submit() refuses anything else (a replay would silently compute on stale or mis-shaped buffers)

@@ -44,7 +44,22 @@ def _sampled_launch(launch, record):
 
 # GEMM arithmetic: "f32" = v_mfma_f32_32x32x2_f32 everywhere (exact fp32 products); "bf16x6" = large GEMMs on the bf16
 # matrix pipe with the exact 3-way operand split (fp32-accurate, see csrc/gemm_split.hip), small ones stay on "f32".
-GEMM_MODE = "f32"
+# The mode is a CONTEXT variable (per thread / per asyncio task), entered by every model method for its own precision: two models of different
+# precision -- or a threaded server -- do not see each other's setting.  `ops.GEMM_MODE` still reads the current value (module __getattr__).
+import contextvars
+_GEMM_MODE_VAR = contextvars.ContextVar("point_sam_amd_gemm_mode", default="f32")
+
+
+def current_gemm_mode() -> str:
+    return _GEMM_MODE_VAR.get()
+
+
+def __getattr__(name):
+    if name == "GEMM_MODE":
+        return _GEMM_MODE_VAR.get()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 128
 SKINNY_MAX_M = 64      # up to this many rows nn.Linear runs on the skinny kernel (exact fp32 products, like "f32")
 GEMM_MODES = ("f32", "bf16x6", "f16x3")
@@ -62,18 +77,16 @@ class gemm_mode:
         self.mode = mode
 
     def __enter__(self):
-        global GEMM_MODE
-        self.prev, GEMM_MODE = GEMM_MODE, self.mode
+        self.token = _GEMM_MODE_VAR.set(self.mode)
 
     def __exit__(self, *exc):
-        global GEMM_MODE
-        GEMM_MODE = self.prev
+        _GEMM_MODE_VAR.reset(self.token)
 
 
 def _gemm_call(fn_args, flops, M, N, K, what):
     global _gemm_counter
     L = _lib.load()
-    split = GEMM_MODE == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K
+    split = current_gemm_mode() == "bf16x6" and M >= SPLIT_MIN_M and N >= SPLIT_MIN_N and K >= SPLIT_MIN_K
     fn = L.psam_gemm_bf16x6 if split else L.psam_gemm_f32
     _gemm_counter += 1
     if not _sample_now():
@@ -371,7 +384,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
         op, ldo = _row_view(out, "out")
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     rbp, ldrb = (0, 0) if rowbias is None else _row_view(rowbias, "rowbias")
-    if GEMM_MODE == "f16x3" and fw is not None and M >= SPLIT_MIN_M:
+    if current_gemm_mode() == "f16x3" and fw is not None and M >= SPLIT_MIN_M:
         if x_packed:
             if x_scale is None or x.shape[1] < fw.Kp or (ldx & 7) or (xp & 31):
                 raise ValueError("x_packed needs x_scale and g8-packed rows padded to a multiple of 32 columns, 32-byte aligned")
@@ -482,7 +495,7 @@ def _f16x3_head_dim(hd: int) -> bool:
 
 
 def attention_can_pack(hd: int) -> bool:
-    return GEMM_MODE == "f16x3" and _f16x3_head_dim(hd)
+    return current_gemm_mode() == "f16x3" and _f16x3_head_dim(hd)
 
 
 def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
@@ -498,14 +511,14 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
         a_scale, k1, k2, o_scale = pack
         check(L.psam_attention_f16x3_ex(*args, a_scale.data_ptr(), float(k1), float(k2), o_scale.data_ptr(), _stream()), "psam_attention")
         return out
-    fn = L.psam_attention_f16x3 if (GEMM_MODE == "f16x3" and _f16x3_head_dim(hd)) else L.psam_attention_f32
+    fn = L.psam_attention_f16x3 if (current_gemm_mode() == "f16x3" and _f16x3_head_dim(hd)) else L.psam_attention_f32
     check(fn(*args, _stream()), "psam_attention")
     return out
 
 
 def attention_packed_supported(hd: int, rows: int, width: int) -> bool:
     """Self-attention straight from the qkv GEMM's packed output: head dim 64, and the qkv GEMM must be able to pack ([rows, 3 * width])."""
-    return GEMM_MODE == "f16x3" and hd == 64 and fuse_supported(rows, 3 * width)
+    return current_gemm_mode() == "f16x3" and hd == 64 and fuse_supported(rows, 3 * width)
 
 
 def attention_packed(qkv_packed, scale_rows, out, out_scale, B, H, L, hd, scale, v_bound):

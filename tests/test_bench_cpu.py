@@ -36,6 +36,10 @@ def _check(res, world, steps, warmup, sustained, batch):
         assert res["rccl"]["ranks_seen"] == world and res["rccl"]["gather_ms"] > 0
     else:
         assert res["rccl"] is None
+    # every rank's own rate is reported (a straggler shows); the contract's value uses the slowest rank's time
+    pr = res["per_rank"]
+    assert [r["rank"] for r in pr["ranks"]] == list(range(world)) and all(r["value"] > 0 and r["ms_per_step"] > 0 for r in pr["ranks"])
+    assert pr["min_value"] <= pr["max_value"] and abs(pr["min_value"] * world - res["value"]) <= 1e-2 * res["value"]
 
 
 def test_bench_self_spawns_two_ranks():

@@ -756,3 +756,39 @@ def test_two_ranks_over_rccl_match_one_rank(gpu):
         assert p.exitcode == 0
     ok_m, ok_i, shape = q.get(timeout=10)
     assert ok_m and ok_i and shape[0] == 4
+
+
+def test_click_session_eager_graph_and_oracle(gpu):
+    """The interactive session (BASELINE config #5's flow: encoder once, T decodes, each with all clicks so far and the previous best mask;
+    pc_sam.py:139-194): PointCloudSAM.click_session equals the predictor-style loop bit for bit, the captured form
+    (GraphPipeline(session=True)) equals the eager one, and the last click matches the oracle's click loop."""
+    from point_sam_amd.model import GraphPipeline
+    cfg = get_config("tiny", 64, 16)
+    sd = random_state_dict(cfg, 6)
+    model = gpu(cfg, sd, precision="f16x3")
+    B, N, T = 2, 2500, 4
+    xyz, rgb, _, _ = O.synthetic_batch(B, N, seed=70)
+    g = torch.Generator().manual_seed(2)
+    clicks = torch.stack([xyz[b, torch.randint(0, N, (T,), generator=g)] for b in range(B)])
+    labels = torch.tensor([[1, 1, 0, 1]]).repeat(B, 1)
+    xd, rd, cd, ld = xyz.cuda(), rgb.cuda(), clicks.cuda(), labels.cuda()
+    st = model.encode(xd, rd)
+    outs = model.click_session(st, cd, ld)
+    # the same loop written out
+    best, ref = None, []
+    for t in range(T):
+        m, i = model.decode(st, cd[:, : t + 1].contiguous(), ld[:, : t + 1].contiguous(), best, best is None)
+        ref.append((m, i))
+        best = torch.gather(m, 1, i.argmax(1).view(-1, 1, 1).expand(-1, 1, N))[:, 0] if t == 0 else m[:, 0]
+    for (m1, i1), (m2, i2) in zip(outs, ref):
+        assert torch.equal(m1, m2) and torch.equal(i1, i2)
+    pipe = GraphPipeline(model, xd, rd, cd, ld, None, True, slots=2, dense_streams=2, session=True)
+    for _ in range(2):
+        pipe.submit(xd, rd, cd, ld)
+    for _ in range(2):
+        m, i = pipe.next()
+        assert torch.equal(m, outs[-1][0]) and torch.equal(i, outs[-1][1])
+    want = [O.click_loop(sd, cfg, xyz[b:b + 1], rgb[b:b + 1], clicks[b:b + 1], labels[b:b + 1])[-1] for b in range(B)]
+    for b in range(B):
+        assert _maxerr(outs[-1][0][b:b + 1], want[b][0]) < TOL and _maxerr(outs[-1][1][b:b + 1], want[b][1]) < TOL
+    model.check_coordinate_range()

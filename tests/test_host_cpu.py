@@ -160,3 +160,34 @@ def test_host_side_planning_functions_without_a_gpu():
     assert lib.psam_twoway_decoder_ws_bytes(8, 6, 512, 256, 2048) > 4 * 6 * 8 * 512 * 256
     assert lib.psam_upscale_masks_ws_bytes(8, 32768, 512, 3, 256) > 4 * 8 * 32768 * 256
     assert lib.psam_twoway_tokens_ws_floats(2048) == 64 * (5 * 256 + 2048) + 64
+
+
+def test_gemm_mode_is_per_context():
+    """The GEMM arithmetic mode is a context variable: a model (or server thread) entering its own precision does not change what another
+    thread sees (two models of different precision, the threaded demo server)."""
+    import threading
+    from point_sam_amd import ops
+    seen, go, done = {}, threading.Event(), threading.Event()
+
+    def other():
+        with ops.gemm_mode("bf16x6"):
+            seen["inside_other"] = ops.GEMM_MODE
+            go.set()
+            done.wait(5)
+            seen["other_after_main_changed"] = ops.current_gemm_mode()
+
+    t = threading.Thread(target=other)
+    t.start()
+    go.wait(5)
+    assert ops.GEMM_MODE == "f32"                      # untouched by the other thread
+    with ops.gemm_mode("f16x3"):
+        assert ops.current_gemm_mode() == "f16x3"
+        with ops.gemm_mode("f32"):
+            assert ops.GEMM_MODE == "f32"
+        assert ops.GEMM_MODE == "f16x3"
+        done.set()
+        t.join()
+    assert seen == {"inside_other": "bf16x6", "other_after_main_changed": "bf16x6"} and ops.GEMM_MODE == "f32"
+    import pytest
+    with pytest.raises(ValueError):
+        ops.gemm_mode("fp8")
