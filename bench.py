@@ -253,12 +253,18 @@ class HipHarness:
         xyz, rgb, prompt, labels = (t[:1] for t in full)
         cores = torch.get_num_threads()
         O.fps(xyz[:, :4096], 16)  # build/load the C library outside the timed region
+        # cpu_baseline TIMES the reference's own arithmetic (mode="reference": kNN / 3-NN through torch.cdist + topk, common.py:51-55,238-255); the
+        # parity CHECK uses mode="exact" (direct fp32 differences -- what the HIP kernels, the C oracle and the bit-exact index tests implement).
+        # cdist's |a|^2 + |b|^2 - 2ab form rounds distances of near neighbours differently: same neighbour sets at cfg #2
+        # (tests/test_gpu_e2e.py::test_cfg2_gap_to_reference_cdist_mode), not at cfg #3's 256-neighbour groups in a 131072-point cloud, where the
+        # reference-mode logits sit ~6e-3 from both the exact-mode oracle and the HIP path: reported as `reference_mode_gap`.
         if self.session:
-            oracle_one = lambda b: O.click_loop(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1])[-1]
+            oracle_one = lambda b, mode="exact": O.click_loop(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1], mode=mode)[-1]
         else:
-            oracle_one = lambda b: O.predict_masks(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1], None, True, mode="reference")
-        run = lambda: oracle_one(0)
-        want = run()
+            oracle_one = lambda b, mode="exact": O.predict_masks(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1], None, True, mode=mode)
+        run = lambda: oracle_one(0, "reference")
+        want_ref = run()
+        want = oracle_one(0)
         ts = []
         for _ in range(iters):
             t0 = time.perf_counter()
@@ -282,7 +288,11 @@ class HipHarness:
         parity = {"checked": f"all {masks.shape[0]} cloud(s) of the last timed step's output (the graph/stream pipeline's own result"
                              + (", last click of the session" if self.session else "") + ") vs the oracle on the same inputs and weights",
                   "max_abs_err_mask_logits": em, "max_abs_err_iou": ei, "per_cloud_max_abs_err_mask_logits": [round(e, 9) for e, _ in per_cloud],
-                  "tolerance": 1e-3, "ok": bool(em < 1e-3 and ei < 1e-3), "logit_scale": scale}
+                  "tolerance": 1e-3, "ok": bool(em < 1e-3 and ei < 1e-3), "logit_scale": scale,
+                  "oracle_mode": "exact (direct fp32 coordinate differences in kNN / 3-NN)",
+                  "reference_mode_gap": {"cloud": 0, "max_abs_err_mask_logits": float((masks[:1] - want_ref[0]).abs().max()),
+                                         "note": "same cloud against the oracle in mode='reference' (torch.cdist + topk, the arithmetic cpu_baseline times): equal to the exact "
+                                                 "mode where cdist's rounding selects the same neighbour sets"}}
         return base, parity
 
 

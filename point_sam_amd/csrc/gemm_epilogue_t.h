@@ -377,7 +377,7 @@ __device__ __forceinline__ void gemm_store_tile_t_rowln(const ArgsT& p, ep_f32x1
     }
     // ---- pass C: normalise, activate, pack, store
     const float so = f16_row_scale(p.out_k2);
-    if (h == 0 && wn == 0) {
+    if (p.pack_out && h == 0 && wn == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) p.out_scale[row_base + i * 32 + r32] = so;
     }
