@@ -244,6 +244,7 @@ int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const f
  * o [B*L, ldo]: g8-packed output for the projection GEMM, o_scale [B*L] = f16_row_scale(v_bound) for every row (v_bound >= max |v|). */
 int32_t psam_attention_packed(const void* qkv, int64_t ld, const float* sc, float* o, int64_t ldo, float* o_scale, int32_t B, int32_t H, int32_t L,
                               int32_t hd, float scale, float v_bound, psam_stream_t stream);
+void psam_attention_packed_force_variant(int32_t v); /* tuning hook: -1 default, 0 = 256-row workgroups / 3-tile ring, 1 = two 128-row workgroups per CU / 2-tile ring */
 
 /* y [M, N] = act(x [M, K] W [N, K]^T + bias) + residual for M <= 64 rows (K % 16 == 0, rows 16-byte aligned; act: none / GELU / ReLU),
  * exact fp32 products.  The decoder's token-side nn.Linear calls (7 output tokens per prompt): transformer.py:109-236. */

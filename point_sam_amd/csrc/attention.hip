@@ -645,9 +645,13 @@ constexpr int PA_BQ = 256;     // query rows per workgroup (8 waves x 32); the N
 #endif
 constexpr int PA_TILE = FA_BKV * 256;      // bytes of one K (or V) tile: 64 keys x 64 channels x 4 B
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void flash_attn_packed_kernel(const PackedAttnArgs p) {
+// RING: K/V tiles in LDS.  3 (96 KiB): tile t + 2 is issued at the barrier of tile t -- two tile times for the data, one workgroup per CU.
+// 2 (64 KiB; NW = 4): tile t + 1 is issued at the barrier of tile t -- one tile time for the data, TWO independent workgroups per CU, whose
+// phases (S^T products, softmax, PV products) drift apart and cover each other instead of idling the matrix pipe together (round 4).
+template <int NW, int RING = 3>
+__global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_kernel(const PackedAttnArgs p) {
     constexpr int HD = 64, KS = 4, DT = 2, ROWB = 256;
+    static_assert(RING == 3 || (RING == 2 && NW == 4), "ring of three tiles, or two tiles with four waves (two workgroups per CU)");
     constexpr int BQ = NW * 32, NPC = 32 / NW;      // query rows per workgroup; DMA pieces (of the 16 K + 16 V per tile) per wave
     static_assert(NW == 8 || NW == 4, "waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [3][K tile | V tile]: ring of three tiles, ONE barrier per tile
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_packed_kernel(const Packed
         }
     };
     issue_tile(0, 0);
-    if (nt > 1) issue_tile(1, 1);
+    if (RING == 3 && nt > 1) issue_tile(1, 1);
 
     // ---- this lane's query row: the hi / lo chunks of channels 16 s + 8 h .. + 7, as stored
     const int q0 = qb * BQ + wave * 32;
@@ -724,10 +728,11 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_packed_kernel(const Packed
     if (PA_PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     int buf = 0;
     for (int t = 0; t < (FA_ABL(128) ? 0 : nt); ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");      // this wave's pieces of tile t landed (tile t+1's may fly)
+        if (RING == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");      // this wave's pieces of tile t landed (tile t+1's may fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!FA_ABL(2)) __builtin_amdgcn_s_barrier();                          // tile t visible to every wave; every wave is done with tile t-1
-        if (t + 2 < nt && !FA_ABL(1)) issue_tile(t + 2, buf == 0 ? 2 : buf - 1);      // ... whose buffer takes tile t+2
+        if (RING == 3) { if (t + 2 < nt && !FA_ABL(1)) issue_tile(t + 2, buf == 0 ? 2 : buf - 1); }      // ... whose buffer takes tile t+2
+        else if (t + 1 < nt && !FA_ABL(1)) issue_tile(t + 1, buf ^ 1);
         const unsigned char* kt0 = smem + buf * 2 * PA_TILE;
         const unsigned char* vt0 = kt0 + PA_TILE;
         // ---- the tile's two 32-key sub-tiles as ONE straight-line block (the second sub-tile of a ragged last tile may lie wholly past the
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_packed_kernel(const Packed
                 for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], ph, oacc[d], 0, 0, 0);
             }
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = RING == 2 ? (buf ^ 1) : (buf == 2 ? 0 : buf + 1);
     }
 
     if (FA_ABL(256)) { if (l_run == 123.f) p.o_scale[0] = oacc[0][0] + oacc[1][5]; return; }
@@ -847,6 +852,16 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_packed_kernel(const Packed
             if (qrow < p.L) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
         }
 }
+
+static int g_attn_variant = -1;
+static int attn_variant_env() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("PSAM_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+// tuning hook: -1 = default (environment PSAM_ATTN_VARIANT, else 0), 0 = one 256-row workgroup per CU on a three-tile ring, 1 = two 128-row
+// workgroups per CU on a two-tile ring
+PSAM_API void psam_attention_packed_force_variant(int32_t v) { g_attn_variant = v; }
 
 // qkv: g8-packed rows [B * L, ld] (containers of 4 bytes: q | k | v column blocks of D = H * 64 each, one scale for all rows in
 // sc[...]); o [B * L, ldo]: g8-packed attention output for the projection GEMM, o_scale [B * L] its (constant) row scales
@@ -873,7 +888,8 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(__atomic_load_n(&attr_done, __ATOMIC_ACQUIRE) & bit)) {
             PSAM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-                         hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                         hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+                         hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * PA_TILE) == hipSuccess,
                          PSAM_EINVAL, "psam_attention_packed: cannot reserve LDS");
             __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
         }
@@ -885,6 +901,13 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
     // and 16 heads is 128 of them on 256 CUs (99 us); 128-row workgroups fill the chip
     const int64_t wg8 = (int64_t)psam_cdiv(L, PA_BQ) * H * B;
     const bool small = force_nw ? force_nw == 4 : (wg8 < ncu && L > PA_BQ / 2);
+    // two 128-row workgroups per CU on a two-tile ring where the 256-row grid is about one workgroup per CU (B = 8 clouds x 16 heads x 512 tokens: 256)
+    const int variant = g_attn_variant >= 0 ? g_attn_variant : attn_variant_env();
+    const int64_t wg4 = (int64_t)psam_cdiv(L, PA_BQ / 2) * H * B;
+    if (variant == 1 && L > PA_BQ / 2 && wg4 <= (int64_t)4 * ncu) {
+        hipLaunchKernelGGL((flash_attn_packed_kernel<4, 2>), dim3((unsigned)wg4), dim3(256), 2 * 2 * PA_TILE, stream, p);
+        return psam_launch_status("psam_attention_packed: launch failed");
+    }
     if (small) hipLaunchKernelGGL(flash_attn_packed_kernel<4>, dim3((unsigned)(psam_cdiv(L, PA_BQ / 2) * H * B)), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(flash_attn_packed_kernel<8>, dim3((unsigned)wg8), dim3(512), lds, stream, p);
     return psam_launch_status("psam_attention_packed: launch failed");
