@@ -275,6 +275,35 @@ size_t psam_eva_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden);
 /* x [B*L, dim] fp32, updated in place; ws: psam_eva_block_ws_bytes(B*L, dim, hidden) bytes of scratch */
 int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes, psam_stream_t stream);
 
+/* ONE GELU-MLP transformer block with a fused qkv projection (timm eva_giant_patch14_560, configs/model/giant.yaml; called through
+ * pc_sam/model/pc_encoder.py:138-139, no rope): x += proj(SDPA(qkv(LN1 x) + [q_bias | 0 | v_bias])); x += fc2(GELU(fc1(LN2 x))).  "f16x3" arithmetic,
+ * sequenced as the Python host sequences it (bit-identical): LayerNorm (packed rows) | qkv GEMM | attention on the fp16 pipe for head dims that are
+ * multiples of 8 in (64, 128] (88 runs zero-padded to 128) or 64, output packed for the projection | projection + residual | LayerNorm | fc1 + GELU |
+ * fc2 + residual.  Few token rows (one cloud: M = 512) leave most of the chip idle on whole-tile launches: every plain GEMM of the block takes the
+ * library's split-K factor (psam_gemm_f16x3p_splitk) with the partial planes in the caller's workspace; when fc1 needs no split its epilogue hands
+ * GELU(.) to fc2 g8-packed (per-row bound from the LayerNorm's L2 norm) and the scale + pack pass disappears.  dim % 32 == 0, hidden % 32 == 0,
+ * 256 <= dim <= 4096, B * L >= 256.  `precision`: PSAM_PRECISION_F16X3 (the f32 / bf16x6 arithmetic of the same block is reachable through the
+ * per-operator entries only). */
+#define PSAM_PRECISION_F16X3 2
+typedef struct {
+    const float *norm1_w, *norm1_b, *qkv_w, *q_bias, *v_bias, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    int32_t dim, heads, hidden, precision;
+    float eps;
+} psam_eva_gelu_block_weights_t;
+typedef struct {
+    int32_t dim, heads, hidden, precision;
+    float eps, vk1, vk2, u_c1, u_c0;      /* attention-output bound from the LayerNorm row scale; fc1 row bound c1 t + c0 from t = ||LN2 x||_2 */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *proj_b, *fc1_b, *fc2_b;
+    int64_t o_wqkv, o_sqkv, o_bqkv, o_wproj, o_sproj, o_w1, o_s1, o_w2, o_s2;      /* byte offsets into `prepared` */
+} psam_eva_gelu_block_plan_t;
+size_t psam_eva_gelu_block_prepared_bytes(int32_t dim, int32_t hidden);
+int32_t psam_eva_gelu_block_prepare(const psam_eva_gelu_block_weights_t* weights, psam_eva_gelu_block_plan_t* plan, void* prepared, size_t prepared_bytes,
+                                    psam_stream_t stream);
+size_t psam_eva_gelu_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden);
+/* x [B*L, dim] fp32, updated in place */
+int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes,
+                            psam_stream_t stream);
+
 /* PatchEncoder.forward on kNN groups in one call (csrc/blocks.hip): the mini-PointNet of the patch embedding (features = rgb) and of the mask
  * encoder (features = mask logits) -- pc_sam/model/common.py:477-506 after the gather of :99-120 / :126-187 -- "f16x3", fused as the Python host
  * runs it (six launches; both max-pools inside GEMM epilogues -- for group sizes above 64 as 64-row parts + psam_group_max over the parts).

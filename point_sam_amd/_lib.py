@@ -54,6 +54,10 @@ SIGNATURES = {
     "psam_eva_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_eva_block_ws_bytes": (size_t, [i64, i32, i32]),
     "psam_eva_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
+    "psam_eva_gelu_block_prepared_bytes": (size_t, [i32, i32]),
+    "psam_eva_gelu_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
+    "psam_eva_gelu_block_ws_bytes": (size_t, [i64, i32, i32]),
+    "psam_eva_gelu_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
     "psam_patch_encoder_prepared_bytes": (size_t, [i32, i32, i32]),
     "psam_patch_encoder_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_patch_encoder_ws_bytes": (size_t, [i64, i64, i32, i32]),
@@ -113,6 +117,19 @@ class EvaBlockPlan(ctypes.Structure):
     _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "hidden_pad")] + [(n, f32) for n in ("eps", "qkv_bound", "v_bound", "u_c2", "u_c1", "u_c0")] +
                 [(n, ptr) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "proj_b")] +
                 [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_b1", "o_w2g", "o_s2g", "o_lnc", "o_lnd")])
+
+
+class EvaGeluBlockWeights(ctypes.Structure):
+    """psam_eva_gelu_block_weights_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, ptr) for n in ("norm1_w", "norm1_b", "qkv_w", "q_bias", "v_bias", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")] +
+                [("dim", i32), ("heads", i32), ("hidden", i32), ("precision", i32), ("eps", f32)])
+
+
+class EvaGeluBlockPlan(ctypes.Structure):
+    """psam_eva_gelu_block_plan_t (include/pointsam_hip.h)."""
+    _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "precision")] + [(n, f32) for n in ("eps", "vk1", "vk2", "u_c1", "u_c0")] +
+                [(n, ptr) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "proj_b", "fc1_b", "fc2_b")] +
+                [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_w2", "o_s2")])
 
 
 class PatchEncoderWeights(ctypes.Structure):

@@ -856,10 +856,10 @@ __global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_
 static int g_attn_variant = -1;
 static int attn_variant_env() {
     static int v = -2;
-    if (v == -2) { const char* e = getenv("PSAM_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
+    if (v == -2) { const char* e = getenv("PSAM_ATTN_VARIANT"); v = e ? atoi(e) : 1; }
     return v;
 }
-// tuning hook: -1 = default (environment PSAM_ATTN_VARIANT, else 0), 0 = one 256-row workgroup per CU on a three-tile ring, 1 = two 128-row
+// tuning hook: -1 = default (environment PSAM_ATTN_VARIANT, else 1), 0 = one 256-row workgroup per CU on a three-tile ring, 1 = two 128-row
 // workgroups per CU on a two-tile ring
 PSAM_API void psam_attention_packed_force_variant(int32_t v) { g_attn_variant = v; }
 

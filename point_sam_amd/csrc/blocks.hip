@@ -221,6 +221,141 @@ PSAM_API int32_t psam_eva_block(const psam_eva_block_plan_t* plan, const void* p
 }
 
 // ================================================================================================================================
+// psam_eva_gelu_block: one block of the giant encoder (timm eva_giant_patch14_560: fused qkv with q / v bias, GELU MLP, head dim 88) -- the launch
+// sequence of PointCloudSAM._block for `not vit.swiglu` (point_sam_amd/model.py), decisions included: the same split-K factors (the library's own
+// psam_gemm_f16x3p_splitk), the same packed hand-overs, hence the same bits.
+// ================================================================================================================================
+PSAM_API size_t psam_eva_gelu_block_prepared_bytes(int32_t dim, int32_t hidden) {
+    if (dim <= 0 || hidden <= 0) return 0;
+    const int64_t D = dim, Dp = kpad(dim), H = hidden, Hp = kpad(hidden);
+    return (size_t)(align256(3 * D * Dp * 4) + 2 * align256(3 * D * 4) + align256(D * Dp * 4) + align256(D * 4) + align256(H * Dp * 4) + align256(H * 4) +
+                    align256(D * Hp * 4) + align256(D * 4));
+}
+
+PSAM_API int32_t psam_eva_gelu_block_prepare(const psam_eva_gelu_block_weights_t* wt, psam_eva_gelu_block_plan_t* plan, void* prepared, size_t prepared_bytes,
+                                             hipStream_t stream) {
+    PSAM_REQUIRE(wt && plan && prepared, PSAM_EINVAL, "psam_eva_gelu_block_prepare: null pointer");
+    const int D = wt->dim, H = wt->hidden, heads = wt->heads;
+    PSAM_REQUIRE(wt->precision == PSAM_PRECISION_F16X3, PSAM_EINVAL, "psam_eva_gelu_block_prepare: the coarse entry is built for PSAM_PRECISION_F16X3");
+    PSAM_REQUIRE(D >= 256 && D <= 4096 && D % 32 == 0 && H > 0 && H % 32 == 0 && heads > 0 && D % heads == 0, PSAM_EINVAL,
+                 "psam_eva_gelu_block_prepare: need 256 <= dim <= 4096, dim % 32 == 0, hidden % 32 == 0");
+    const int hd = D / heads;
+    PSAM_REQUIRE(hd == 64 || (hd > 64 && hd <= 128 && hd % 8 == 0), PSAM_EINVAL, "psam_eva_gelu_block_prepare: head dim must be 64 or a multiple of 8 in (64, 128]");
+    PSAM_REQUIRE(prepared_bytes >= psam_eva_gelu_block_prepared_bytes(D, H), PSAM_EWORKSPACE, "psam_eva_gelu_block_prepare: prepared buffer too small");
+    const float* ptrs[] = {wt->norm1_w, wt->norm1_b, wt->qkv_w, wt->q_bias, wt->v_bias, wt->proj_w, wt->proj_b, wt->norm2_w, wt->norm2_b, wt->fc1_w, wt->fc1_b, wt->fc2_w, wt->fc2_b};
+    for (const float* q : ptrs) PSAM_REQUIRE(q, PSAM_EINVAL, "psam_eva_gelu_block_prepare: null weight pointer");
+    PSAM_REQUIRE(hipStreamSynchronize(stream) == hipSuccess, PSAM_EINVAL, "psam_eva_gelu_block_prepare: stream error");
+    auto fetch = [&](const float* dev, int64_t n) { std::vector<float> h((size_t)n); return hipMemcpy(h.data(), dev, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? h : std::vector<float>(); };
+#define FETCH(name, dev, n) std::vector<float> name = fetch(dev, n); PSAM_REQUIRE((int64_t)name.size() == (int64_t)(n), PSAM_EINVAL, "psam_eva_gelu_block_prepare: cannot read a weight tensor")
+    FETCH(vw, wt->qkv_w + (int64_t)2 * D * D, (int64_t)D * D); FETCH(qb, wt->q_bias, D); FETCH(vb, wt->v_bias, D);
+    FETCH(w1, wt->fc1_w, (int64_t)H * D); FETCH(b1, wt->fc1_b, H);
+#undef FETCH
+    std::vector<float> bqkv((size_t)3 * D, 0.f);
+    for (int i = 0; i < D; ++i) { bqkv[i] = qb[i]; bqkv[2 * D + i] = vb[i]; }
+    // bound of |V| from the scale of the LayerNorm row that produced it (psam_attention_f16x3_ex): k1 = 2^15 sqrt(D) max ||W_v[n]||, k2 = max |b_v|
+    double nv = 0.0, bv = 0.0, n1 = 0.0, bm1 = 0.0;
+    for (int n = 0; n < D; ++n) { nv = std::fmax(nv, row_norm(&vw[(size_t)n * D], D)); bv = std::fmax(bv, std::fabs((double)vb[n])); }
+    for (int n = 0; n < H; ++n) { n1 = std::fmax(n1, row_norm(&w1[(size_t)n * D], D)); bm1 = std::fmax(bm1, std::fabs((double)b1[n])); }
+    std::memset(plan, 0, sizeof(*plan));
+    plan->dim = D; plan->heads = heads; plan->hidden = H; plan->precision = wt->precision; plan->eps = wt->eps;
+    plan->vk1 = (float)(32768.0 * std::sqrt((double)D) * nv); plan->vk2 = (float)bv;
+    plan->u_c1 = (float)(1.002 * n1); plan->u_c0 = (float)(1.002 * bm1 + 1e-30);      // |GELU(W_n . h + b_n)| <= ||W_n|| t + |b_n|, t = ||h||_2
+    plan->norm1_w = wt->norm1_w; plan->norm1_b = wt->norm1_b; plan->norm2_w = wt->norm2_w; plan->norm2_b = wt->norm2_b; plan->proj_b = wt->proj_b;
+    plan->fc1_b = wt->fc1_b; plan->fc2_b = wt->fc2_b;
+    const int Dp = kpad(D), Hp = kpad(H);
+    Carve cv(prepared);
+    float* p_wqkv = cv.take<float>((int64_t)3 * D * Dp); float* s_wqkv = cv.take<float>(3 * D); float* d_bqkv = cv.take<float>(3 * D);
+    float* p_proj = cv.take<float>((int64_t)D * Dp); float* s_proj = cv.take<float>(D);
+    float* p_w1 = cv.take<float>((int64_t)H * Dp); float* s_w1 = cv.take<float>(H);
+    float* p_w2 = cv.take<float>((int64_t)D * Hp); float* s_w2 = cv.take<float>(D);
+    plan->o_wqkv = (char*)p_wqkv - cv.base; plan->o_sqkv = (char*)s_wqkv - cv.base; plan->o_bqkv = (char*)d_bqkv - cv.base;
+    plan->o_wproj = (char*)p_proj - cv.base; plan->o_sproj = (char*)s_proj - cv.base; plan->o_w1 = (char*)p_w1 - cv.base; plan->o_s1 = (char*)s_w1 - cv.base;
+    plan->o_w2 = (char*)p_w2 - cv.base; plan->o_s2 = (char*)s_w2 - cv.base;
+    int32_t rc = PSAM_OK;
+    auto pack = [&](const float* src, int rows, int K, float* packed, float* scales) {
+        if (rc != PSAM_OK) return;
+        rc = psam_row_scale_f16(src, K, rows, K, scales, stream);
+        if (rc == PSAM_OK) rc = psam_pack_rows_f16x2_g8(src, K, scales, rows, K, packed, kpad(K), stream);
+    };
+    pack(wt->qkv_w, 3 * D, D, p_wqkv, s_wqkv);
+    pack(wt->proj_w, D, D, p_proj, s_proj);
+    pack(wt->fc1_w, H, D, p_w1, s_w1);
+    pack(wt->fc2_w, D, H, p_w2, s_w2);
+    if (rc == PSAM_OK && hipMemcpy(d_bqkv, bqkv.data(), bqkv.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { psam_set_error("psam_eva_gelu_block_prepare: upload failed"); rc = PSAM_EINVAL; }
+    if (rc == PSAM_OK && hipStreamSynchronize(stream) != hipSuccess) { psam_set_error("psam_eva_gelu_block_prepare: packing failed"); rc = PSAM_EINVAL; }
+    return rc;
+}
+
+PSAM_API size_t psam_eva_gelu_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden) {
+    if (M <= 0 || dim <= 0 || hidden <= 0) return 0;
+    const int64_t D = dim, Dp = kpad(dim), Hp = kpad(hidden), widest = 3 * D > Hp ? 3 * D : Hp;
+    int64_t b = 0;
+    b += align256(M * Dp * 4) + 4 * align256(M * 4);      // h (packed LayerNorm rows), its scales, the fc1 bound, attention-output scales, fc2-input scales
+    b += align256(M * 3 * D * 4);                         // qkv, fp32
+    b += align256(M * Dp * 4);                            // attention output, packed
+    b += 2 * align256(M * Hp * 4);                        // GELU(fc1) rows (fp32 or packed) and their packed copy
+    b += align256(4 * M * widest * 4);                    // split-K partial planes (<= 4 per launch)
+    return (size_t)b;
+}
+
+PSAM_API int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes,
+                                     hipStream_t stream) {
+    PSAM_REQUIRE(plan && prepared && x && ws, PSAM_EINVAL, "psam_eva_gelu_block: null pointer");
+    const int D = plan->dim, H = plan->hidden, heads = plan->heads, Dp = kpad(D), Hp = kpad(H), hd = D / heads;
+    const int64_t M = (int64_t)B * L;
+    PSAM_REQUIRE(B > 0 && L > 0 && M >= 256 && M < ((int64_t)1 << 31), PSAM_EINVAL, "psam_eva_gelu_block: B * L must be at least 256 (the packed-operand GEMMs)");
+    PSAM_REQUIRE(ws_bytes >= psam_eva_gelu_block_ws_bytes(M, D, H), PSAM_EWORKSPACE, "psam_eva_gelu_block: workspace too small");
+    const char* pb = static_cast<const char*>(prepared);
+    auto P = [&](int64_t off) { return reinterpret_cast<const float*>(pb + off); };
+    const int64_t widest = 3 * (int64_t)D > Hp ? 3 * (int64_t)D : Hp;
+    Carve cv(ws);
+    float* h = cv.take<float>(M * Dp);
+    float* rs = cv.take<float>(M); float* ub = cv.take<float>(M); float* so = cv.take<float>(M); float* sg = cv.take<float>(M);
+    float* qkv = cv.take<float>(M * 3 * D);
+    float* o = cv.take<float>(M * Dp);
+    float* g = cv.take<float>(M * Hp); float* gp = cv.take<float>(M * Hp);
+    float* planes = cv.take<float>(4 * M * widest);
+    // a plain GEMM as the host's ops.linear issues it: the library's split-K factor, partial planes in the workspace
+    auto gemm = [&](const float* A, int64_t lda, const float* sA, int64_t ow, int64_t os, int N, int K, float* C, int64_t ldc, const float* bias, const float* res, int act) -> int32_t {
+        psam_gemm_fuse_t f;
+        std::memset(&f, 0, sizeof(f));
+        const int ks = ((N & 3) == 0 && (ldc & 3) == 0) ? psam_gemm_f16x3p_splitk((int32_t)M, N, K, act) : 1;
+        if (ks > 1) { f.splitk = ks; f.splitk_ws = planes; f.splitk_plane = M * (int64_t)N; }
+        return psam_gemm_f16x3p_ex(A, lda, sA, P(ow), K, P(os), C, ldc, bias, res, res ? ldc : 0, nullptr, 0, 0, (int32_t)M, N, K, 1.f, act, ks > 1 ? &f : nullptr, stream);
+    };
+    int32_t rc;
+    // attention half
+    rc = psam_layernorm_ex(x, D, nullptr, 0, plan->norm1_w, plan->norm1_b, h, Dp, M, D, plan->eps, 0, rs, 1, stream);
+    if (rc) return rc;
+    rc = gemm(h, Dp, rs, plan->o_wqkv, plan->o_sqkv, 3 * D, Dp, qkv, 3 * D, P(plan->o_bqkv), nullptr, 0);
+    if (rc) return rc;
+    rc = psam_attention_f16x3_ex(qkv, 3 * D, (int64_t)L * 3 * D, qkv + D, 3 * D, (int64_t)L * 3 * D, qkv + 2 * D, 3 * D, (int64_t)L * 3 * D, o, Dp, (int64_t)L * Dp, B, heads, L, L,
+                                 hd, (float)std::pow((double)hd, -0.5), rs, plan->vk1, plan->vk2, so, stream);      // float(hd ** -0.5), as the host computes it
+    if (rc) return rc;
+    rc = gemm(o, Dp, so, plan->o_wproj, plan->o_sproj, D, Dp, x, D, plan->proj_b, x, 0);
+    if (rc) return rc;
+    // MLP half
+    const bool fused_gelu = (M % 256 == 0) && (H % 128 == 0) && psam_gemm_f16x3p_splitk((int32_t)M, H, Dp, PSAM_ACT_GELU) == 1;
+    if (fused_gelu) {
+        rc = psam_layernorm_ex2(x, D, nullptr, 0, plan->norm2_w, plan->norm2_b, h, Dp, M, D, plan->eps, 0, rs, 1, ub, 0.f, plan->u_c1, plan->u_c0, stream);
+        if (rc) return rc;
+        psam_gemm_fuse_t f;
+        std::memset(&f, 0, sizeof(f));
+        f.pack_out = 1; f.out_scale = sg; f.out_bound = ub;
+        rc = psam_gemm_f16x3p_ex(h, Dp, rs, P(plan->o_w1), Dp, P(plan->o_s1), g, Hp, plan->fc1_b, nullptr, 0, nullptr, 0, 0, (int32_t)M, H, Dp, 1.f, PSAM_ACT_GELU, &f, stream);
+        if (rc) return rc;
+        return gemm(g, Hp, sg, plan->o_w2, plan->o_s2, D, Hp, x, D, plan->fc2_b, x, 0);
+    }
+    rc = psam_layernorm_ex(x, D, nullptr, 0, plan->norm2_w, plan->norm2_b, h, Dp, M, D, plan->eps, 0, rs, 1, stream);
+    if (rc) return rc;
+    rc = gemm(h, Dp, rs, plan->o_w1, plan->o_s1, H, Dp, g, H, plan->fc1_b, nullptr, PSAM_ACT_GELU);
+    if (rc) return rc;
+    rc = psam_scale_pack_rows_g8(g, H, (int32_t)M, H, gp, Hp, sg, stream);
+    if (rc) return rc;
+    return gemm(gp, Hp, sg, plan->o_w2, plan->o_s2, D, Hp, x, D, plan->fc2_b, x, 0);
+}
+
+// ================================================================================================================================
 // psam_patch_encoder: PatchEncoder.forward on kNN groups (pc_sam/model/common.py:477-506 after KNNGrouper / group_with_centers_and_knn,
 // :99-120 / :126-187) -- the mini-PointNet of the patch embedding (features = rgb) and of the mask encoder (features = mask logits) -- as the
 // Python host runs it in "f16x3": gather + Linear + LayerNorm + GELU in one kernel (packed rows) | conv1.3 GEMM with the group maximum and a

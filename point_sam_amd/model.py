@@ -237,6 +237,9 @@ class PointCloudSAM:
             if cfg.vit.swiglu and ops.EvaBlock.supported(D, cfg.vit.heads, cfg.vit.mlp_hidden):
                 for blk in self.blocks:     # the library's own packing of the block (psam_eva_block_prepare)
                     blk.c_block = ops.EvaBlock(w, blk.p, D, cfg.vit.heads, cfg.vit.mlp_hidden, cfg.vit.ln_eps)
+            elif not cfg.vit.swiglu and ops.EvaGeluBlock.supported(D, cfg.vit.heads, cfg.vit.mlp_hidden):
+                for blk in self.blocks:     # the giant encoder's block (psam_eva_gelu_block_prepare)
+                    blk.c_block = ops.EvaGeluBlock(w, blk.p, D, cfg.vit.heads, cfg.vit.mlp_hidden, cfg.vit.ln_eps)
             torch.cuda.current_stream(self.device).synchronize()   # the packed weights are consumed from several streams afterwards
 
     # ------------------------------------------------------------------------------------------ building blocks
@@ -324,8 +327,9 @@ class PointCloudSAM:
         # "f16x3" GEMMs need a power-of-two scale per operand row and stage hi/lo fp16 planes: the LayerNorms that feed them emit
         # the scale and (when the float4 LN path applies) the packed planes directly, so the GEMM does no split arithmetic for A
         f16 = self.precision == "f16x3"
-        if (f16 and self.c_blocks and hasattr(blk, "c_block") and x.shape[0] % 256 == 0 and self.fuse_mlp and self.fuse_attn_pack and self.fuse_attn_operands
-                and self.row_bounds and ops.GEMM_MODE == "f16x3" and x.is_contiguous()):
+        if (f16 and self.c_blocks and hasattr(blk, "c_block") and self.fuse_mlp and self.fuse_attn_pack and self.fuse_attn_operands
+                and self.row_bounds and ops.GEMM_MODE == "f16x3" and x.is_contiguous()
+                and (x.shape[0] % 256 == 0 if vit.swiglu else x.shape[0] >= ops.SPLIT_MIN_M)):
             return blk.c_block.run(x, B, L)
         pk = f16 and x.shape[0] >= ops.SPLIT_MIN_M and isinstance(blk.wqkv, ops.F16Weight) and ops.layernorm_can_pack(D)
         rs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if pk else None

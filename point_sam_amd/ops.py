@@ -576,6 +576,51 @@ class EvaBlock:
         return x
 
 
+class EvaGeluBlock:
+    """One block of the giant encoder (fused qkv with q / v bias, GELU MLP; timm eva_giant_patch14_560) prepared for psam_eva_gelu_block
+    (csrc/blocks.hip).  w: name -> fp32 device tensor; prefix 'pc_encoder.transformer.blocks.i'."""
+    PRECISION_F16X3 = 2
+
+    def __init__(self, w, prefix: str, dim: int, heads: int, hidden: int, eps: float):
+        import ctypes
+        L = _lib.load()
+        wt = _lib.EvaGeluBlockWeights()
+        self.keep = []
+        names = dict(norm1_w="norm1.weight", norm1_b="norm1.bias", qkv_w="attn.qkv.weight", q_bias="attn.q_bias", v_bias="attn.v_bias", proj_w="attn.proj.weight",
+                     proj_b="attn.proj.bias", norm2_w="norm2.weight", norm2_b="norm2.bias", fc1_w="mlp.fc1.weight", fc1_b="mlp.fc1.bias", fc2_w="mlp.fc2.weight",
+                     fc2_b="mlp.fc2.bias")
+        for slot, n in names.items():
+            t = w[f"{prefix}.{n}"]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"{prefix}.{n}: contiguous fp32 expected")
+            self.keep.append(t)
+            setattr(wt, slot, t.data_ptr())
+        wt.dim, wt.heads, wt.hidden, wt.precision, wt.eps = int(dim), int(heads), int(hidden), self.PRECISION_F16X3, float(eps)
+        self.plan = _lib.EvaGeluBlockPlan()
+        self.blob = torch.empty(int(L.psam_eva_gelu_block_prepared_bytes(dim, hidden)), dtype=torch.uint8, device=self.keep[0].device)
+        check(L.psam_eva_gelu_block_prepare(ctypes.byref(wt), ctypes.byref(self.plan), self.blob.data_ptr(), self.blob.numel(), _stream()), "psam_eva_gelu_block_prepare")
+        self.dim, self.hidden = int(dim), int(hidden)
+
+    @staticmethod
+    def supported(dim: int, heads: int, hidden: int) -> bool:
+        hd = dim // heads
+        return dim % heads == 0 and 256 <= dim <= 4096 and dim % 32 == 0 and hidden % 32 == 0 and (hd == 64 or (64 < hd <= 128 and hd % 8 == 0))
+
+    def run(self, x, B: int, L: int, ws=None):
+        """x [B*L, dim] fp32, updated in place."""
+        import ctypes
+        lib = _lib.load()
+        _chk(x, name="x")
+        M = B * L
+        if x.shape != (M, self.dim) or not x.is_contiguous():
+            raise ValueError("x must be a contiguous [B*L, dim] tensor")
+        need = int(lib.psam_eva_gelu_block_ws_bytes(M, self.dim, self.hidden))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        check(lib.psam_eva_gelu_block(ctypes.byref(self.plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), _stream()), "psam_eva_gelu_block")
+        return x
+
+
 class CPatchEncoder:
     """A PatchEncoder (common.py:477-506) prepared for psam_patch_encoder (csrc/blocks.hip).  prefix: 'pc_encoder.patch_embed.patch_encoder' |
     'mask_encoder.patch_encoder'."""

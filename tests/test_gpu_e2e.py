@@ -209,6 +209,39 @@ def test_c_eva_block_matches_python_sequence(gpu):
         blk.run(torch.randn(100, cfg.vit.dim, device="cuda"), 1, 100)      # M % 256 != 0
 
 
+def test_c_eva_gelu_block_matches_python_sequence(gpu):
+    """psam_eva_gelu_block (the giant encoder's block through the coarse C ABI: fused qkv with q / v bias, head dim 88 on the fp16-pipe attention,
+    GELU MLP, the library's split-K factors) against the same launches sequenced by the Python host: one cloud (M = 512 token rows: split-K in
+    every plain GEMM, fc1 unfused) and a batch (M = 2304: no split, fc1 hands GELU(.) to fc2 packed) -- the same kernels in the same order with
+    the same decisions, so the embeddings agree to fp32 round-off at worst (the bounds are computed twice: C++ doubles / torch doubles)."""
+    from dataclasses import replace
+    from point_sam_amd import ops
+    from point_sam_amd.config import ViTConfig
+    cfg = replace(get_config("giant", 256, 16), vit=ViTConfig("mini_eva_giant", 352, 3, 4, 1024, False))      # head dim 88
+    sd = random_state_dict(cfg, seed=12)
+    model = gpu(cfg, sd, precision="f16x3")
+    assert all(isinstance(b.c_block, ops.EvaGeluBlock) for b in model.blocks)
+    for B, N in ((2, 4096), (9, 2048)):
+        xyz, rgb, prompt, labels = O.synthetic_batch(B, N, seed=13 + B)
+        outs = {}
+        for c in (True, False):
+            model.c_blocks = c
+            st = model.encode(xyz.cuda(), rgb.cuda())
+            outs[c] = (st.pc_embeddings, *model.decode(st, prompt.cuda(), labels.cuda(), None, True))
+        model.c_blocks = True
+        errs = [_maxerr(a, b) for a, b in zip(outs[True], outs[False])]
+        print(f"\n[psam_eva_gelu_block vs Python-sequenced launches, B={B} (M={B * 256})] max|diff| embeddings {errs[0]:.2e} masks {errs[1]:.2e} iou {errs[2]:.2e}")
+        assert max(errs) < 2e-5
+    blk = model.blocks[0].c_block
+    x = torch.randn(512, cfg.vit.dim, device="cuda")
+    a, b = blk.run(x.clone(), 2, 256), blk.run(x.clone(), 2, 256)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and not torch.equal(a, x)
+    import ctypes
+    lib = ops._lib.load()
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    assert lib.psam_eva_gelu_block(ctypes.byref(blk.plan), blk.blob.data_ptr(), x.data_ptr(), 2, 256, small.data_ptr(), small.numel(), None) == -3      # PSAM_EWORKSPACE
+
+
 def test_attention_packed_output_is_transparent(gpu):
     """Attention writing its output packed for the projection (bound-derived per-cloud scale) vs fp32 output + separate pack pass: a
     power-of-two scale does not change the decoded hi + lo except where lo goes subnormal (elements ~2^-10 below the row maximum, since
