@@ -251,6 +251,23 @@ void psam_attention_packed_force_variant(int32_t v); /* tuning hook: -1 default,
 int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                            float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 
+/* Up to three skinny Linears over the same M <= 64 input rows in one launch: y_i = act_i((x_i + xadd_i) W_i^T + bias_i), xadd optional (the
+ * decoder's q = k = queries + query_pe, v = queries: transformer.py:153-170,214-236).  All jobs share ldx (x rows), ldxadd, ldw, M and K. */
+typedef struct {
+    const float* x; const float* xadd; const float* W; const float* bias; float* y;
+    int64_t ldy;
+    int32_t N, act;
+} psam_skinny_job_t;
+typedef struct {
+    psam_skinny_job_t job[3];
+    int32_t n;
+} psam_skinny_jobs_t;
+int32_t psam_linear_skinny_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int64_t ldxadd, int64_t ldw, int32_t M, int32_t K, psam_stream_t stream);
+/* psam_scale_pack_rows_g8 of X + add[(row / (rep * rows_per_set)) * rows_per_set + row % rows_per_set]: the broadcast positional add of the decoder's
+ * keys (k = keys + key_pe, transformer.py:160-170) folded into the pass that scales and packs the rows for the k / q projection GEMMs. */
+int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const float* add, int64_t ldadd, int32_t rows_per_set, int32_t rep, int32_t rows, int32_t K,
+                                    void* P, int64_t ldp, float* scale, psam_stream_t stream);
+
 /* ONE EVA02 (SwiGLU) transformer block of the patch encoder in one call (csrc/blocks.hip) -- timm's block as the reference runs it
  * (pc_sam/model/pc_encoder.py:138-139, no rope): x += proj(SDPA(LN1 x)); x += fc2(LN(SiLU(fc1_g h) * fc1_x h)), h = LN2 x.  "f16x3" arithmetic with
  * every hand-over fused as the Python host does it: eight launches, nothing in between.  Head dim 64, dim % 32 == 0, B * L % 256 == 0.

@@ -54,6 +54,8 @@ SIGNATURES = {
     "psam_eva_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_eva_block_ws_bytes": (size_t, [i64, i32, i32]),
     "psam_eva_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
+    "psam_linear_skinny_multi": (i32, [ptr, i64, i64, i64, i32, i32, ptr]),
+    "psam_scale_pack_rows_g8_add": (i32, [ptr, i64, ptr, i64, i32, i32, i32, i32, ptr, i64, ptr, ptr]),
     "psam_eva_gelu_block_prepared_bytes": (size_t, [i32, i32]),
     "psam_eva_gelu_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_eva_gelu_block_ws_bytes": (size_t, [i64, i32, i32]),
@@ -117,6 +119,16 @@ class EvaBlockPlan(ctypes.Structure):
     _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "hidden_pad")] + [(n, f32) for n in ("eps", "qkv_bound", "v_bound", "u_c2", "u_c1", "u_c0")] +
                 [(n, ptr) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "proj_b")] +
                 [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_b1", "o_w2g", "o_s2g", "o_lnc", "o_lnd")])
+
+
+class SkinnyJob(ctypes.Structure):
+    """psam_skinny_job_t (include/pointsam_hip.h)."""
+    _fields_ = [(n, ptr) for n in ("x", "xadd", "W", "bias", "y")] + [("ldy", i64), ("N", i32), ("act", i32)]
+
+
+class SkinnyJobs(ctypes.Structure):
+    """psam_skinny_jobs_t (include/pointsam_hip.h)."""
+    _fields_ = [("job", SkinnyJob * 3), ("n", i32)]
 
 
 class EvaGeluBlockWeights(ctypes.Structure):

@@ -629,7 +629,8 @@ PSAM_API int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* wt, ps
 PSAM_API size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, int32_t dim, int32_t mlp) {
     if (Z <= 0 || T <= 0 || G <= 0 || dim <= 0 || mlp <= 0) return 0;
     const int64_t R = Z * T, I = Z * G, E = dim, big = R > I ? R : I, wide = mlp > E ? mlp : E;
-    return (size_t)(6 * align256(R * E * 4) + align256(R * mlp * 4) + 6 * align256(I * E * 4) + align256(big * kpad((int)wide) * 4) + align256(big * 4));
+    return (size_t)(6 * align256(R * E * 4) + align256(R * mlp * 4) + 6 * align256(I * E * 4) + align256(big * kpad((int)wide) * 4) + align256(big * 4) +
+                    align256(I * kpad((int)E) * 4) + align256(I * 4));      // + the packed keys + key_pe rows (shared by two projections per layer) and their scales
 }
 
 // tokens [Z*T, dim] (output tokens + sparse prompt embeddings = the point embedding `query_pe`), keys [Z*G, dim] (src = image embedding + dense
@@ -657,7 +658,27 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
     float* k = cv.take<float>(I * E); float* ik = cv.take<float>(I * E); float* iv = cv.take<float>(I * E); float* iq = cv.take<float>(I * E);
     float* ia = cv.take<float>(I * E); float* iy = cv.take<float>(I * E);
     float* pack_buf = cv.take<float>((R > I ? R : I) * kpad(mlp > E ? mlp : E)); float* scale_buf = cv.take<float>(R > I ? R : I);
+    float* kin_p = cv.take<float>(I * kpad(E)); float* kin_s = cv.take<float>(I);
     int32_t rc = PSAM_OK;
+    // Round 4, fewer and wider launches with the same arithmetic (the same bits as the per-operator sequence the Python host issues):
+    //  * token side (R <= 64 rows): the q / k / v projections of an attention are ONE psam_linear_skinny_multi launch, `queries + query_pe` is added
+    //    while the rows are loaded -- no psam_add_bcast, no separate launches;
+    //  * patch side: `keys + key_pe` is added inside the pass that scales and packs the rows (psam_scale_pack_rows_g8_add), and the packed rows feed
+    //    BOTH projections that read them in a layer (k of tokens -> patches, q of patches -> tokens): one pack instead of an add and two packs.
+    const bool tok_fast = R <= 64 && (E & 15) == 0;
+    auto skinny = [&](int n, const TwLin* l, const float* const* xs, const float* const* xadds, float* const* ys) -> int32_t {
+        psam_skinny_jobs_t jobs;
+        std::memset(&jobs, 0, sizeof(jobs));
+        jobs.n = n;
+        for (int i = 0; i < n; ++i) { jobs.job[i].x = xs[i]; jobs.job[i].xadd = xadds[i]; jobs.job[i].W = l[i].w; jobs.job[i].bias = l[i].b; jobs.job[i].y = ys[i]; jobs.job[i].ldy = l[i].N; jobs.job[i].N = l[i].N; jobs.job[i].act = 0; }
+        return psam_linear_skinny_multi(&jobs, E, E, l[0].K, (int32_t)R, l[0].K, stream);
+    };
+    auto gemm_packed = [&](const TwLin& l, const float* xp, const float* sx, int64_t M, float* y) -> int32_t {
+        const int kp = kpad(l.K);
+        return psam_gemm_f16x3p_ex(xp, kp, sx, l.packed, kp, l.scales, y, l.N, l.b, nullptr, 0, nullptr, 0, 0, (int32_t)M, l.N, kp, 1.f, 0, nullptr, stream);
+    };
+    // k_in = keys + pos, packed: shared by every projection of the layer that reads it (needs I >= 256 and packed weights)
+    auto pack_kin = [&]() -> int32_t { return psam_scale_pack_rows_g8_add(keys, E, pos, E, G, rep, (int32_t)I, E, kin_p, kpad(E), kin_s, stream); };
 #define TWCK(call) do { rc = (call); if (rc) return rc; } while (0)
     // Attention.forward up to out_proj: projections + softmax(q k^T / sqrt(hd)) v
     auto attn = [&](const TwLin& lq, const TwLin& lk, const TwLin& lv, const float* q_in, int64_t Mq, const float* k_in, const float* v_in, int64_t Mk, float* oq, float* ok,
@@ -679,21 +700,48 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
         const TwLin m1 = L(Lw.m1_w, Lw.m1_b, mlp, E), m2 = L(Lw.m2_w, Lw.m2_b, E, mlp);
         const TwLin jq = L(Lw.i2t.q_w, Lw.i2t.q_b, IX, E), jk = L(Lw.i2t.k_w, Lw.i2t.k_b, IX, E), jv = L(Lw.i2t.v_w, Lw.i2t.v_b, IX, E), jo = L(Lw.i2t.o_w, Lw.i2t.o_b, E, IX);
         // self-attention of the tokens (the first layer without positional encoding and without residual: skip_first_layer_pe)
-        if (i == 0) {
+        const bool key_fast = I >= 256 && ck.packed && jq.packed && cvl.packed;
+        auto small_attn = [&](const TwLin& lq, const float* oq, const float* ok, const float* ov, float* out, int Lq, int Lk) -> int32_t {
+            const int inner = lq.N, hd = inner / H;
+            return psam_attention_small(oq, inner, (int64_t)Lq * inner, ok, inner, (int64_t)Lk * inner, ov, inner, (int64_t)Lk * inner, out, inner, (int64_t)Lq * inner, Z, H, Lq, Lk,
+                                        hd, 1.0f / std::sqrt((float)hd), stream);
+        };
+        if (tok_fast) {
+            const TwLin ls[3] = {sq, sk, sv};
+            const float* xs[3] = {cur, cur, cur};
+            const float* xa[3] = {i == 0 ? nullptr : tokens, i == 0 ? nullptr : tokens, nullptr};      // first layer: no positional encoding (skip_first_layer_pe)
+            float* ys[3] = {pq, pk, pv};
+            TWCK(skinny(3, ls, xs, xa, ys));
+            TWCK(small_attn(sq, pq, pk, pv, ta, T, T));
+        } else if (i == 0) {
             TWCK(attn(sq, sk, sv, cur, R, cur, cur, R, pq, pk, pv, ta, T, T));
-            TWCK(tw_lin(so, ta, R, ty, 0, pack_buf, scale_buf, stream));
-            TWCK(psam_layernorm(ty, E, nullptr, 0, Lw.n1_w, Lw.n1_b, queries, E, R, E, W.eps, 0, stream));
         } else {
             TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
             TWCK(attn(sq, sk, sv, q, R, q, queries, R, pq, pk, pv, ta, T, T));
-            TWCK(tw_lin(so, ta, R, ty, 0, pack_buf, scale_buf, stream));
-            TWCK(psam_layernorm(ty, E, queries, E, Lw.n1_w, Lw.n1_b, queries, E, R, E, W.eps, 0, stream));
         }
+        TWCK(tw_lin(so, ta, R, ty, 0, pack_buf, scale_buf, stream));
+        TWCK(psam_layernorm(ty, E, i == 0 ? nullptr : queries, i == 0 ? 0 : E, Lw.n1_w, Lw.n1_b, queries, E, R, E, W.eps, 0, stream));
         cur = queries;
         // tokens attend to the patch tokens
-        TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
-        TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
-        TWCK(attn(cq, ck, cvl, q, R, k, keys, I, pq, ik, iv, ta, T, G));
+        if (tok_fast) {
+            const TwLin ls[1] = {cq};
+            const float* xs[1] = {queries};
+            const float* xa[1] = {tokens};
+            float* ys[1] = {pq};
+            TWCK(skinny(1, ls, xs, xa, ys));
+        } else {
+            TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+            TWCK(tw_lin(cq, q, R, pq, 0, pack_buf, scale_buf, stream));
+        }
+        if (key_fast) {
+            TWCK(pack_kin());
+            TWCK(gemm_packed(ck, kin_p, kin_s, I, ik));
+        } else {
+            TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
+            TWCK(tw_lin(ck, k, I, ik, 0, pack_buf, scale_buf, stream));
+        }
+        TWCK(tw_lin(cvl, keys, I, iv, 0, pack_buf, scale_buf, stream));
+        TWCK(small_attn(cq, pq, ik, iv, ta, T, G));
         TWCK(tw_lin(co, ta, R, ty, 0, pack_buf, scale_buf, stream));
         TWCK(psam_layernorm(ty, E, queries, E, Lw.n2_w, Lw.n2_b, queries, E, R, E, W.eps, 0, stream));
         // token MLP
@@ -701,16 +749,48 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
         TWCK(tw_lin(m2, tm, R, ty, 0, pack_buf, scale_buf, stream));
         TWCK(psam_layernorm(ty, E, queries, E, Lw.n3_w, Lw.n3_b, queries, E, R, E, W.eps, 0, stream));
         // patch tokens attend to the tokens
-        TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
-        TWCK(attn(jq, jk, jv, k, I, q, queries, R, iq, pk, pv, ia, G, T));
+        if (key_fast) TWCK(gemm_packed(jq, kin_p, kin_s, I, iq));      // keys + key_pe: packed once above, unchanged since
+        else TWCK(tw_lin(jq, k, I, iq, 0, pack_buf, scale_buf, stream));
+        if (tok_fast) {
+            const TwLin ls[2] = {jk, jv};
+            const float* xs[2] = {queries, queries};
+            const float* xa[2] = {tokens, nullptr};
+            float* ys[2] = {pk, pv};
+            TWCK(skinny(2, ls, xs, xa, ys));
+        } else {
+            TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+            TWCK(tw_lin(jk, q, R, pk, 0, pack_buf, scale_buf, stream));
+            TWCK(tw_lin(jv, queries, R, pv, 0, pack_buf, scale_buf, stream));
+        }
+        TWCK(small_attn(jq, iq, pk, pv, ia, G, T));
         TWCK(tw_lin(jo, ia, I, iy, 0, pack_buf, scale_buf, stream));
         TWCK(psam_layernorm(iy, E, keys, E, Lw.n4_w, Lw.n4_b, keys, E, I, E, W.eps, 0, stream));
     }
     const TwLin fq = L(W.final_attn.q_w, W.final_attn.q_b, IX, E), fk = L(W.final_attn.k_w, W.final_attn.k_b, IX, E), fv = L(W.final_attn.v_w, W.final_attn.v_b, IX, E),
                 fo = L(W.final_attn.o_w, W.final_attn.o_b, E, IX);
-    TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
-    TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
-    TWCK(attn(fq, fk, fv, q, R, k, keys, I, pq, ik, iv, ta, T, G));
+    {
+        const int inner = fq.N, hd = inner / H;
+        if (tok_fast) {
+            const TwLin ls[1] = {fq};
+            const float* xs[1] = {queries};
+            const float* xa[1] = {tokens};
+            float* ys[1] = {pq};
+            TWCK(skinny(1, ls, xs, xa, ys));
+        } else {
+            TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
+            TWCK(tw_lin(fq, q, R, pq, 0, pack_buf, scale_buf, stream));
+        }
+        if (I >= 256 && fk.packed) {
+            TWCK(pack_kin());
+            TWCK(gemm_packed(fk, kin_p, kin_s, I, ik));
+        } else {
+            TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
+            TWCK(tw_lin(fk, k, I, ik, 0, pack_buf, scale_buf, stream));
+        }
+        TWCK(tw_lin(fv, keys, I, iv, 0, pack_buf, scale_buf, stream));
+        TWCK(psam_attention_small(pq, inner, (int64_t)T * inner, ik, inner, (int64_t)G * inner, iv, inner, (int64_t)G * inner, ta, inner, (int64_t)T * inner, Z, H, T, G, hd,
+                                  1.0f / std::sqrt((float)hd), stream));
+    }
     TWCK(tw_lin(fo, ta, R, ty, 0, pack_buf, scale_buf, stream));
     TWCK(psam_layernorm(ty, E, queries, E, W.nf_w, W.nf_b, queries, E, R, E, W.eps, 0, stream));
 #undef TWCK

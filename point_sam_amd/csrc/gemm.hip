@@ -291,6 +291,65 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
     }
 }
 
+// Up to three skinny Linears that share their input rows in ONE launch (grid.y = job): the q / k / v projections of a decoder attention
+// (transformer.py:214-236), each job with its own weight, bias, output and -- optionally -- a second input added to x on load (q = k = queries +
+// query_pe, v = queries: transformer.py:153-170), so that neither the positional add nor three separate launches exist.  Same arithmetic per
+// output element as linear_skinny_kernel on the pre-added input (x + xadd is one fp32 add, as psam_add_bcast makes it): the same bits.
+__global__ __launch_bounds__(256) void linear_skinny_multi_kernel(const psam_skinny_jobs_t jobs, int64_t ldx, int64_t ldxa, int64_t ldw, int M, int K) {
+    const psam_skinny_job_t jb = jobs.job[blockIdx.y];
+    const int N = jb.N;
+    if ((int)blockIdx.x * 16 >= N) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int row = wave * 16 + r, col = blockIdx.x * 16 + r;
+    const float* xp = jb.x + (int64_t)(row < M ? row : 0) * ldx + 4 * g;
+    const float* xa = jb.xadd ? jb.xadd + (int64_t)(row < M ? row : 0) * ldxa + 4 * g : nullptr;
+    const float* wp = jb.W + (int64_t)(col < N ? col : 0) * ldw + 4 * g;
+    const bool rok = row < M, cok = col < N;
+    sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    sk_f32x4 xr[SK_CH], wr[SK_CH];
+    for (int kc = 0; kc < K; kc += 16 * SK_CH) {
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s) {
+            const int k = kc + 16 * s;
+            const bool in = k < K;
+            xr[s] = (in && rok) ? *reinterpret_cast<const sk_f32x4*>(xp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (xa && in && rok) xr[s] += *reinterpret_cast<const sk_f32x4*>(xa + k);
+            wr[s] = (in && cok) ? *reinterpret_cast<const sk_f32x4*>(wp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[s][e], wr[s][e], acc, 0, 0, 0);
+    }
+    if (cok) {
+        const float bv = jb.bias ? jb.bias[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int orow = wave * 16 + 4 * g + v;
+            if (orow < M) {
+                float val = acc[v] + bv;
+                if (jb.act == 1) val = gelu_erf(val);
+                else if (jb.act == 2) val = fmaxf(val, 0.f);
+                jb.y[(int64_t)orow * jb.ldy + col] = val;
+            }
+        }
+    }
+}
+
+PSAM_API int32_t psam_linear_skinny_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int64_t ldxadd, int64_t ldw, int32_t M, int32_t K, hipStream_t stream) {
+    PSAM_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= 3, PSAM_EINVAL, "psam_linear_skinny_multi: one to three jobs");
+    PSAM_REQUIRE(M > 0 && M <= 64 && K > 0 && (K & 15) == 0 && ((ldx | ldw | ldxadd) & 3) == 0, PSAM_EINVAL, "psam_linear_skinny_multi: need 0 < M <= 64, K % 16 == 0, rows 16-byte aligned");
+    int nmax = 0;
+    for (int i = 0; i < jobs->n; ++i) {
+        const psam_skinny_job_t& j = jobs->job[i];
+        PSAM_REQUIRE(j.x && j.W && j.y && j.N > 0 && j.act >= 0 && j.act <= 2, PSAM_EINVAL, "psam_linear_skinny_multi: bad job");
+        PSAM_REQUIRE((((uintptr_t)j.x | (uintptr_t)j.W | (uintptr_t)j.xadd) & 15) == 0, PSAM_EALIGN, "psam_linear_skinny_multi: rows must be 16-byte aligned");
+        nmax = j.N > nmax ? j.N : nmax;
+    }
+    hipLaunchKernelGGL(linear_skinny_multi_kernel, dim3((unsigned)psam_cdiv(nmax, 16), (unsigned)jobs->n), dim3(256), 0, stream, *jobs, ldx, ldxadd, ldw, M, K);
+    return psam_launch_status("psam_linear_skinny_multi: launch failed");
+}
+
 // y [M, N] = act(x [M, K] W [N, K]^T + bias) + residual for M <= 64, K % 16 == 0, 16-byte aligned rows (ld % 4 == 0).
 PSAM_API int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                                     float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, hipStream_t stream) {

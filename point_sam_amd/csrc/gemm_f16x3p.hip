@@ -315,12 +315,16 @@ PSAM_API int32_t psam_pack_rows_f16x2_g8(const float* X, int64_t ldx, const floa
 // row stays in registers between the maximum and the split.  K <= NV4 * 256, K % 4 == 0, rows 16-byte aligned.
 template <int NV4>
 __global__ __launch_bounds__(256) void scale_pack_rows_g8_kernel(const float* __restrict__ X, int64_t ldx, int rows, int K, unsigned* __restrict__ P,
-                                                                 int64_t ldp, float* __restrict__ scale) {
+                                                                 int64_t ldp, float* __restrict__ scale, const float* __restrict__ add = nullptr,
+                                                                 int64_t ldadd = 0, int rows_per_set = 1, int rep = 1) {
     typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int row = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6);
     if (row >= rows) return;
     const sp_f32x4* xr = reinterpret_cast<const sp_f32x4*>(X + (int64_t)row * ldx);
+    // optional broadcast addend (psam_scale_pack_rows_g8_add): set z = row / rows_per_set reads the rows of set z / rep; the sum is add + x, one
+    // fp32 addition per element, as psam_add_bcast writes it
+    const sp_f32x4* ar = add ? reinterpret_cast<const sp_f32x4*>(add + ((int64_t)(row / (rep * rows_per_set)) * rows_per_set + row % rows_per_set) * ldadd) : nullptr;
     const int c4n = K >> 2;
     sp_f32x4 v[NV4];
     float amax = 0.f;
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(256) void scale_pack_rows_g8_kernel(const float* __
     for (int i = 0; i < NV4; ++i) {
         const int c = i * 64 + lane;
         v[i] = xr[c < c4n ? c : c4n - 1];                       // unconditional (clamped) loads
+        if (ar) v[i] = ar[c < c4n ? c : c4n - 1] + v[i];
         if (c >= c4n) v[i] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
     }
@@ -357,7 +362,7 @@ PSAM_API int32_t psam_scale_pack_rows_g8(const float* X, int64_t ldx, int32_t ro
     PSAM_REQUIRE((ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 && (ldp & 7) == 0 && ((uintptr_t)P & 31) == 0, PSAM_EALIGN,
                  "psam_scale_pack_rows_g8: rows of X 16-byte, of P 32-byte aligned");
     const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
-#define SP_LAUNCH(R) hipLaunchKernelGGL(scale_pack_rows_g8_kernel<R>, grid, block, 0, stream, X, ldx, rows, K, (unsigned*)P, ldp, scale)
+#define SP_LAUNCH(R) hipLaunchKernelGGL(scale_pack_rows_g8_kernel<R>, grid, block, 0, stream, X, ldx, rows, K, (unsigned*)P, ldp, scale, (const float*)nullptr, (int64_t)0, 1, 1)
     if (Kp <= 256) SP_LAUNCH(1);
     else if (Kp <= 512) SP_LAUNCH(2);
     else if (Kp <= 1024) SP_LAUNCH(4);
@@ -366,6 +371,26 @@ PSAM_API int32_t psam_scale_pack_rows_g8(const float* X, int64_t ldx, int32_t ro
     else SP_LAUNCH(24);
 #undef SP_LAUNCH
     return psam_launch_status("psam_scale_pack_rows_g8: launch failed");
+}
+
+PSAM_API int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const float* add, int64_t ldadd, int32_t rows_per_set, int32_t rep, int32_t rows, int32_t K,
+                                             void* P, int64_t ldp, float* scale, hipStream_t stream) {
+    PSAM_REQUIRE(X && add && P && scale, PSAM_EINVAL, "psam_scale_pack_rows_g8_add: null pointer");
+    const int Kp = (K + 31) / 32 * 32;
+    PSAM_REQUIRE(rows > 0 && K > 0 && K <= 6144 && (K & 3) == 0 && ldx >= K && ldadd >= K && ldp >= Kp && rows_per_set > 0 && rep > 0, PSAM_EINVAL,
+                 "psam_scale_pack_rows_g8_add: bad shape (K % 4 == 0, K <= 6144, ldp >= K rounded up to 32)");
+    PSAM_REQUIRE(((ldx | ldadd) & 3) == 0 && (((uintptr_t)X | (uintptr_t)add) & 15) == 0 && (ldp & 7) == 0 && ((uintptr_t)P & 31) == 0, PSAM_EALIGN,
+                 "psam_scale_pack_rows_g8_add: rows of X / add 16-byte, of P 32-byte aligned");
+    const dim3 grid((unsigned)psam_cdiv(rows, 4)), block(256);
+#define SPA_LAUNCH(R) hipLaunchKernelGGL(scale_pack_rows_g8_kernel<R>, grid, block, 0, stream, X, ldx, rows, K, (unsigned*)P, ldp, scale, add, ldadd, rows_per_set, rep)
+    if (Kp <= 256) SPA_LAUNCH(1);
+    else if (Kp <= 512) SPA_LAUNCH(2);
+    else if (Kp <= 1024) SPA_LAUNCH(4);
+    else if (Kp <= 2048) SPA_LAUNCH(8);
+    else if (Kp <= 4096) SPA_LAUNCH(16);
+    else SPA_LAUNCH(24);
+#undef SPA_LAUNCH
+    return psam_launch_status("psam_scale_pack_rows_g8_add: launch failed");
 }
 
 // ---------------------------------------------------------------------------------------------- host
