@@ -218,7 +218,7 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -m point_sam_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback on the product path."
             )
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(os.environ.get("PSAM_LIB_PATH", LIB_PATH))      # PSAM_LIB_PATH: an alternative build of the same library (A/B measurements)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
