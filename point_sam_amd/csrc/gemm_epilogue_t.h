@@ -17,7 +17,8 @@
 // Options covered (what the encoder / decoder hot path launches): bias, alpha, GELU / ReLU, SwiGLU gate (act == 3, column tiles (2q, 2q+1)),
 // residual, folded LayerNorm (ln_c / ln_mean / ln_rstd), packed output (pack_out with out_k1 / out_k2 or out_bound), row statistics (stats).
 // hyper products of 64-column wave tiles (TN == 2; N / 64 partial planes) with or without storing the activation (no_store).
-// Not covered (the host keeps gemm_epilogue.h for those launches): rowbias, group maximum, full-row LayerNorm / full-row hyper products.
+// rowbias (a bias row per group of rows).
+// Not covered (the host keeps gemm_epilogue.h for those launches): group maximum, full-row LayerNorm / full-row hyper products.
 // Store pattern: a wave instruction writes 32 rows x 2 x 16 B (32 B contiguous per row for fp32 outputs, 2 x 16 B 32 B apart for packed
 // ones); the four instructions of a tile complete each row's 128-byte line in L2.
 #pragma once
@@ -68,6 +69,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
     const float alpha = swiglu ? 1.f : p.alpha;
     const int o_act = F < 0 ? p.act : ((F & EP_GELU) ? 1 : ((F & EP_RELU) ? 2 : 0));
     const bool o_res = !swiglu && (F < 0 ? R != nullptr : bool(F & EP_RES));
+    const bool o_rowbias = !swiglu && (F < 0 ? p.rowbias != nullptr : bool(F & EP_ROWBIAS));      // bias row per group of `rowgroup` rows: the lane's own row picks it
     if (!interior) {
         // ---- edge tiles: every element bounds-checked, plain options only (the host guarantees interior tiles for the fused extras)
 #pragma unroll
@@ -90,6 +92,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
                             oc = (col_base >> 1) + (j >> 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                         }
                     } else {
+                        if (o_rowbias) v += p.rowbias[(int64_t)(row / p.rowgroup) * p.ldrb + pc];
                         v = ep_act(v, o_act);
                         if (o_res) v += R[(int64_t)row * p.ldr + pc];
                     }
@@ -157,6 +160,12 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
 #pragma unroll
                 for (int g = 0; g < 4; ++g) res[g] = ep_load4(R + (int64_t)row * p.ldr + ocol + 8 * g);
             }
+            ep_f32x4 rbv[4];
+            if (o_rowbias) {
+                const float* rbp = p.rowbias + (int64_t)(row / p.rowgroup) * p.ldrb + pcol;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rbv[g] = ep_load4(rbp + 8 * g);
+            }
             ep_f32x4 v[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -171,6 +180,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
                             a = silu(a) * x;
                         }
                     } else {
+                        if (o_rowbias) a += rbv[g][e];
                         a = ep_act(a, o_act);
                     }
                     v[g][e] = a;
@@ -263,7 +273,7 @@ __device__ __forceinline__ void gemm_store_tile_t(const ArgsT& p, ep_f32x16 (&ac
                                                   const float* __restrict__ R) {
     const bool interior = gemm_epilogue_interior<TM, TN>(p, row_base, col_base, C, R);      // wave-uniform
     const bool swiglu = (TN % 2 == 0) && p.act == 3;
-    const int opt = (swiglu ? EP_SWIGLU : 0) | ((R && !swiglu) ? EP_RES : 0) | (!swiglu && p.act == 1 ? EP_GELU : 0) | (!swiglu && p.act == 2 ? EP_RELU : 0) |
+    const int opt = (swiglu ? EP_SWIGLU : 0) | ((R && !swiglu) ? EP_RES : 0) | ((p.rowbias && !swiglu) ? EP_ROWBIAS : 0) | (!swiglu && p.act == 1 ? EP_GELU : 0) | (!swiglu && p.act == 2 ? EP_RELU : 0) |
                     ((swiglu && p.stats) ? EP_STATS : 0) | (p.pack_out ? EP_PACK : 0) | (p.ln_c ? EP_LNC : 0) | ((p.pack_out && !p.ln_c && p.out_bound) ? EP_BND : 0) |
                     ((p.hyper && !swiglu) ? EP_HYPER : 0) | (p.no_store ? EP_NOSTORE : 0);
     using std::integral_constant;
@@ -274,6 +284,7 @@ __device__ __forceinline__ void gemm_store_tile_t(const ArgsT& p, ep_f32x16 (&ac
         EPT_CASE(EP_PACK);                                      // qkv, packed for the attention kernel
         EPT_CASE(EP_LNC | EP_RES);                              // fc2 with the folded LayerNorm
         EPT_CASE(EP_GELU);
+        EPT_CASE(EP_ROWBIAS);                                   // PatchEncoder conv2.0 (per-row half; the pooled half arrives as the group's bias row)
         if constexpr (TN == 2) { EPT_CASE(EP_GELU | EP_HYPER | EP_NOSTORE); }      // last Linear of the upscaling MLP + the hyper products
         if constexpr (TN % 2 == 0) {
             EPT_CASE(EP_SWIGLU | EP_STATS | EP_PACK | EP_BND);  // fc1 of the fused EVA02 MLP

@@ -429,7 +429,8 @@ bool f16x3p_use_register_epilogue(const F16PArgs& p) {
         mode = env;
     }
     if (mode <= 0) return false;
-    if (p.rowbias || p.gmax_out || p.row_ln_g || (p.no_store && !p.hyper)) return false;      // options only gemm_epilogue.h implements
+    if (p.gmax_out || p.row_ln_g || (p.no_store && !p.hyper)) return false;      // options only gemm_epilogue.h implements
+    if (p.rowbias && ((p.ldrb & 3) != 0 || (((uintptr_t)p.rowbias) & 15) != 0 || p.act == 3)) return false;
     if (p.hyper && (p.hyper_rows % 32 != 0 || (((uintptr_t)p.hyper) & 15) != 0 || (p.N & 3) != 0)) return false;
     if ((((uintptr_t)p.scaleW | (uintptr_t)p.bias | (uintptr_t)p.ln_c) & 15) != 0) return false;      // float4 loads of the column constants
     return true;

@@ -585,6 +585,7 @@ def test_gemm_f16x3_register_epilogue_bitwise(ops):
     wq, bq = ops.F16Weight(cu(torch.randn(3 * D, D, generator=g) / 32)), cu(torch.randn(3 * D, generator=g) * 0.1)
     wp = ops.F16Weight(cu(torch.randn(D, D, generator=g) / 32))
     xr, wr, br, rr = cu(torch.randn(777, 260, generator=g)), ops.F16Weight(cu(torch.randn(392, 260, generator=g) / 16)), cu(torch.randn(392, generator=g)), cu(torch.randn(777, 392, generator=g))
+    rbias = cu(torch.randn(M // 64, D, generator=g))
     # upscaling MLP tail: Linear + GELU + hyper products over [Z * N, 256]
     Z, Npts, C, E = 2, 4096, 3, 256
     u1 = torch.randn(Z * Npts, E, generator=g)
@@ -612,6 +613,8 @@ def test_gemm_f16x3_register_epilogue_bitwise(ops):
                 o["gelu"] = ops.linear(hp, wp, bq[:D].contiguous(), act=ops.ACT_GELU, x_scale=sh, x_packed=True)
                 o["ragged_gelu_res"] = ops.linear(xr, wr, br, act=ops.ACT_GELU, residual=rr)
                 o["ragged_plain"] = ops.linear(xr, wr, None)
+                o["rowbias"] = ops.linear(hp, wp, None, rowbias=rbias, rowgroup=64, x_scale=sh, x_packed=True)      # PatchEncoder conv2.0: a bias row per group of 64 rows
+                o["ragged_rowbias"] = ops.linear(xr, wr, br, rowbias=rr[:26].contiguous(), rowgroup=30)
                 masks = torch.empty(Z, C, Npts, device="cuda")
                 ops.linear(u1p, fw3, cu(b3), act=ops.ACT_GELU, x_scale=s1, x_packed=True, hyper=(cu(hyper), masks, Npts), no_store=True)
                 o["masks"] = masks
