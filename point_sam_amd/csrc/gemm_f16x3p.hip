@@ -430,7 +430,10 @@ bool f16x3p_use_register_epilogue(const F16PArgs& p) {
     }
     if (mode <= 0) return false;
     if (p.gmax_out || p.row_ln_g || (p.no_store && !p.hyper)) return false;      // options only gemm_epilogue.h implements
-    if (p.rowbias && ((p.ldrb & 3) != 0 || (((uintptr_t)p.rowbias) & 15) != 0 || p.act == 3)) return false;
+    // per-group row bias: implemented, bitwise equal, but only when forced -- its one user (PatchEncoder conv2.0, K = 128, 512 MB of fp32 output)
+    // is bound by the stores, and one-row-per-lane 16-byte stores lose against the LDS epilogue's full rows (247 vs 235 us,
+    // profiles/r04_gemm_experiments.txt)
+    if (p.rowbias && (g_f16x3p_tr <= 0 || (p.ldrb & 3) != 0 || (((uintptr_t)p.rowbias) & 15) != 0 || p.act == 3)) return false;
     if (p.hyper && (p.hyper_rows % 32 != 0 || (((uintptr_t)p.hyper) & 15) != 0 || (p.N & 3) != 0)) return false;
     if ((((uintptr_t)p.scaleW | (uintptr_t)p.bias | (uintptr_t)p.ln_c) & 15) != 0) return false;      // float4 loads of the column constants
     return true;
