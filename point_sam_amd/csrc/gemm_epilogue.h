@@ -24,11 +24,11 @@ constexpr int gemm_epilogue_lds_floats_per_wave() { return 32 * (TN * 32 + 4); }
 __device__ __forceinline__ float inv_pow2(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
 __device__ __forceinline__ ep_f32x4 ep_load4(const float* q) { return *reinterpret_cast<const ep_f32x4*>(q); }
 __device__ __forceinline__ float ep_act(float v, int act) { return act == 1 ? gelu_erf(v) : (act == 2 ? fmaxf(v, 0.f) : v); }
-// Every DS operation in flight (the fetch of the NEXT pass: LDS reads and ds_bpermute lane shuffles) completes here, before the current pass
-// issues DS operations of another kind (stats / packing shuffles, the parked ds_write).  hipcc counts lgkmcnt on the assumption that DS
-// operations retire in issue order; with a ds_bpermute and a ds_read / ds_write in flight together that did not hold under load: a
-// counted `s_waitcnt lgkmcnt(1)` let a pass start on a shuffle result that had not landed for the last 16 lanes -- wrong fc2 outputs
-// (1e-2) whenever another stream's kernels shared the CU, never when the kernel ran alone (scripts/exp/r03_race.py, profiles/r03_race.txt).
+// Every DS operation in flight completes here.  Added in round 3 as the presumed cure of 1e-2 wrong fc2 outputs in multi-stream runs (a DS
+// ordering hazard was suspected); round 4 bisected the failure at ISA level to something else: the pass loop's packed multiply
+// `v_pk_mul_f32 .. op_sel:[0,1]`, which returns wrong lanes 48-63 while another stream's GEMM workgroups are launched on the CU -- the code change
+// merely made hipcc pick another instruction form (profiles/r04_hazard.txt; point_sam_amd/isa_lint.py now rejects a library that contains one).
+// The drains stay: they cost nothing measurable and keep the loop's DS traffic simple.
 __device__ __forceinline__ void ep_lgkm_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Sum over aligned groups of W = 4, 8 or 16 consecutive lanes, every lane ending with the group's sum, in the order of the xor butterfly
 // (1, 2, 4, 8) it replaces -- on the DPP path (quad_perm, quad_perm, row_half_mirror, row_mirror: each partner already holds its sub-group's
@@ -333,10 +333,9 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
 #endif
 #pragma unroll 1
                 for (int q = 0; q < np_run; ++q) {
-                    // (fetching pass q+1 here, under the arithmetic of pass q, measured 1e-2 WRONG results in the folded-LayerNorm + residual
-                    // instance whenever another stream's kernels shared the CU -- never alone, never with this in-iteration fetch; the stale
-                    // values sat in lanes 48-63 of one shuffle result.  Root cause not established (scripts/exp/r03_race.py);
-                    // tests/test_gpu_kernels.py::test_fused_mlp_bitwise_stable_beside_other_streams holds the line.)
+                    // (the round-3 version fetched pass q+1 here, one pass ahead; that form of the loop compiled to `v_pk_mul_f32 .. op_sel:[0,1]` for
+                    // lnc * mean, the instruction behind the 1e-2 multi-stream errors -- see ep_lgkm_drain() and profiles/r04_hazard.txt;
+                    // tests/test_gpu_kernels.py::test_fused_mlp_bitwise_stable_beside_other_streams and the ISA lint hold the line.)
                     const PassIn cur = fetch(q);
                     const int rl = q * rpp + rl0;
                     const int row = row_base + i * 32 + rl;

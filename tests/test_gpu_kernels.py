@@ -493,6 +493,46 @@ def test_fused_mlp_two_gemms(ops, M, D, H):
     assert e1 < 3e-6 and e1 < 4 * e0 + 5e-7, (e0, e1)
 
 
+def test_interp3_bitwise_stable_beside_gemm_stream(ops):
+    """interpolate_features at the benchmark's size (LayerNorm + GELU + packed output, the decoder's launch; and the plain form) must give the SAME
+    BITS alone and while another stream launches GEMM workgroups.  Until round 4 the kernel multiplied by its second weight with
+    `v_pk_mul_f32 .. op_sel:[1,0]`, one of the packed forms that return wrong lanes 48-63 beside such workgroups in the probe
+    (point_sam_amd/isa_lint.py, scripts/exp/r04_pk_opsel.hip).  The pre-fix build also passes this test (the kernel's short-lived waves were never
+    caught, profiles/r04_hazard.txt) -- the ISA lint is what keeps the form out; this holds the line on the behaviour."""
+    g = torch.Generator().manual_seed(0)
+    Z, G, C, N = 8, 512, 256, 32768
+    src = cu(torch.randn(Z, G, C, generator=g))
+    idx3 = cu(torch.randint(0, G, (Z, N, 3), generator=g))
+    w3 = torch.rand(Z, N, 3, generator=g) + 0.05
+    w3 = cu(w3 / w3.sum(-1, keepdim=True))
+    gam, bet = cu(torch.randn(C, generator=g)), cu(torch.randn(C, generator=g) * 0.1)
+    M, D = 4096, 1024
+    wq, bq = ops.F16Weight(cu(torch.randn(3 * D, D, generator=g) / 32)), cu(torch.zeros(3 * D))
+    with ops.gemm_mode("f16x3"):
+        hp, sh = ops.scale_pack_rows_g8(cu(torch.randn(M, D, generator=g)))
+        qkv = torch.empty(M, 3 * D, device="cuda")
+
+        def run():
+            a = torch.empty(Z, N, C, device="cuda"); sa = torch.empty(Z * N, device="cuda"); b = torch.empty(Z, N, C, device="cuda")
+            ops.interp3(src, idx3, w3, a, 1, scale_out=sa, ln=(gam, bet, 1e-6), act=ops.ACT_GELU)
+            ops.interp3(src, idx3, w3, b, 1)
+            return a, sa, b
+
+        ref = run()
+        torch.cuda.synchronize()
+        s2 = torch.cuda.Stream()
+        for it in range(6):
+            s2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s2):
+                for _ in range(40):
+                    ops.linear(hp, wq, bq, x_scale=sh, x_packed=True, out=qkv)
+            out = run()
+            torch.cuda.synchronize()
+            for name, x, y in zip(("packed", "scales", "plain"), out, ref):
+                nbad = int((x.view(torch.int32) != y.view(torch.int32)).sum())
+                assert nbad == 0, f"run {it}: {nbad} words of the {name} output changed beside the GEMM stream"
+
+
 def test_fused_mlp_bitwise_stable_beside_other_streams(ops):
     """The fused EVA02 MLP GEMMs (fc1: SwiGLU + row statistics + packed output; fc2: folded LayerNorm + residual) at the benchmark's
     size must give the SAME BITS whether they run alone or while another stream's kernels (GEMMs, attention, LayerNorm) share the CUs.

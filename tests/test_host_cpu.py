@@ -11,6 +11,21 @@ from point_sam_amd.weights import check_state_dict, expected_shapes, random_stat
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_library_has_no_packed_fp32_instruction_with_nonuniform_op_sel():
+    """The instruction forms behind round 3's multi-stream corruption (point_sam_amd/isa_lint.py, profiles/r04_hazard.txt) must not ship."""
+    from point_sam_amd import isa_lint
+    from point_sam_amd.build import build_library
+    assert isa_lint.hazardous("v_pk_mul_f32 v[52:53], v[74:75], v[42:43] op_sel:[0,1]")
+    assert isa_lint.hazardous("\tv_pk_mul_f32 v[6:7], v[18:19], v[6:7] op_sel:[1,0]     // 000000001234: D3B14006 ...")
+    assert isa_lint.hazardous("v_pk_fma_f32 v[52:53], v[74:75], v[42:43], v[60:61] op_sel:[0,1,0] neg_lo:[0,0,1]")
+    assert isa_lint.hazardous("v_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1] op_sel_hi:[1,0]")
+    for safe in ("v_pk_mul_f32 v[2:3], v[4:5], v[6:7]", "v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0]", "v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,1]",
+                 "v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]", "v_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]",
+                 "v_mul_f32_e32 v52, v74, v43"):
+        assert not isa_lint.hazardous(safe), safe
+    assert isa_lint.lint(build_library()) == []
+
+
 def test_library_exports_every_declared_symbol():
     from point_sam_amd.build import build_library
     build_library()
