@@ -143,6 +143,10 @@ void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring con
  * launch's options allow it, 0 = always the LDS-transposition epilogue (csrc/gemm_epilogue.h), -1 = default (environment PSAM_GEMM_TR, else 1).
  * Both give the same bits; the hook exists for A/B measurements and the bitwise test. */
 void psam_gemm_f16x3p_force_epilogue(int32_t mode);
+/* split-K launches of psam_gemm_f16x3p_ex: 1 = in-kernel fix-up (the last workgroup of a tile adds the partial accumulators in split order and runs the
+ * epilogue; no reduction launch), 0 = partial planes + reduction launch, -1 = the default (fix-up wherever the workspace and the stream's counters allow;
+ * environment PSAM_GEMM_SPLITK_FIXUP=0 switches it off).  Tuning / test hook: both forms give the same bits for power-of-two scales. */
+void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
 /* 1 when psam_gemm_f16x3p_ex accepts psam_gemm_fuse_t.row_ln_* for N output columns (Linear -> LayerNorm -> activation in one GEMM; common.py:493-496,
  * mask_decoder.py:53-59): N == 256 always, N == 512 with the register epilogue (packed output scaled by the a-priori bound out_k2, out_k1 == 0). */
 int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "psam_gemm_f16x3p": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr]),
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
+    "psam_gemm_f16x3p_force_splitk_fixup": (None, [i32]),
     "psam_attention_packed_force_variant": (None, [i32]),
     "psam_gemm_f16x3p_fused_row_ln": (i32, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),

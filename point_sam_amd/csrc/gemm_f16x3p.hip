@@ -24,6 +24,9 @@
 #include <type_traits>
 #include <cstdlib>
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include "gemm_f16x3p_args.h"
 #include "gemm_epilogue.h"
 #include "gemm_epilogue_t.h"
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
     // them through the K loop (gemm_epilogue.h)
     constexpr bool PREFETCH_EPI = TM * TN >= 4 && TN <= 4 && !TR;
     EpPre<TM> epre;
-    float* const Cout = p.C + (int64_t)split * p.plane;
+    float* const Cout = p.sk_part ? p.C : p.C + (int64_t)split * p.plane;
     if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, Cout, p.residual);
     pf16x8 f0a[TM][2], f0w[TN][2], f1a[TM][2], f1w[TN][2];
     // fragment read n in [0, NFR) of step s from `stage`: n -> (operand, tile, plane)
@@ -243,6 +246,55 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
                 for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
         if (sum == 123.456f) p.C[0] = sum;
         return;
+    }
+    if constexpr (!TR) if (p.sk_part) {      // (split-K launches use the LDS-epilogue instances only: the register-epilogue kernels have no registers to spare)
+        // ---- split-K fix-up.  Every split of a tile parks its accumulators (raw MFMA layout: [register quad][wave][lane] float4, 1 KiB per store
+        // instruction) with device-coherent stores (sc1: written through the XCD's L2), counts itself in, and all but the last arrival are done.  The
+        // last one reads the ksplit partials back (its own too: same bits, and the sum order s = 0 .. ksplit-1 then never depends on who came last),
+        // zeroes the counter for the next launch and runs the epilogue -- any epilogue -- on the sum.  No reduction launch, no fp32 planes.
+        constexpr int QUADS = TM * TN * 4, TILE_F4 = QUADS * NW * 64;
+        constexpr int SC1 = 16;
+        const int tile_id = blockIdx.x - split * ntiles;      // the un-permuted id: any bijection serves
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_part + (int64_t)tile_id * p.ksplit * TILE_F4 * 4), 0, 0x7fffffff, 0x00020000);
+        const int lane_off = (wave * 64 + lane) * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    // (element by element into floats first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 every time)
+                    const float a0 = acc[i][j][4 * r4], a1 = acc[i][j][4 * r4 + 1], a2 = acc[i][j][4 * r4 + 2], a3 = acc[i][j][4 * r4 + 3];
+                    const ep_f32x4 vf = {a0, a1, a2, a3};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, vf), rs, (split * QUADS + (i * TN + j) * 4 + r4) * (NW * 64 * 16) + lane_off, 0, SC1);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials are acknowledged by the memory side
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) *flag = (int)__hip_atomic_fetch_add(p.sk_count + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int arrived = *flag;
+        __syncthreads();      // the epilogue below stages through this LDS
+        if (arrived != p.ksplit - 1) return;
+        if (tid == 0) __hip_atomic_store(p.sk_count + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const ep_f32x4 v = __builtin_bit_cast(ep_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * QUADS + (i * TN + j) * 4 + r4) * (NW * 64 * 16) + lane_off, 0, SC1));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
+                    }
+        }
     }
     if constexpr (TR) gemm_store_tile_t<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, Cout, p.residual);
     else gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
@@ -521,6 +573,36 @@ static void f16x3p_cfg_tile(int cfg, int& bm, int& bn, int& per_cu) {
     }
 }
 
+// Arrival counters of the split-K fix-up: SK_MAX_TILES ints per (device, stream), zeroed once and left zero by every launch (the last workgroup of a
+// tile resets its counter).  Launches on one stream are ordered, so they share the block; another stream gets its own.  Allocated on first use --
+// not possible while the stream is being captured into a graph: such a launch falls back to the reduction pass (GraphPipeline runs one eager pass
+// on each of its streams before capturing, which is when the block appears).  PSAM_GEMM_SPLITK_FIXUP=0 switches the fix-up off.
+constexpr int64_t SK_MAX_TILES = 4096;
+static int g_f16x3p_sk_fixup = -1;      // -1: PSAM_GEMM_SPLITK_FIXUP (default on); 0 / 1 forced (psam_gemm_f16x3p_force_splitk_fixup)
+static bool f16x3p_splitk_fixup_enabled() {
+    if (g_f16x3p_sk_fixup >= 0) return g_f16x3p_sk_fixup != 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_GEMM_SPLITK_FIXUP"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
+PSAM_API void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode) { g_f16x3p_sk_fixup = mode; }
+static int* f16x3p_sk_counters(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int*> table;
+    int dev = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipGetDevice(&dev) != hipSuccess || hipStreamIsCapturing(stream, &cs) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find({dev, stream});
+    if (it != table.end()) return it->second;
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    int* c = nullptr;
+    if (hipMalloc(&c, SK_MAX_TILES * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(c, 0, SK_MAX_TILES * sizeof(int), stream) != hipSuccess) { (void)hipFree(c); return nullptr; }
+    table[{dev, stream}] = c;
+    return c;
+}
+
 // Split-K factor for a shape (1: none).  A launch whose tiles cover less than half of the CUs (M = 512 rows of one cloud: 44 tiles of
 // 128x128 for the N = 1408 GEMMs of the giant encoder) leaves the rest of the chip idle for a K loop of up to 192 slabs; `ks` workgroups
 // per tile share the slabs (>= 8 each) and psam_gemm_f16x3p_ex adds the partial planes in a fixed order (deterministic).
@@ -588,7 +670,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
     p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0; p.epi_abl = 0;
-    p.ksplit = 1; p.plane = 0;
+    p.ksplit = 1; p.plane = 0; p.sk_part = nullptr; p.sk_count = nullptr;
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
     if (fuse && fuse->splitk > 1) {
@@ -601,8 +683,15 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         PSAM_REQUIRE((((uintptr_t)fuse->splitk_ws | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0 && (ldc & 3) == 0 && (ldr & 3) == 0,
                      PSAM_EALIGN, "psam_gemm_f16x3p_ex: split-K needs 16-byte aligned rows");
         if (cfg >= 50 || cfg == 30 || cfg == 31) cfg = f16x3p_pick(M, N, K, act, true);
-        p.C = fuse->splitk_ws; p.ldc = N; p.bias = nullptr; p.residual = nullptr; p.act = 0; p.alpha = 1.f;
+        // in-kernel fix-up (the last workgroup of a tile sums the partials and runs the epilogue) where the workspace holds the tiles' raw accumulators
+        // and this stream has its arrival counters; otherwise partial planes + the reduction launch
+        int bm = 0, bn = 0, per_cu = 0;
+        f16x3p_cfg_tile(cfg, bm, bn, per_cu);
+        const int64_t sk_tiles = psam_cdiv(M, bm) * psam_cdiv(N, bn);
+        int* counters = (f16x3p_splitk_fixup_enabled() && sk_tiles <= SK_MAX_TILES && sk_tiles * bm * bn <= fuse->splitk_plane) ? f16x3p_sk_counters(stream) : nullptr;
         p.ksplit = ks; p.plane = fuse->splitk_plane;
+        if (counters) { p.sk_part = fuse->splitk_ws; p.sk_count = counters; }
+        else { p.C = fuse->splitk_ws; p.ldc = N; p.bias = nullptr; p.residual = nullptr; p.act = 0; p.alpha = 1.f; }
         int32_t rc = PSAM_EINVAL;
         switch (cfg) {
             case 0: rc = launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream); break;
@@ -615,7 +704,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
             case 28: rc = launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream); break;
             default: psam_set_error("psam_gemm_f16x3p_ex: split-K has no such tile configuration"); return PSAM_EINVAL;
         }
-        if (rc != PSAM_OK) return rc;
+        if (rc != PSAM_OK || counters) return rc;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)psam_cdiv((int64_t)M * (N / 4), 256)), dim3(256), 0, stream, (const float*)fuse->splitk_ws,
                            fuse->splitk_plane, ks, M, N, bias, residual, ldr, alpha, act, C, ldc);
         return psam_launch_status("psam_gemm_f16x3p_ex: split-K reduction launch failed");

@@ -25,6 +25,8 @@ struct F16PArgs {
     const float* row_ln_g; const float* row_ln_b; float row_ln_eps;
     const float* hyper; float* masks; int hyper_c, hyper_rows; int64_t hyper_pstride;
     int ksplit; int64_t plane;        // split-K (lock-step kernel): workgroup (tile, split) sums its share of the K slabs into C + split * plane
+    float* sk_part; int* sk_count;    // split-K with the in-kernel fix-up: raw accumulator tiles [tile][split] and one arrival counter per tile (zero between launches);
+                                      // the LAST workgroup of a tile adds the ksplit partials in split order and runs the whole epilogue on the sum
     int epi_abl;      // measurement builds (-DPSAM_GEMM_ABLATE): parts of the epilogue switched off (gemm_epilogue.h)
 };
 

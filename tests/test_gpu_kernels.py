@@ -355,6 +355,20 @@ def test_gemm_f16x3_split_k(ops, M, N, K, act):
         got = ops.linear(x, fw, b, act=act, residual=res)
         again = ops.linear(x, fw, b, act=act, residual=res)
     assert torch.equal(got, again)
+    # the two forms of the reduction -- in-kernel fix-up by the last workgroup of a tile (default) and partial planes + a reduction launch -- add the
+    # same partials in the same order: same bits, also in place (C == residual, the encoder's x += proj(..))
+    L0 = _lib.load()
+    try:
+        with ops.gemm_mode("f16x3"):
+            forms = {}
+            for fx in (0, 1):
+                L0.psam_gemm_f16x3p_force_splitk_fixup(fx)
+                inpl = res.clone()
+                ops.linear(x, fw, b, act=act, residual=inpl, out=inpl)
+                forms[fx] = (ops.linear(x, fw, b, act=act, residual=res), inpl)
+    finally:
+        L0.psam_gemm_f16x3p_force_splitk_fixup(-1)
+    assert torch.equal(forms[0][0], forms[1][0]) and torch.equal(forms[0][1], forms[1][1]) and torch.equal(forms[1][0], forms[1][1]) and torch.equal(forms[1][0], got)
     z = x.double() @ W.double().t() + b.double()
     want = (torch.nn.functional.gelu(z) if act == 1 else z.clamp_min(0) if act == 2 else z) + res.double()
     with ops.gemm_mode("f32"):
