@@ -147,6 +147,9 @@ void psam_gemm_f16x3p_force_epilogue(int32_t mode);
  * epilogue; no reduction launch), 0 = partial planes + reduction launch, -1 = the default (fix-up wherever the workspace and the stream's counters allow;
  * environment PSAM_GEMM_SPLITK_FIXUP=0 switches it off).  Tuning / test hook: both forms give the same bits for power-of-two scales. */
 void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
+/* psam_attention_f16x3(_ex) with few workgroups (one cloud, head dim in (64, 128]): up to four workgroups per (query block, head) share the key tiles and
+ * the last arrival combines their partial softmax states in split order.  0 = never split, 1 / -1 = the default (environment PSAM_ATTN_KEYSPLIT=0: off). */
+void psam_attention_f16x3_force_keysplit(int32_t mode);
 /* 1 when psam_gemm_f16x3p_ex accepts psam_gemm_fuse_t.row_ln_* for N output columns (Linear -> LayerNorm -> activation in one GEMM; common.py:493-496,
  * mask_decoder.py:53-59): N == 256 always, N == 512 with the register epilogue (packed output scaled by the a-priori bound out_k2, out_k1 == 0). */
 int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N);
@@ -239,6 +242,11 @@ int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const floa
 int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                                 int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
                                 const float* a_scale, float k1, float k2, float* o_scale, psam_stream_t stream);
+/* the same with the key split capped: max_keysplit = 1 never splits (a caller that keeps the chip busy from several streams -- throughput --
+ * is better off without the split's extra work), 4 = what psam_attention_f16x3_ex does (latency of a single cloud). */
+int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                                int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
+                                const float* a_scale, float k1, float k2, float* o_scale, int32_t max_keysplit, psam_stream_t stream);
 
 /* Self-attention on PRE-PACKED operands (head dim 64): qkv [B*L, ld] holds every row's q | k | v (column blocks of D = H*64 containers) in
  * the g8-packed hi|lo fp16 form of psam_gemm_f16x3p, all rows with ONE power-of-two scale (sc[b*L] is read) -- what the qkv GEMM writes with
@@ -314,6 +322,7 @@ typedef struct {
 typedef struct {
     int32_t dim, heads, hidden, precision;
     float eps, vk1, vk2, u_c1, u_c0;      /* attention-output bound from the LayerNorm row scale; fc1 row bound c1 t + c0 from t = ||LN2 x||_2 */
+    int32_t attn_keysplit;                /* max key split of the attention (psam_attention_f16x3_ex2): _prepare sets 4; 1 = off (throughput callers) */
     const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *proj_b, *fc1_b, *fc2_b;
     int64_t o_wqkv, o_sqkv, o_bqkv, o_wproj, o_sproj, o_w1, o_s1, o_w2, o_s2;      /* byte offsets into `prepared` */
 } psam_eva_gelu_block_plan_t;

@@ -45,6 +45,7 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
     "psam_gemm_f16x3p_force_splitk_fixup": (None, [i32]),
+    "psam_attention_f16x3_force_keysplit": (None, [i32]),
     "psam_attention_packed_force_variant": (None, [i32]),
     "psam_gemm_f16x3p_fused_row_ln": (i32, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3_ex": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, ptr]),
+    "psam_attention_f16x3_ex2": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, i32, ptr]),
     "psam_attention_packed": (i32, [ptr, i64, ptr, ptr, i64, ptr, i32, i32, i32, i32, f32, f32, ptr]),
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
     "psam_gemm_f16x3p_hyper_planes": (i32, [i32, i32]),
@@ -140,7 +142,7 @@ class EvaGeluBlockWeights(ctypes.Structure):
 
 class EvaGeluBlockPlan(ctypes.Structure):
     """psam_eva_gelu_block_plan_t (include/pointsam_hip.h)."""
-    _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "precision")] + [(n, f32) for n in ("eps", "vk1", "vk2", "u_c1", "u_c0")] +
+    _fields_ = ([(n, i32) for n in ("dim", "heads", "hidden", "precision")] + [(n, f32) for n in ("eps", "vk1", "vk2", "u_c1", "u_c0")] + [("attn_keysplit", i32)] +
                 [(n, ptr) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "proj_b", "fc1_b", "fc2_b")] +
                 [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_w2", "o_s2")])
 

@@ -13,6 +13,10 @@
 // buffered with a register prefetch; Q stays in registers, pre-scaled by scale*log2(e) so softmax uses v_exp_f32.
 #include "common.h"
 #include <math.h>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,6 +35,9 @@ struct FlashArgs {
     // of the qkv GEMM's A operand (LayerNorm output), k1 = 2^15 sqrt(D) max_n ||W_v[n]||, k2 = max |b_v|.
     const float* a_scale; float* o_scale; float k1, k2;
     int hd;       // flash_attn_f16x3_kernel: real head dim <= the kernel's HD (% 8 == 0); channels hd .. HD-1 are read as zeros, never written
+    // flash_attn_f16x3_kernel, few workgroups (one cloud): `ksplit` workgroups per (query block, head) share the key tiles; each parks its unnormalised
+    // output, running maximum and sum (device-coherent stores), and the last arrival combines them in split order (fixed: results do not depend on timing)
+    int ksplit; float* sk_part; int* sk_count;
 #ifdef PSAM_ATTN_ABLATE
     int abl;      // scripts/exp/attn_abl.*: 1 no per-tile convert+store, 2 no tile loads, 4 no exp/split, 8 no S MFMAs, 16 no PV MFMAs
 #endif
@@ -279,9 +286,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     // same K/V slice -- take ids 8 apart and share an XCD's L2 (rocprofv3 FETCH_SIZE at B=8, H=16, L=512 with the query block as the fastest
     // grid dimension: 151 MB per launch against 50 MB of q/k/v -- four XCDs each fetched every slice)
     const int nq = (p.Lq + FA_BQ - 1) / FA_BQ, HB = p.H * p.B;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x % (unsigned)p.ksplit) : 0, bid = p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)p.ksplit) : (int)blockIdx.x;
     int qb, hb;
-    if ((HB & 7) == 0) { const int id = blockIdx.x, grp = id / (8 * nq), r = id - grp * 8 * nq; hb = grp * 8 + (r & 7); qb = r >> 3; }
-    else { qb = blockIdx.x % nq; hb = blockIdx.x / nq; }
+    if ((HB & 7) == 0) { const int id = bid, grp = id / (8 * nq), r = id - grp * 8 * nq; hb = grp * 8 + (r & 7); qb = r >> 3; }
+    else { qb = bid % nq; hb = bid / nq; }
     const int head = hb % p.H, b = hb / p.H;
     const int q0 = qb * FA_BQ + wave * 32;
     const int hd = p.hd;      // == HD, or smaller (88 under HD = 128): the missing channels are zeros
@@ -374,9 +382,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         }
     };
 
-    const int ntiles = (p.Lk + FA_BKV - 1) / FA_BKV;
+    const int ntiles_all = (p.Lk + FA_BKV - 1) / FA_BKV;
+    const int t_first = p.ksplit > 1 ? (int)((int64_t)split * ntiles_all / p.ksplit) : 0;
+    const int ntiles = p.ksplit > 1 ? (int)((int64_t)(split + 1) * ntiles_all / p.ksplit) : ntiles_all;      // this workgroup's key tiles: [t_first, ntiles)
     float sk_cur, sv_cur;
-    load_tile(0);      // in flight while the query rows (and the packed output's scale) are fetched: one memory round trip, not three
+    load_tile(t_first * FA_BKV);      // in flight while the query rows (and the packed output's scale) are fetched: one memory round trip, not three
     float out_scale = 0.f;     // packed output: one scale for every row of the cloud (see FlashArgs)
     if (p.o_scale) {
         float smin = INFINITY;
@@ -427,8 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     tile_scales(0, sk_cur, sv_cur);
     store_tile(0, sk_cur, sv_cur);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+    for (int t = t_first; t < ntiles; ++t) {
+        const int buf = (t - t_first) & 1;
         const unsigned char* st_base = smem + buf * STAGE;
         if (t + 1 < ntiles && !FA_ABL(2)) load_tile((t + 1) * FA_BKV);
         const float c_s = p.scale_log2e * q_inv * fa_inv_pow2(sk_cur);     // S_scaled -> log2-domain logits
@@ -518,7 +528,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         if (!FA_ABL(32)) __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);          // 2^14 * sum of probabilities
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);                // 2^14 * sum of probabilities
+    if (p.ksplit > 1) {
+        // ---- key-split combine.  Partials: the accumulators in units of V (raw MFMA layout: [register quad][thread] float4, coalesced), then
+        // (m, l) per thread.  sc1 = device-coherent accesses (written through / not served from another XCD's stale L2 line), as in the GEMM's
+        // split-K fix-up (gemm_f16x3p.hip).  The last arrival re-reads ALL partials, its own too, and adds them in split order.
+        constexpr int SC1 = 16, QUADS = DT * 4, SPLIT_BYTES = (QUADS * 256 + 128) * 16;      // + 256 x (m, l) pairs
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_part + (int64_t)bid * p.ksplit * (SPLIT_BYTES / 4)), 0, 0x7fffffff, 0x00020000);
+        const float isv = fa_inv_pow2(sv_acc);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float a0 = oacc[d][4 * r4] * isv, a1 = oacc[d][4 * r4 + 1] * isv, a2 = oacc[d][4 * r4 + 2] * isv, a3 = oacc[d][4 * r4 + 3] * isv;
+                const f32x4 vf = {a0, a1, a2, a3};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fa_u32x4, vf), rs, split * SPLIT_BYTES + ((d * 4 + r4) * 256 + tid) * 16, 0, SC1);
+            }
+        {
+            const fa_f32x2 ml = {m_run, l_tot};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fa_u32x2, ml), rs, split * SPLIT_BYTES + QUADS * 256 * 16 + tid * 8, 0, SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(&smax[0][0][0]);
+        if (tid == 0) *flag = (int)__hip_atomic_fetch_add(p.sk_count + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.ksplit - 1) return;
+        if (tid == 0) __hip_atomic_store(p.sk_count + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float ms[4], ls[4], m_all = -INFINITY;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            ms[sp] = -INFINITY; ls[sp] = 0.f;
+            if (sp < p.ksplit) {
+                const fa_f32x2 ml = __builtin_bit_cast(fa_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, sp * SPLIT_BYTES + QUADS * 256 * 16 + tid * 8, 0, SC1));
+                ms[sp] = ml[0]; ls[sp] = ml[1];
+                m_all = fmaxf(m_all, ml[0]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+        l_tot = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            if (sp < p.ksplit) {      // uniform
+                const float w = __builtin_amdgcn_exp2f(ms[sp] - m_all);
+                l_tot = __builtin_fmaf(w, ls[sp], l_tot);
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, sp * SPLIT_BYTES + ((d * 4 + r4) * 256 + tid) * 16, 0, SC1));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oacc[d][4 * r4 + e] = __builtin_fmaf(w, v[e], oacc[d][4 * r4 + e]);
+                    }
+            }
+        }
+        sv_acc = 1.f;
+    }
     const float inv = fa_inv_pow2(sv_acc) / l_tot;                  // (oacc / (2^14 sv)) / (l_tot / 2^14)
     const int qrow = q0 + r32;
     if (p.o_scale) {
@@ -552,11 +620,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     }
 }
 
+// Key-split state of a stream (see FlashArgs.ksplit): a partial-state workspace and one arrival counter per (query block, head), allocated on the
+// stream's first use -- outside a graph capture; a captured launch on a stream without them runs unsplit -- and shared by the stream's (ordered)
+// launches.  PSAM_ATTN_KEYSPLIT=0 / psam_attention_f16x3_force_keysplit(0) switch the split off.
+constexpr int64_t FA_SK_WS_BYTES = (int64_t)32 << 20, FA_SK_MAX_UNITS = 4096;
+struct FaStreamBlock { float* part; int* count; };
+static int g_fa_keysplit = -1;
+static bool fa_keysplit_enabled() {
+    if (g_fa_keysplit >= 0) return g_fa_keysplit != 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_ATTN_KEYSPLIT"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
+PSAM_API void psam_attention_f16x3_force_keysplit(int32_t mode) { g_fa_keysplit = mode; }
+static FaStreamBlock fa_stream_block(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, FaStreamBlock> table;
+    int dev = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipGetDevice(&dev) != hipSuccess || hipStreamIsCapturing(stream, &cs) != hipSuccess) return {nullptr, nullptr};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find({dev, stream});
+    if (it != table.end()) return it->second;
+    if (cs != hipStreamCaptureStatusNone) return {nullptr, nullptr};
+    void* part = nullptr; void* count = nullptr;
+    if (hipMalloc(&part, FA_SK_WS_BYTES) != hipSuccess) return {nullptr, nullptr};
+    if (hipMalloc(&count, FA_SK_MAX_UNITS * sizeof(int)) != hipSuccess || hipMemsetAsync(count, 0, FA_SK_MAX_UNITS * sizeof(int), stream) != hipSuccess) {
+        (void)hipFree(part); if (count) (void)hipFree(count);
+        return {nullptr, nullptr};
+    }
+    const FaStreamBlock b = {static_cast<float*>(part), static_cast<int*>(count)};
+    table[{dev, stream}] = b;
+    return b;
+}
+
 // Same contract as psam_attention_f32; head_dim 64, or a multiple of 8 in (64, 128] (computed zero-padded to 128: the giant encoder's 88).  a_scale != NULL: packed output (FlashArgs), o_scale [B*Lq] receives the row
 // scales; o must then be 32-byte aligned with ldo % 8 == 0 and H*hd % 8 == 0.
-PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
-                                         int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
-                                         float scale, const float* a_scale, float k1, float k2, float* o_scale, hipStream_t stream) {
+PSAM_API int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                                          int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                                          float scale, const float* a_scale, float k1, float k2, float* o_scale, int32_t max_keysplit, hipStream_t stream) {
     PSAM_REQUIRE(q && k && v && o, PSAM_EINVAL, "psam_attention_f16x3: null pointer");
     PSAM_REQUIRE((a_scale == nullptr) == (o_scale == nullptr), PSAM_EINVAL, "psam_attention_f16x3: packed output needs both a_scale and o_scale");
     PSAM_REQUIRE(!o_scale || ((ldo & 7) == 0 && ((uintptr_t)o & 31) == 0 && (so & 7) == 0 && Lq == Lk), PSAM_EINVAL,
@@ -576,7 +678,26 @@ PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq
 #ifdef PSAM_ATTN_ABLATE
     p.abl = g_attn_abl;
 #endif
-    const dim3 grid((unsigned)(psam_cdiv(Lq, FA_BQ) * H * B)), block(256);      // 1-D over (query block, head, batch), see the kernel
+    // few workgroups (one cloud: 16 heads x 4 query blocks = 64 on 256 CUs, each walking all key tiles in sequence): split the keys over up to four
+    // workgroups per (query block, head); the last arrival combines the partial softmax states in the kernel (no second launch)
+    p.ksplit = 1; p.sk_part = nullptr; p.sk_count = nullptr;
+    const int64_t units = (int64_t)psam_cdiv(Lq, FA_BQ) * H * B;
+    {
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        const int ntiles = (int)psam_cdiv(Lk, FA_BKV), HDk = hd == 64 ? 64 : 128;
+        const int64_t split_bytes = ((int64_t)(HDk / 32) * 4 * 256 + 128) * 16;
+        int ks = fa_keysplit_enabled() ? (int)(ncu / units) : 1;
+        if (ks > 4) ks = 4;
+        if (ks > max_keysplit) ks = max_keysplit;
+        if (ks > ntiles / 2) ks = ntiles / 2;
+        while (ks > 1 && units * ks * split_bytes > FA_SK_WS_BYTES) --ks;
+        if (ks > 1 && units <= FA_SK_MAX_UNITS && hd > 64) {      // (head dim 64 at this size runs on the packed-operand kernel)
+            FaStreamBlock blk = fa_stream_block(stream);
+            if (blk.part) { p.ksplit = ks; p.sk_part = blk.part; p.sk_count = blk.count; }
+        }
+    }
+    const dim3 grid((unsigned)(units * p.ksplit)), block(256);      // 1-D over (key split, query block, head, batch), see the kernel
     if (hd == 64) hipLaunchKernelGGL((flash_attn_f16x3_kernel<64>), grid, block, 0, stream, p);
     else if (hd > 64 && hd <= 128 && (hd & 7) == 0) hipLaunchKernelGGL((flash_attn_f16x3_kernel<128>), grid, block, 0, stream, p);   // zero-padded to 128
     else {
@@ -584,6 +705,12 @@ PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq
         return PSAM_EINVAL;
     }
     return psam_launch_status("psam_attention_f16x3: launch failed");
+}
+
+PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                                         int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
+                                         float scale, const float* a_scale, float k1, float k2, float* o_scale, hipStream_t stream) {
+    return psam_attention_f16x3_ex2(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, B, H, Lq, Lk, hd, scale, a_scale, k1, k2, o_scale, 4, stream);
 }
 
 PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,

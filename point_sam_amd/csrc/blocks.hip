@@ -258,6 +258,7 @@ PSAM_API int32_t psam_eva_gelu_block_prepare(const psam_eva_gelu_block_weights_t
     for (int n = 0; n < H; ++n) { n1 = std::fmax(n1, row_norm(&w1[(size_t)n * D], D)); bm1 = std::fmax(bm1, std::fabs((double)b1[n])); }
     std::memset(plan, 0, sizeof(*plan));
     plan->dim = D; plan->heads = heads; plan->hidden = H; plan->precision = wt->precision; plan->eps = wt->eps;
+    plan->attn_keysplit = 4;
     plan->vk1 = (float)(32768.0 * std::sqrt((double)D) * nv); plan->vk2 = (float)bv;
     plan->u_c1 = (float)(1.002 * n1); plan->u_c0 = (float)(1.002 * bm1 + 1e-30);      // |GELU(W_n . h + b_n)| <= ||W_n|| t + |b_n|, t = ||h||_2
     plan->norm1_w = wt->norm1_w; plan->norm1_b = wt->norm1_b; plan->norm2_w = wt->norm2_w; plan->norm2_b = wt->norm2_b; plan->proj_b = wt->proj_b;
@@ -329,8 +330,8 @@ PSAM_API int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, con
     if (rc) return rc;
     rc = gemm(h, Dp, rs, plan->o_wqkv, plan->o_sqkv, 3 * D, Dp, qkv, 3 * D, P(plan->o_bqkv), nullptr, 0);
     if (rc) return rc;
-    rc = psam_attention_f16x3_ex(qkv, 3 * D, (int64_t)L * 3 * D, qkv + D, 3 * D, (int64_t)L * 3 * D, qkv + 2 * D, 3 * D, (int64_t)L * 3 * D, o, Dp, (int64_t)L * Dp, B, heads, L, L,
-                                 hd, (float)std::pow((double)hd, -0.5), rs, plan->vk1, plan->vk2, so, stream);      // float(hd ** -0.5), as the host computes it
+    rc = psam_attention_f16x3_ex2(qkv, 3 * D, (int64_t)L * 3 * D, qkv + D, 3 * D, (int64_t)L * 3 * D, qkv + 2 * D, 3 * D, (int64_t)L * 3 * D, o, Dp, (int64_t)L * Dp, B, heads, L, L,
+                                  hd, (float)std::pow((double)hd, -0.5), rs, plan->vk1, plan->vk2, so, plan->attn_keysplit > 0 ? plan->attn_keysplit : 1, stream);      // float(hd ** -0.5), as the host computes it
     if (rc) return rc;
     rc = gemm(o, Dp, so, plan->o_wproj, plan->o_sproj, D, Dp, x, D, plan->proj_b, x, 0);
     if (rc) return rc;

@@ -791,7 +791,7 @@ class BatchPipeline:
             t.record_stream(ds)
         ds.wait_stream(main)
         ds.wait_event(ready)
-        with torch.cuda.stream(ds):
+        with torch.cuda.stream(ds), ops.attention_keysplit(1):      # several batches in flight: the other streams fill idle CUs, no key split
             st = m.encode(coords, features, tok)
             out = m.decode(st, prompt_coords, prompt_labels, prompt_masks, multimask_output)
             done = torch.cuda.Event()
@@ -862,14 +862,16 @@ class GraphPipeline:
             with torch.cuda.stream(self.tok_stream):
                 tok = model.tokenize(st.coords, with_interp=True)
             ds.wait_stream(self.tok_stream)
-            with torch.cuda.stream(ds):
+            # the key split of the single-cloud attention serves the latency of ONE stream; with several dense streams the graphs are captured without it
+            keysplit = ops.attention_keysplit(1 if len(self.dense) > 1 else 4)
+            with torch.cuda.stream(ds), keysplit:
                 dense_body(st, tok)
             torch.cuda.synchronize(dev)
             st.g_tok = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st.g_tok, stream=self.tok_stream):
                 st.tok = model.tokenize(st.coords, with_interp=True)
             st.g_dense = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.g_dense, stream=ds):
+            with torch.cuda.graph(st.g_dense, stream=ds), keysplit:
                 st.out = dense_body(st, st.tok)
             st.tok_done, st.done = torch.cuda.Event(), torch.cuda.Event()
             self.slots.append(st)

@@ -60,6 +60,29 @@ def __getattr__(name):
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
+# Key split of the fp16-pipe attention for single-cloud shapes (csrc/attention.hip, psam_attention_f16x3_ex2): 4 = up to four workgroups per
+# (query block, head), combined in the kernel -- the latency of ONE stream of work; 1 = off, what the multi-stream pipelines use (their other streams
+# fill the idle CUs and the split's extra work costs throughput: 133 -> 129 sessions/s at cfg #5, while the encoder latency drops 8.7 -> 8.1 ms).
+_ATTN_KEYSPLIT_VAR = contextvars.ContextVar("point_sam_amd_attn_keysplit", default=4)
+
+
+def current_attention_keysplit() -> int:
+    return _ATTN_KEYSPLIT_VAR.get()
+
+
+class attention_keysplit:
+    """Context manager: cap of the attention's key split for the enclosed launches (1 = never split)."""
+
+    def __init__(self, n: int):
+        self.n = max(1, int(n))
+
+    def __enter__(self):
+        self.token = _ATTN_KEYSPLIT_VAR.set(self.n)
+
+    def __exit__(self, *exc):
+        _ATTN_KEYSPLIT_VAR.reset(self.token)
+
+
 SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 128
 SKINNY_MAX_M = 64      # up to this many rows nn.Linear runs on the skinny kernel (exact fp32 products, like "f32")
 GEMM_MODES = ("f32", "bf16x6", "f16x3")
@@ -283,9 +306,29 @@ class F16Weight:
         _row_view(W, "W")
         self.fp32 = W
         self.N, self.K = W.shape
-        self.scale = row_scale_f16(W)
-        self.packed = pack_rows_g8(W, self.scale)
-        self.Kp = self.packed.shape[1]
+        self.Kp = _kpad(self.K)
+        self._scale = self._packed = None      # packed on first use: weights that only ever run through a coarse C-ABI stage (psam_eva_block & co. hold
+                                                # their own packed blob) never get this second copy
+
+    def _materialise(self):
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.PointSamHipError("F16Weight: first use inside a graph capture (run one eager pass first, as GraphPipeline does)")
+        self._scale = row_scale_f16(self.fp32)
+        self._packed = pack_rows_g8(self.fp32, self._scale)
+        assert self._packed.shape[1] == self.Kp
+        torch.cuda.current_stream(self.fp32.device).synchronize()      # other streams may use it right after (the pipelines run several)
+
+    @property
+    def scale(self):
+        if self._scale is None:
+            self._materialise()
+        return self._scale
+
+    @property
+    def packed(self):
+        if self._packed is None:
+            self._materialise()
+        return self._packed
 
     @staticmethod
     def eligible(N: int, K: int) -> bool:
@@ -509,7 +552,7 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
         if not attention_can_pack(hd):
             raise ValueError("packed attention output needs the f16x3 kernel (head dim 64, or a multiple of 8 in (64, 128])")
         a_scale, k1, k2, o_scale = pack
-        check(L.psam_attention_f16x3_ex(*args, a_scale.data_ptr(), float(k1), float(k2), o_scale.data_ptr(), _stream()), "psam_attention")
+        check(L.psam_attention_f16x3_ex2(*args, a_scale.data_ptr(), float(k1), float(k2), o_scale.data_ptr(), current_attention_keysplit(), _stream()), "psam_attention")
         return out
     fn = L.psam_attention_f16x3 if (current_gemm_mode() == "f16x3" and _f16x3_head_dim(hd)) else L.psam_attention_f32
     check(fn(*args, _stream()), "psam_attention")
@@ -617,6 +660,7 @@ class EvaGeluBlock:
         need = int(lib.psam_eva_gelu_block_ws_bytes(M, self.dim, self.hidden))
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        self.plan.attn_keysplit = current_attention_keysplit()
         check(lib.psam_eva_gelu_block(ctypes.byref(self.plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), _stream()), "psam_eva_gelu_block")
         return x
 

@@ -993,6 +993,52 @@ def test_attention_packed_operands(ops, H, L, B, spike):
         assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("hd,H,L,B", [(88, 16, 512, 1), (128, 4, 300, 1), (88, 4, 1000, 2)])      # H * hd % 32 == 0: the packed rows have no padding
+def test_flash_attention_f16x3_key_split(ops, hd, H, L, B):
+    """One cloud through the giant encoder's attention (16 heads x 4 query blocks = 64 workgroups on 256 CUs): the key tiles are split over up to
+    four workgroups per (query block, head) and the last arrival combines the partial softmax states in split order inside the kernel.  Same
+    accuracy against an fp64 SDPA as the unsplit launch, bitwise repeatable, packed output = packing of the fp32 output; a key that dominates late
+    and V magnitudes that change by 2^10 between the splits (each split carries its own running maximum and V-tile scale)."""
+    L0 = ops._lib.load()
+    g = torch.Generator().manual_seed(hd * 7 + L)
+    D = H * hd
+    q = torch.randn(B, L, D, generator=g) * torch.exp(torch.randn(B, L, 1, generator=g))
+    k = torch.randn(B, L, D, generator=g)
+    v = torch.randn(B, L, D, generator=g)
+    k[0, L - 30, :hd] = q[0, 7, :hd] * 3.0
+    v[:, L // 2:] *= 1000.0
+    scale = hd ** -0.5
+    want = _sdpa(q, k, v, H, scale)
+    qd, kd, vd = (cu(t).view(-1, D) for t in (q, k, v))
+    res = {}
+    try:
+        with ops.gemm_mode("f16x3"):
+            for mode in (0, 1):
+                L0.psam_attention_f16x3_force_keysplit(mode)
+                outs = []
+                for rep in range(3):
+                    o = torch.empty(B * L, D, device="cuda")
+                    ops.attention(qd, kd, vd, o, B, H, L, L, hd, scale)
+                    outs.append(o)
+                torch.cuda.synchronize()
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"keysplit {mode}: not repeatable"
+                res[mode] = outs[0]
+            # packed output under the split
+            a_scale = torch.ones(B * L, device="cuda")
+            k1 = float(v.abs().max()) * 1.1
+            got = torch.empty(B * L, D, device="cuda"); so = torch.empty(B * L, device="cuda")
+            ops.attention(qd, kd, vd, got, B, H, L, L, hd, scale, pack=(a_scale, k1, 0.0, so))
+            assert torch.equal(got.view(torch.int32), ops.pack_rows_g8(res[1], so).view(torch.int32))
+    finally:
+        L0.psam_attention_f16x3_force_keysplit(-1)
+    e0 = (res[0].view(B, L, D).cpu().double() - want).abs().max().item() / want.abs().max().item()
+    e1 = (res[1].view(B, L, D).cpu().double() - want).abs().max().item() / want.abs().max().item()
+    print(f"\n[flash f16x3 key split hd={hd} H={H} L={L} B={B}] rel err unsplit {e0:.2e} split {e1:.2e}; differ {not torch.equal(res[0], res[1])}")
+    assert e1 < 2e-6 and e1 < 3 * e0 + 2e-7
+    if B * H * ((L + 127) // 128) * 2 <= 256 and L >= 256:
+        assert not torch.equal(res[0], res[1]), "the split path did not run"
+
+
 def test_flash_attention_f16x3_spike(ops):
     g = torch.Generator().manual_seed(9)
     B, H, hd, L = 1, 1, 64, 256
