@@ -233,7 +233,8 @@ class PointCloudSAM:
             if cfg.embed_dim == 256 and "mask_decoder.output_upscaling.0.weight" in w:
                 self.c_upscale = ops.CUpscale(w, cfg.ln_eps)
             self.c_twoway = ops.CTwoWay(w, "mask_decoder.transformer", cfg.dec_depth, cfg.embed_dim, cfg.dec_heads, cfg.dec_mlp, cfg.dec_downsample, cfg.ln_eps) \
-                if cfg.dec_depth <= 4 and cfg.embed_dim % 32 == 0 else None
+                if cfg.dec_depth <= 4 and cfg.embed_dim % 32 == 0 and cfg.dec_mlp % 32 == 0 and (cfg.embed_dim // cfg.dec_downsample) % cfg.dec_heads == 0 \
+                and cfg.embed_dim % cfg.dec_heads == 0 else None      # psam_twoway_decoder_prepare's preconditions: anything else runs the Python sequence
             if cfg.vit.swiglu and ops.EvaBlock.supported(D, cfg.vit.heads, cfg.vit.mlp_hidden):
                 for blk in self.blocks:     # the library's own packing of the block (psam_eva_block_prepare)
                     blk.c_block = ops.EvaBlock(w, blk.p, D, cfg.vit.heads, cfg.vit.mlp_hidden, cfg.vit.ln_eps)

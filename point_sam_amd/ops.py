@@ -602,7 +602,7 @@ class EvaBlock:
 
     @staticmethod
     def supported(dim: int, heads: int, hidden: int) -> bool:
-        return dim % heads == 0 and dim // heads == 64 and dim % 32 == 0 and ((hidden + 31) // 32 * 32) % 64 == 0
+        return dim % heads == 0 and dim // heads == 64 and dim % 32 == 0 and 256 <= dim <= 4096 and ((hidden + 31) // 32 * 32) % 64 == 0      # 256..4096: the packed LayerNorm (layernorm_can_pack)
 
     def run(self, x, B: int, L: int, ws=None):
         """x [B*L, dim] fp32, updated in place."""
