@@ -405,16 +405,22 @@ __global__ void scatter_fill_kernel(float* __restrict__ out, int64_t n, float v)
     if (t < n) out[t] = v;
 }
 __global__ void scatter_amax_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ idx, int64_t rows, int C, int64_t rows_per_set,
-                                    int64_t set_stride, int idx_rep, float* __restrict__ out) {
+                                    int64_t set_stride, int idx_rep, float* __restrict__ out, int64_t out_rows) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * C) return;
     const int64_t r = t / C;
     const int c = (int)(t % C);
     const int64_t set = r / rows_per_set, within = r - set * rows_per_set;
     const int64_t dest = idx[(set / idx_rep) * rows_per_set + within] + set * set_stride;
+    if (dest < 0 || dest >= out_rows) return;      // a bad index / set stride from the caller never writes outside `out`
     const float raw = x[r * ldx + c];
-    const float v = raw == 0.f ? 0.f : raw;      // -0.0 -> +0.0: as an integer pattern -0.0 is INT_MIN and would lose against every negative value
     float* o = out + dest * C + c;
+    if (raw != raw) {      // NaN propagates (torch scatter_reduce "amax"): the canonical positive quiet NaN is the largest signed pattern any input can set
+        atomicMax(reinterpret_cast<int*>(o), 0x7fc00000);
+        return;
+    }
+    const float v = raw == 0.f ? 0.f : raw;      // -0.0 -> +0.0: as an integer pattern -0.0 is INT_MIN and would lose against every negative value
+    // a destination already holding that NaN keeps it: signed max cannot go below it, and the unsigned min of a negative value (>= 0x80000000) neither
     if (v >= 0.f) atomicMax(reinterpret_cast<int*>(o), __float_as_int(v));
     else atomicMin(reinterpret_cast<unsigned*>(o), __float_as_uint(v));
 }
@@ -429,7 +435,7 @@ PSAM_API int32_t psam_scatter_amax(const float* x, int64_t ldx, const int64_t* i
                  "psam_scatter_amax: bad argument");
     const int64_t n = out_rows * C;
     hipLaunchKernelGGL(scatter_fill_kernel, dim3((unsigned)psam_cdiv(n, 256)), dim3(256), 0, stream, out, n, include_self ? 0.f : -INFINITY);
-    hipLaunchKernelGGL(scatter_amax_kernel, dim3((unsigned)psam_cdiv(rows * C, 256)), dim3(256), 0, stream, x, ldx, idx, rows, C, rows_per_set, set_stride, idx_rep, out);
+    hipLaunchKernelGGL(scatter_amax_kernel, dim3((unsigned)psam_cdiv(rows * C, 256)), dim3(256), 0, stream, x, ldx, idx, rows, C, rows_per_set, set_stride, idx_rep, out, out_rows);
     if (!include_self) hipLaunchKernelGGL(scatter_fix_kernel, dim3((unsigned)psam_cdiv(n, 256)), dim3(256), 0, stream, out, n);
     return psam_launch_status("psam_scatter_amax: launch failed");
 }

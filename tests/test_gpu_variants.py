@@ -131,6 +131,24 @@ def test_scatter_amax_and_group_feats_kernels(build):
     want0 = torch.zeros(B * G, C).scatter_reduce(0, idx.reshape(-1, 1).expand(-1, C), x, "amax")       # as MaskEncoderNN does it: no batch offset
     got0 = ops.scatter_amax(x.cuda(), idx.cuda(), B * G, rows_per_set=N, set_stride=0, include_self=True)
     assert torch.equal(got0.cpu(), want0)
+    # NaN propagates like torch's amax (whatever arrives before or after it); an index outside the output is skipped, never written through
+    xn = x.clone(); xn[5, 2] = float("nan"); xn[B * N - 1, 0] = float("nan")
+    want_n = x.view(B, N, C).new_zeros(B, G, C).scatter_reduce(1, idx.unsqueeze(-1).expand(B, N, C), xn.view(B, N, C), "amax", include_self=False)
+    got_n = ops.scatter_amax(xn.cuda(), idx.cuda(), B * G, rows_per_set=N, set_stride=G, include_self=False).cpu().view(B, G, C)
+    assert torch.equal(torch.isnan(got_n), torch.isnan(want_n)) and int(torch.isnan(want_n).sum()) == 2
+    assert torch.equal(torch.nan_to_num(got_n, nan=0.0), torch.nan_to_num(want_n, nan=0.0))
+    bad = idx.clone(); bad[0, :5] = 10 ** 9; bad[1, :3] = -(10 ** 9)
+    keep = torch.ones(B, N, dtype=torch.bool); keep[0, :5] = False; keep[1, :3] = False
+    xs = torch.where(keep.view(-1, 1), x, torch.full_like(x, -float("inf")))
+    want_b = x.view(B, N, C).new_zeros(B, G, C).scatter_reduce(1, idx.unsqueeze(-1).expand(B, N, C), xs.view(B, N, C), "amax", include_self=False)
+    want_b = torch.where(torch.isinf(want_b), torch.zeros_like(want_b), want_b)
+    guard = torch.full((B * G + 8, C), 123.0, device="cuda")
+    from point_sam_amd import _lib
+    L = _lib.load()
+    xc, bc = x.cuda(), bad.cuda()
+    ops.check(L.psam_scatter_amax(xc.data_ptr(), C, bc.data_ptr(), B * N, C, N, G, 1, guard.data_ptr(), B * G, 0, None), "psam_scatter_amax")
+    torch.cuda.synchronize()
+    assert torch.equal(guard[: B * G].cpu().view(B, G, C), want_b) and bool((guard[B * G:] == 123.0).all())
     xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
     centers, feats = xyz[:, :G].contiguous(), torch.rand(B, N, 3, generator=g)
     _, nn = O.knn(xyz, centers, 1, "exact")
