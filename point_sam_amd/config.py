@@ -52,6 +52,8 @@ class ModelConfig:
     variant: str = "knn"
     nn_hidden: int = 256             # PatchEmbedNN.hidden_dim   (voronoi.yaml:7)
     nn_mask_hidden: int = 1024       # MaskEncoderNN first_nn / ResMlp width: fixed in the reference (prompt_encoder.py:259-260)
+    nn_mask_scatter_fixed: bool = False   # MaskEncoderNN scatters every mask set into the FIRST set's cells (no batch offset, prompt_encoder.py:291-297):
+                                          # False = as the reference does it (results must equal the reference's); True = each set into its own cells
     hier_groups: tuple = (2048, 512)     # PatchEmbedHier.num_patches (hier.yaml:8)
     hier_sizes: tuple = (32, 32)         # PatchEmbedHier.patch_size  (hier.yaml:9)
     hier_radius: tuple = (0.05, 0.1)     # hier.yaml:10 (also MaskEncoderHier.radius, :18); None = no normalisation

@@ -18,6 +18,8 @@ The reference as found (see oracle/variants_oracle.py, which restates it and is 
   * PointCloudSAMHier defines only forward, with the random click sampler (common.py:319-365); `forward` here uses the deterministic
     evaluation sampler of the base model (the reference's own choice for evaluation, common.py:287-316), predict_masks is the same decode.
 """
+import warnings
+
 import torch
 
 from . import ops
@@ -126,7 +128,11 @@ class PointCloudSAMNN(_VariantBase):
         B, G = st.coords.shape[0], st.centers.shape[1]
         pg = ops.nn_group_feats(st.coords, st.centers, st.knn_idx, logits=pm, width=8)
         feat = ops.linear(pg, self._padded("mask_encoder.first_nn.weight", 8), self.w["mask_encoder.first_nn.bias"])
-        agg = ops.scatter_amax(feat, st.knn_idx, Z * G, rows_per_set=N, set_stride=0, idx_rep=Z // B, include_self=True)
+        fixed = bool(getattr(self.cfg, "nn_mask_scatter_fixed", False))
+        if Z > 1 and not fixed:
+            warnings.warn("MaskEncoderNN with more than one mask set pools every set into the first set's cells, as the reference does (prompt_encoder.py:291-297); "
+                          "ModelConfig.nn_mask_scatter_fixed=True gives each set its own cells", RuntimeWarning, stacklevel=2)
+        agg = ops.scatter_amax(feat, st.knn_idx, Z * G, rows_per_set=N, set_stride=G if fixed else 0, idx_rep=Z // B, include_self=True)
         del feat
         x = self._lin(S + ".0", agg)
         self._ln(S + ".1", x, eps, act=ACT_GELU, out=x)
