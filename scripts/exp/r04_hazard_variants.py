@@ -9,6 +9,7 @@ gpurun), patches the fetch of the pass loop behind -DPSAM_HAZ=n and builds one l
   4  as 0, plus the whole LDS allocation filled with NaN at kernel entry (stale-LDS read?)
   5  as 0, ds_read issued BEFORE the three ds_bpermute (does the stale value follow the last-issued bpermute?)
 
+To re-run on the GPU box take the hazard_tree lines out of .gpurunignore first (the tree + its variant libraries are ~110 MB per push).
 scripts/exp/r04_hazard_run.sh runs the reproducer (graph pipeline at the bench configuration vs eager) on each of them on the GPU box.
 """
 import os, subprocess, sys
