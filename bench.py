@@ -239,8 +239,37 @@ class HipHarness:
                     best = m[:, 0]
                 e1.record(); torch.cuda.synchronize()
                 per.append(e0.elapsed_time(e1) / (prompt.shape[1] - 1))
-            st["ms_per_additional_click"] = round(sorted(per)[1], 3)
-            st["ms_per_additional_click_note"] = "eager launches, HIP events around clicks 2..T on the cached encoder state, median of 3"
+            st["ms_per_additional_click_eager"] = round(sorted(per)[1], 3)
+            # the same clicks 2..T as ONE captured graph on the cached state (what the timed sessions replay): the ~60 launches of a click are issued
+            # by the GPU front end instead of Python, so the figure is the kernels' own time
+            m, i = self.model.decode(enc, prompt[:, :1].contiguous(), labels[:, :1].contiguous(), None, True)
+            best0 = torch.gather(m, 1, i.argmax(1).view(-1, 1, 1).expand(-1, 1, xyz.shape[1]))[:, 0].contiguous()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+
+            def later_clicks():
+                best = best0
+                for t in range(1, prompt.shape[1]):
+                    mm, _ = self.model.decode(enc, prompt[:, : t + 1].contiguous(), labels[:, : t + 1].contiguous(), best, False)
+                    best = mm[:, 0]
+                return best
+
+            with torch.cuda.stream(side):
+                later_clicks()      # eager once on the capture stream: one-time set-up must not happen inside the capture
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                last = later_clicks()
+            torch.cuda.synchronize()
+            per_g = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+                per_g.append(e0.elapsed_time(e1) / (prompt.shape[1] - 1))
+            del last
+            st["ms_per_additional_click"] = round(sorted(per_g)[2], 3)
+            st["ms_per_additional_click_note"] = ("clicks 2..T on the cached encoder state replayed as one HIP graph (median of 5 replays); "
+                                                  "`ms_per_additional_click_eager` = the same clicks issued launch by launch from Python (median of 3)")
         return st, tokenizer_metrics(st, a.batch, a.points, a.groups, a.group_size)
 
     def cpu_baseline(self, out, iters=3):
