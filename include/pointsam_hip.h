@@ -150,6 +150,10 @@ void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
 /* psam_attention_f16x3(_ex) with few workgroups (one cloud, head dim in (64, 128]): up to four workgroups per (query block, head) share the key tiles and
  * the last arrival combines their partial softmax states in split order.  0 = never split, 1 / -1 = the default (environment PSAM_ATTN_KEYSPLIT=0: off). */
 void psam_attention_f16x3_force_keysplit(int32_t mode);
+/* psam_twoway_decoder: 1 = the patch-side projections of a layer run on a side stream forked from (and joined back into) the caller's stream -- also
+ * inside a graph capture --, 0 / -1 = everything in sequence on the caller's stream (the default: the fork measured slower, csrc/blocks.hip TwSide;
+ * environment PSAM_TWOWAY_FORK=1 switches it on).  Same kernels, same bits. */
+void psam_twoway_decoder_force_fork(int32_t mode);
 /* 1 when psam_gemm_f16x3p_ex accepts psam_gemm_fuse_t.row_ln_* for N output columns (Linear -> LayerNorm -> activation in one GEMM; common.py:493-496,
  * mask_decoder.py:53-59): N == 256 always, N == 512 with the register epilogue (packed output scaled by the a-priori bound out_k2, out_k1 == 0). */
 int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N);

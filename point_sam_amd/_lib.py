@@ -46,6 +46,7 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
     "psam_gemm_f16x3p_force_splitk_fixup": (None, [i32]),
     "psam_attention_f16x3_force_keysplit": (None, [i32]),
+    "psam_twoway_decoder_force_fork": (None, [i32]),
     "psam_attention_packed_force_variant": (None, [i32]),
     "psam_gemm_f16x3p_fused_row_ln": (i32, [i32]),
     "psam_gemm_f16x3p_stat_segs": (i32, [i32]),

@@ -9,7 +9,11 @@
 // folded LayerNorm + residual -- so that a caller in any language drives the dominant 83 % of the path's FLOPs with one call per layer.
 // Host code only; every kernel is another entry point of this library.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 #include "common.h"      // brings in include/pointsam_hip.h
 
@@ -585,7 +589,44 @@ int32_t tw_lin(const TwLin& l, const float* x, int64_t M, float* y, int act, flo
     if (M <= 64 && (l.K & 15) == 0) return psam_linear_skinny(x, l.K, l.w, l.K, l.b, nullptr, 0, y, l.N, (int32_t)M, l.N, l.K, act, stream);
     return psam_linear(x, l.K, l.w, l.K, l.b, nullptr, 0, y, l.N, (int32_t)M, l.N, l.K, act, stream);
 }
+
+// The two-way transformer has two chains per layer that do not depend on each other: the token side (self-attention, norm1, the q projection of
+// the token -> patch attention; later the token MLP) and the projections of the PATCH rows (keys + key_pe packed once, k / v of token -> patch, q of
+// patch -> token).  psam_twoway_decoder issues the patch-side chain on a side stream forked from the caller's stream by an event and joins it (two
+// events) where its results are consumed -- inside a graph capture the side stream joins the capture and the graph gets two parallel branches.
+// Same kernels on the same data: same bits.  One side stream + three events per (device, caller stream), created on first use outside a capture
+// (a captured call on a stream that has none yet runs the serial sequence).
+// MEASURED SLOWER, so OFF by default (PSAM_TWOWAY_FORK=1 / psam_twoway_decoder_force_fork(1) switch it on): the event hand-overs cost more than the
+// six short launches they take off the critical path -- eager two-way stage 0.43 -> 0.43 ms (no gain), and inside captured graphs every fork / join
+// splits the graph into segments: cfg #2 792 -> 704 clouds/s, cfg #5 131 -> 94 sessions/s, a replayed click 0.61 -> 1.27 ms (profiles/r04_twoway_fork.txt).
+struct TwSide { hipStream_t side; hipEvent_t fork, join1, join2; };
+static int g_tw_fork = -1;
+static bool tw_fork_enabled() {
+    if (g_tw_fork >= 0) return g_tw_fork != 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_TWOWAY_FORK"); on = e ? (atoi(e) != 0) : 0; }
+    return on != 0;
+}
+static const TwSide* tw_side(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, TwSide> table;
+    if (!tw_fork_enabled()) return nullptr;
+    int dev = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipGetDevice(&dev) != hipSuccess || hipStreamIsCapturing(stream, &cs) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find({dev, stream});
+    if (it != table.end()) return &it->second;
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    TwSide t;
+    if (hipStreamCreateWithFlags(&t.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.join1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return &(table[{dev, stream}] = t);
+}
 }  // namespace
+
+PSAM_API void psam_twoway_decoder_force_fork(int32_t mode) { g_tw_fork = mode; }
 
 PSAM_API size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample) {
     if (depth <= 0 || dim <= 0 || mlp <= 0 || downsample <= 0) return 0;
@@ -674,13 +715,15 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
         for (int i = 0; i < n; ++i) { jobs.job[i].x = xs[i]; jobs.job[i].xadd = xadds[i]; jobs.job[i].W = l[i].w; jobs.job[i].bias = l[i].b; jobs.job[i].y = ys[i]; jobs.job[i].ldy = l[i].N; jobs.job[i].N = l[i].N; jobs.job[i].act = 0; }
         return psam_linear_skinny_multi(&jobs, E, E, l[0].K, (int32_t)R, l[0].K, stream);
     };
-    auto gemm_packed = [&](const TwLin& l, const float* xp, const float* sx, int64_t M, float* y) -> int32_t {
+    auto gemm_packed = [&](const TwLin& l, const float* xp, const float* sx, int64_t M, float* y, hipStream_t s) -> int32_t {
         const int kp = kpad(l.K);
-        return psam_gemm_f16x3p_ex(xp, kp, sx, l.packed, kp, l.scales, y, l.N, l.b, nullptr, 0, nullptr, 0, 0, (int32_t)M, l.N, kp, 1.f, 0, nullptr, stream);
+        return psam_gemm_f16x3p_ex(xp, kp, sx, l.packed, kp, l.scales, y, l.N, l.b, nullptr, 0, nullptr, 0, 0, (int32_t)M, l.N, kp, 1.f, 0, nullptr, s);
     };
     // k_in = keys + pos, packed: shared by every projection of the layer that reads it (needs I >= 256 and packed weights)
-    auto pack_kin = [&]() -> int32_t { return psam_scale_pack_rows_g8_add(keys, E, pos, E, G, rep, (int32_t)I, E, kin_p, kpad(E), kin_s, stream); };
+    auto pack_kin = [&](hipStream_t s) -> int32_t { return psam_scale_pack_rows_g8_add(keys, E, pos, E, G, rep, (int32_t)I, E, kin_p, kpad(E), kin_s, s); };
 #define TWCK(call) do { rc = (call); if (rc) return rc; } while (0)
+#define TWHIP(call) do { if ((call) != hipSuccess) { psam_set_error("psam_twoway_decoder: stream fork / join failed"); return PSAM_EINVAL; } } while (0)
+    const TwSide* sd = tok_fast ? tw_side(stream) : nullptr;      // patch-side projections on a forked side stream (see TwSide)
     // Attention.forward up to out_proj: projections + softmax(q k^T / sqrt(hd)) v
     auto attn = [&](const TwLin& lq, const TwLin& lk, const TwLin& lv, const float* q_in, int64_t Mq, const float* k_in, const float* v_in, int64_t Mk, float* oq, float* ok,
                     float* ov, float* out, int Lq, int Lk) -> int32_t {
@@ -707,6 +750,17 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
             return psam_attention_small(oq, inner, (int64_t)Lq * inner, ok, inner, (int64_t)Lk * inner, ov, inner, (int64_t)Lk * inner, out, inner, (int64_t)Lq * inner, Z, H, Lq, Lk,
                                         hd, 1.0f / std::sqrt((float)hd), stream);
         };
+        const bool fork = sd && key_fast;
+        if (fork) {      // keys (as the previous layer left them) -> k_in packed, k / v for token -> patch, q for patch -> token: beside the token chain below
+            TWHIP(hipEventRecord(sd->fork, stream));
+            TWHIP(hipStreamWaitEvent(sd->side, sd->fork, 0));
+            TWCK(pack_kin(sd->side));
+            TWCK(gemm_packed(ck, kin_p, kin_s, I, ik, sd->side));
+            TWCK(tw_lin(cvl, keys, I, iv, 0, pack_buf, scale_buf, sd->side));
+            TWHIP(hipEventRecord(sd->join1, sd->side));
+            TWCK(gemm_packed(jq, kin_p, kin_s, I, iq, sd->side));
+            TWHIP(hipEventRecord(sd->join2, sd->side));
+        }
         if (tok_fast) {
             const TwLin ls[3] = {sq, sk, sv};
             const float* xs[3] = {cur, cur, cur};
@@ -734,14 +788,18 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
             TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
             TWCK(tw_lin(cq, q, R, pq, 0, pack_buf, scale_buf, stream));
         }
-        if (key_fast) {
-            TWCK(pack_kin());
-            TWCK(gemm_packed(ck, kin_p, kin_s, I, ik));
+        if (fork) {
+            TWHIP(hipStreamWaitEvent(stream, sd->join1, 0));
         } else {
-            TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
-            TWCK(tw_lin(ck, k, I, ik, 0, pack_buf, scale_buf, stream));
+            if (key_fast) {
+                TWCK(pack_kin(stream));
+                TWCK(gemm_packed(ck, kin_p, kin_s, I, ik, stream));
+            } else {
+                TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
+                TWCK(tw_lin(ck, k, I, ik, 0, pack_buf, scale_buf, stream));
+            }
+            TWCK(tw_lin(cvl, keys, I, iv, 0, pack_buf, scale_buf, stream));
         }
-        TWCK(tw_lin(cvl, keys, I, iv, 0, pack_buf, scale_buf, stream));
         TWCK(small_attn(cq, pq, ik, iv, ta, T, G));
         TWCK(tw_lin(co, ta, R, ty, 0, pack_buf, scale_buf, stream));
         TWCK(psam_layernorm(ty, E, queries, E, Lw.n2_w, Lw.n2_b, queries, E, R, E, W.eps, 0, stream));
@@ -750,7 +808,8 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
         TWCK(tw_lin(m2, tm, R, ty, 0, pack_buf, scale_buf, stream));
         TWCK(psam_layernorm(ty, E, queries, E, Lw.n3_w, Lw.n3_b, queries, E, R, E, W.eps, 0, stream));
         // patch tokens attend to the tokens
-        if (key_fast) TWCK(gemm_packed(jq, kin_p, kin_s, I, iq));      // keys + key_pe: packed once above, unchanged since
+        if (fork) TWHIP(hipStreamWaitEvent(stream, sd->join2, 0));
+        else if (key_fast) TWCK(gemm_packed(jq, kin_p, kin_s, I, iq, stream));      // keys + key_pe: packed once above, unchanged since
         else TWCK(tw_lin(jq, k, I, iq, 0, pack_buf, scale_buf, stream));
         if (tok_fast) {
             const TwLin ls[2] = {jk, jv};
@@ -771,6 +830,15 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
                 fo = L(W.final_attn.o_w, W.final_attn.o_b, E, IX);
     {
         const int inner = fq.N, hd = inner / H;
+        const bool fork = sd && I >= 256 && fk.packed && fv.packed;
+        if (fork) {
+            TWHIP(hipEventRecord(sd->fork, stream));
+            TWHIP(hipStreamWaitEvent(sd->side, sd->fork, 0));
+            TWCK(pack_kin(sd->side));
+            TWCK(gemm_packed(fk, kin_p, kin_s, I, ik, sd->side));
+            TWCK(tw_lin(fv, keys, I, iv, 0, pack_buf, scale_buf, sd->side));
+            TWHIP(hipEventRecord(sd->join1, sd->side));
+        }
         if (tok_fast) {
             const TwLin ls[1] = {fq};
             const float* xs[1] = {queries};
@@ -781,19 +849,24 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
             TWCK(psam_add_bcast(queries, (int64_t)T * E, 1, tokens, (int64_t)T * E, E, q, (int64_t)T * E, Z, T, E, stream));
             TWCK(tw_lin(fq, q, R, pq, 0, pack_buf, scale_buf, stream));
         }
-        if (I >= 256 && fk.packed) {
-            TWCK(pack_kin());
-            TWCK(gemm_packed(fk, kin_p, kin_s, I, ik));
+        if (fork) {
+            TWHIP(hipStreamWaitEvent(stream, sd->join1, 0));
         } else {
-            TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
-            TWCK(tw_lin(fk, k, I, ik, 0, pack_buf, scale_buf, stream));
+            if (I >= 256 && fk.packed) {
+                TWCK(pack_kin(stream));
+                TWCK(gemm_packed(fk, kin_p, kin_s, I, ik, stream));
+            } else {
+                TWCK(psam_add_bcast(pos, (int64_t)G * E, rep, keys, (int64_t)G * E, E, k, (int64_t)G * E, Z, G, E, stream));
+                TWCK(tw_lin(fk, k, I, ik, 0, pack_buf, scale_buf, stream));
+            }
+            TWCK(tw_lin(fv, keys, I, iv, 0, pack_buf, scale_buf, stream));
         }
-        TWCK(tw_lin(fv, keys, I, iv, 0, pack_buf, scale_buf, stream));
         TWCK(psam_attention_small(pq, inner, (int64_t)T * inner, ik, inner, (int64_t)G * inner, iv, inner, (int64_t)G * inner, ta, inner, (int64_t)T * inner, Z, H, T, G, hd,
                                   1.0f / std::sqrt((float)hd), stream));
     }
     TWCK(tw_lin(fo, ta, R, ty, 0, pack_buf, scale_buf, stream));
     TWCK(psam_layernorm(ty, E, queries, E, W.nf_w, W.nf_b, queries, E, R, E, W.eps, 0, stream));
 #undef TWCK
+#undef TWHIP
     return PSAM_OK;
 }

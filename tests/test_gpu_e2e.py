@@ -209,6 +209,35 @@ def test_c_eva_block_matches_python_sequence(gpu):
         blk.run(torch.randn(100, cfg.vit.dim, device="cuda"), 1, 100)      # M % 256 != 0
 
 
+def test_twoway_decoder_fork_is_bitwise_equal_to_serial(gpu):
+    """psam_twoway_decoder issues the patch-side projections of each layer (keys + key_pe packed, k / v for token -> patch, q for patch -> token) on a side
+    stream forked from the caller's stream and joins them where they are consumed.  Same kernels on the same data: the logits must be the SAME BITS as
+    with everything in sequence on one stream -- first click (no mask prompt) and a second click with the mask prompt, several prompt sets per cloud."""
+    from point_sam_amd import ops
+    L = ops._lib.load()
+    cfg = get_config("base", 256, 32)
+    sd = random_state_dict(cfg, seed=18)
+    xyz, rgb, prompt, labels = O.synthetic_batch(2, 8192, seed=19, num_prompts=3)
+    model = gpu(cfg, sd, precision="f16x3")
+    assert model.c_twoway is not None
+    st = model.encode(xyz.cuda(), rgb.cuda())
+    outs = {}
+    try:
+        for mode in (0, 1, 0, 1):
+            L.psam_twoway_decoder_force_fork(mode)
+            m1, i1 = model.decode(st, prompt.cuda(), labels.cuda(), None, True)
+            best = torch.gather(m1, 1, i1.argmax(1).view(-1, 1, 1).expand(-1, 1, m1.shape[2]))[:, 0]
+            m2, i2 = model.decode(st, prompt.cuda(), labels.cuda(), best, False)
+            torch.cuda.synchronize()
+            got = (m1, i1, m2, i2)
+            if mode in outs:
+                assert all(torch.equal(a, b) for a, b in zip(outs[mode], got)), f"fork={mode}: not repeatable"
+            outs[mode] = got
+    finally:
+        L.psam_twoway_decoder_force_fork(-1)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
 def test_c_eva_gelu_block_matches_python_sequence(gpu):
     """psam_eva_gelu_block (the giant encoder's block through the coarse C ABI: fused qkv with q / v bias, head dim 88 on the fp16-pipe attention,
     GELU MLP, the library's split-K factors) against the same launches sequenced by the Python host: one cloud (M = 512 token rows: split-K in
