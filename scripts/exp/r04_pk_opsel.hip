@@ -7,7 +7,7 @@
 #include <cstdio>
 #define SET "v_mov_b32 v74, %2\n\tv_mov_b32 v75, %3\n\tv_mov_b32 v42, %4\n\tv_mov_b32 v43, %5\n\tv_mov_b32 v60, %6\n\tv_mov_b32 v61, %7\n\ts_nop 7\n\t"
 #define GET "\n\ts_nop 7\n\tv_mov_b32 %0, v52\n\tv_mov_b32 %1, v53"
-#define REGS "v42", "v43", "v52", "v53", "v60", "v61", "v74", "v75"
+#define REGS "v42", "v43", "v52", "v53", "v60", "v61", "v74", "v75", "s20", "s21"
 #define FORM_LIST(X) \
     X(0,  "v_pk_mul_f32 v[52:53], v[74:75], v[42:43] op_sel:[0,1]",                 __fmul_rn(a0, b1), __fmul_rn(a1, b1)) \
     X(1,  "v_pk_mul_f32 v[52:53], v[74:75], v[42:43]",                              __fmul_rn(a0, b0), __fmul_rn(a1, b1)) \
@@ -19,7 +19,16 @@
     X(7,  "v_pk_add_f32 v[52:53], v[74:75], v[42:43] op_sel:[0,1]",                 __fadd_rn(a0, b1), __fadd_rn(a1, b1)) \
     X(8,  "v_pk_fma_f32 v[52:53], v[74:75], v[42:43], v[60:61] op_sel:[0,1,0]",     __fmaf_rn(a0, b1, c0), __fmaf_rn(a1, b1, c1)) \
     X(9,  "v_pk_mov_b32 v[52:53], v[74:75], v[42:43] op_sel:[1,0]",                 a1, b0) \
-    X(10, "v_mul_f32 v52, v74, v43\n\tv_mul_f32 v53, v75, v43",                       __fmul_rn(a0, b1), __fmul_rn(a1, b1))
+    X(10, "v_mul_f32 v52, v74, v43\n\tv_mul_f32 v53, v75, v43",                       __fmul_rn(a0, b1), __fmul_rn(a1, b1)) \
+    /* cross-lane operand forms the library's reductions and epilogues use (DPP adds, lane reads, the half-wave swap): do they share the behaviour? */ \
+    X(11, "v_add_f32_dpp v52, v74, v42 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp v53, v75, v43 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", \
+          __fadd_rn(__shfl_xor(a0, 1, 64), b0), __fadd_rn(__shfl_xor(a1, 2, 64), b1)) \
+    X(12, "v_add_f32_dpp v52, v74, v42 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp v53, v75, v43 row_mirror row_mask:0xf bank_mask:0xf", \
+          __fadd_rn(__shfl(a0, (lane & ~7) | (7 - (lane & 7)), 64), b0), __fadd_rn(__shfl(a1, (lane & ~15) | (15 - (lane & 15)), 64), b1)) \
+    X(13, "v_readlane_b32 s20, v74, 55\n\tv_readlane_b32 s21, v75, 63\n\ts_nop 3\n\tv_add_f32 v52, s20, v42\n\tv_add_f32 v53, s21, v43", \
+          __fadd_rn(__shfl(a0, 55, 64), b0), __fadd_rn(__shfl(a1, 63, 64), b1)) \
+    X(14, "v_mov_b32 v52, v74\n\tv_mov_b32 v53, v42\n\ts_nop 1\n\tv_permlane32_swap_b32 v52, v53", \
+          (lane < 32 ? a0 : __shfl(b0, lane - 32, 64)), (lane < 32 ? __shfl(a0, lane + 32, 64) : b0))
 template <int FORM> __global__ __launch_bounds__(512) void victim(unsigned* bad, int iters) {
     const int lane = threadIdx.x & 63;
     float a0 = 1.0f + lane * 0.37f, a1 = 2.0f + lane * 0.11f, b0 = 0.5f + lane * 0.07f, b1 = 3.0f + lane * 0.013f, c0 = 0.25f + lane, c1 = 7.0f - lane;
