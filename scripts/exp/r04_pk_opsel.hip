@@ -28,7 +28,7 @@
     X(13, "v_readlane_b32 s20, v74, 55\n\tv_readlane_b32 s21, v75, 63\n\ts_nop 3\n\tv_add_f32 v52, s20, v42\n\tv_add_f32 v53, s21, v43", \
           __fadd_rn(__shfl(a0, 55, 64), b0), __fadd_rn(__shfl(a1, 63, 64), b1)) \
     X(14, "v_mov_b32 v52, v74\n\tv_mov_b32 v53, v42\n\ts_nop 1\n\tv_permlane32_swap_b32 v52, v53", \
-          (lane < 32 ? a0 : __shfl(b0, lane - 32, 64)), (lane < 32 ? __shfl(a0, lane + 32, 64) : b0))
+          sw_lo, sw_hi)
 template <int FORM> __global__ __launch_bounds__(512) void victim(unsigned* bad, int iters) {
     const int lane = threadIdx.x & 63;
     float a0 = 1.0f + lane * 0.37f, a1 = 2.0f + lane * 0.11f, b0 = 0.5f + lane * 0.07f, b1 = 3.0f + lane * 0.013f, c0 = 0.25f + lane, c1 = 7.0f - lane;
@@ -36,6 +36,9 @@ template <int FORM> __global__ __launch_bounds__(512) void victim(unsigned* bad,
     for (int it = 0; it < iters; ++it) {
         float lo = 0.f, hi = 0.f, elo = 0.f, ehi = 0.f;
         b1 += 0.25f; a0 -= 0.125f; a1 += 0.5f; b0 -= 0.0625f;
+        const float b_dn = __shfl(b0, (lane + 32) & 63, 64), a_up = __shfl(a0, (lane + 32) & 63, 64);      // every lane takes part (no divergent shuffle)
+        const float sw_lo = lane < 32 ? a0 : b_dn, sw_hi = lane < 32 ? a_up : b0;      // v_permlane32_swap: lanes 32-63 of the first register <-> lanes 0-31 of the second
+        (void)sw_lo; (void)sw_hi;
 #define X(N, INSTR, ELO, EHI) if constexpr (FORM == N) { asm volatile(SET INSTR GET : "=v"(lo), "=v"(hi) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1) : REGS); elo = ELO; ehi = EHI; }
         FORM_LIST(X)
 #undef X
