@@ -47,6 +47,24 @@ def test_invalid_arguments_return_status_not_crash():
     assert lib.psam_fps_workspace_bytes(2, 1000, 10) == 2 * 4 * 4096 * 4 + 2 * (2 * 64 * 8 + 16)   # planar xyz + min-dist + cooperative keys/counter
 
 
+def test_attention_keysplit_is_per_context():
+    """The cap of the single-cloud attention's key split (ops.attention_keysplit: the multi-stream pipelines run with 1, everything else with 4) is a
+    context variable like the GEMM mode: another thread -- another pipeline, a server worker -- does not see it."""
+    import threading
+    from point_sam_amd import ops
+    assert ops.current_attention_keysplit() == 4
+    with ops.attention_keysplit(1):
+        assert ops.current_attention_keysplit() == 1
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops.current_attention_keysplit()))
+        t.start(); t.join()
+        assert seen == [4]
+        with ops.attention_keysplit(0):      # clamped: 1 = never split
+            assert ops.current_attention_keysplit() == 1
+        assert ops.current_attention_keysplit() == 1
+    assert ops.current_attention_keysplit() == 4
+
+
 def test_product_path_refuses_cpu():
     from point_sam_amd.model import PointCloudSAM
     cfg = get_config("tiny")
