@@ -71,6 +71,11 @@ def parse_args(argv=None):
                          "batch 1 (large scene); cfg5 = ViT-giant N=32768 512x64 batch 1, 5-click session (encoder cached, decoder-only loop).  Sets --config / "
                          "--points / --groups / --group-size / --batch / --clicks unless those are given explicitly")
     ap.add_argument("--clicks", type=int, default=None, help="clicks per cloud: > 1 = interactive session (click t decodes with clicks 0..t and the previous best mask)")
+    ap.add_argument("--other-workloads", default="cfg3,cfg5",
+                    help="with the default workload on one GPU: BASELINE configurations run as short extra legs after the main measurement and reported under "
+                         "`other_workloads` (value, ms_per_step, roofline.frac, parity, a one-run cpu_baseline); '' or --no-other-workloads skips them")
+    ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_const", const="")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each extra leg")
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "ply"],
                     help="synthetic: uniform clouds in the unit ball; ply: the reference's six demo clouds tiled / jittered to N points (SURVEY.md 8(d))")
     args = ap.parse_args(argv)
@@ -137,8 +142,12 @@ class HipHarness:
         self.args, self.ops = args, ops
         self.dev = torch.device("cuda", local)
         self.cfg = get_config(args.config, args.groups, args.group_size)
+        t0 = time.perf_counter()
         self.sd = random_state_dict(self.cfg, seed=42)
+        t1 = time.perf_counter()
         self.model = PointCloudSAM(self.cfg, self.sd, self.dev, precision=args.precision)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
         self.seed = 42 + rank
         self.session = args.clicks > 1
         if args.data == "ply":
@@ -158,6 +167,10 @@ class HipHarness:
         self.depth = self.gpipe.depth if self.use_graphs else (self.pipe.depth if self.pipe is not None else 1)
         self.inline = self.pipe is None and not self.use_graphs
         self.prof = None
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        # what a rank pays before its first step: N ranks do this concurrently on one host (weight generation and packing are host + device work)
+        self.startup = {"weights_s": round(t1 - t0, 3), "model_init_s": round(t2 - t1, 3), "pipeline_capture_s": round(t3 - t2, 3), "total_s": round(t3 - t0, 3)}
 
     def sync(self):
         torch.cuda.synchronize()
@@ -292,20 +305,25 @@ class HipHarness:
         else:
             oracle_one = lambda b, mode="exact": O.predict_masks(self.sd, self.cfg, full[0][b:b + 1], full[1][b:b + 1], full[2][b:b + 1], full[3][b:b + 1], None, True, mode=mode)
         run = lambda: oracle_one(0, "reference")
+        t0 = time.perf_counter()
         want_ref = run()
+        first = time.perf_counter() - t0
         want = oracle_one(0)
         ts = []
-        for _ in range(iters):
+        for _ in range(iters if iters > 1 else 0):
             t0 = time.perf_counter()
             run()
             ts.append(time.perf_counter() - t0)
+        if not ts:      # a one-run leg: the first (cold) run is the sample
+            ts = [first]
         ts.sort()
         dt = ts[len(ts) // 2]
-        base = {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port", "iterations": iters,
+        base = {"value": round(1.0 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port", "iterations": len(ts),
                 "seconds_per_cloud": {"median": round(dt, 3), "min": round(ts[0], 3), "max": round(ts[-1], 3)},
                 "sample": f"cloud 0 of the timed batch (ViT-{a.config}, N={a.points}, {a.groups}x{a.group_size}, {a.clicks} click(s)), oracle "
-                          + ("click loop, " if self.session else "mode='reference' (torch.cdist+topk), ") +
-                          f"1 warm-up + {iters} timed runs, median {dt:.1f} s; torch {torch.__version__}, {cores} threads"}
+                          + ("click loop, " if self.session else "") + "mode='reference' (torch.cdist+topk), "
+                          + (f"1 warm-up + {len(ts)} timed runs, median {dt:.1f} s" if iters > 1 else f"one (cold) run, {dt:.1f} s")
+                          + f"; torch {torch.__version__}, {cores} threads"}
         masks, iou = out
         masks, iou = masks.float().cpu(), iou.float().cpu()
         per_cloud, scale = [], 0.0
@@ -314,14 +332,28 @@ class HipHarness:
             per_cloud.append((float((masks[b:b + 1] - w[0]).abs().max()), float((iou[b:b + 1] - w[1]).abs().max())))
             scale = max(scale, float(w[0].abs().max()))
         em, ei = max(e for e, _ in per_cloud), max(e for _, e in per_cloud)
+        # Against the REFERENCE's own kNN arithmetic (torch.cdist's matmul form + topk, common.py:51-55).  Where cdist's rounding selects the same neighbour
+        # sets as the direct differences (cfg #2), the reference-mode logits must themselves be within tolerance.  Where it does not (cfg #3: ties at the
+        # 256-th distance of a 131072-point cloud), the two ORACLE modes differ by what the swapped neighbours are worth, and the HIP path -- bit-exact
+        # with the exact mode's indices -- may be that far from the reference mode, not farther: |HIP - ref| <= |exact - ref| + 1e-4.
+        st0 = self.model.encode(self.batch[0][:1].contiguous(), self.batch[1][:1].contiguous())
+        ref_idx = O.knn(O.batch_index_select(xyz, O.fps(xyz, a.groups)), xyz, a.group_size, "reference")[1]
+        same = (st0.knn_idx.cpu().sort(-1).values == ref_idx.sort(-1).values).all(-1)
+        gap_hip = float((masks[:1] - want_ref[0]).abs().max())
+        gap_oracles = float((want[0] - want_ref[0]).abs().max())
+        sets_identical = bool(same.all())
+        ok_ref = gap_hip < 1e-3 if sets_identical else gap_hip <= gap_oracles + 1e-4
+        ok_exact = bool(em < 1e-3 and ei < 1e-3)
         parity = {"checked": f"all {masks.shape[0]} cloud(s) of the last timed step's output (the graph/stream pipeline's own result"
                              + (", last click of the session" if self.session else "") + ") vs the oracle on the same inputs and weights",
                   "max_abs_err_mask_logits": em, "max_abs_err_iou": ei, "per_cloud_max_abs_err_mask_logits": [round(e, 9) for e, _ in per_cloud],
-                  "tolerance": 1e-3, "ok": bool(em < 1e-3 and ei < 1e-3), "logit_scale": scale,
+                  "tolerance": 1e-3, "ok": bool(ok_exact and ok_ref), "ok_vs_exact_oracle": ok_exact, "ok_vs_reference": bool(ok_ref), "logit_scale": scale,
                   "oracle_mode": "exact (direct fp32 coordinate differences in kNN / 3-NN)",
-                  "reference_mode_gap": {"cloud": 0, "max_abs_err_mask_logits": float((masks[:1] - want_ref[0]).abs().max()),
-                                         "note": "same cloud against the oracle in mode='reference' (torch.cdist + topk, the arithmetic cpu_baseline times): equal to the exact "
-                                                 "mode where cdist's rounding selects the same neighbour sets"}}
+                  "reference_mode_gap": {"cloud": 0, "max_abs_err_mask_logits": gap_hip, "oracle_exact_vs_reference": gap_oracles,
+                                         "groups_with_other_knn_set": int((~same).sum()), "groups": int(same.numel()),
+                                         "rule": "identical neighbour sets: |HIP - reference| < 1e-3; otherwise |HIP - reference| <= |exact - reference| + 1e-4 "
+                                                 "(the gap is then a property of the two oracle modes: cdist's rounding picks other neighbours)",
+                                         "note": "same cloud against the oracle in mode='reference' (torch.cdist + topk, the arithmetic cpu_baseline times)"}}
         return base, parity
 
 
@@ -334,6 +366,7 @@ class StubHarness:
         self.submitted, self.taken, self.queue = 0, 0, []
         self.dev = torch.device("cpu")
         self.use_graphs, self.prof = True, None
+        self.startup = {"weights_s": 0.0, "model_init_s": 0.0, "pipeline_capture_s": 0.0, "total_s": 0.001 * (rank + 1)}
 
     def sync(self):
         pass
@@ -501,11 +534,25 @@ def worker(args):
                 "gather_bytes_per_rank": int(keep[0].numel() * 4 + keep[1].numel() * 4), "backend": torch.distributed.get_backend(),
                 "note": "all_gather_into_tensor of one step's [B,3,N] logits + [B,3] IoU on the side stream, 10 back-to-back, host-timed between barriers"}
 
+    # every rank's set-up time (weights, model, graph capture) -- N ranks pay it concurrently on one host
+    startup = [H.startup]
+    if world > 1:
+        t = torch.tensor([H.startup[k] for k in ("weights_s", "model_init_s", "pipeline_capture_s", "total_s")], device=H.dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        startup = [dict(zip(("weights_s", "model_init_s", "pipeline_capture_s", "total_s"), (round(float(v), 3) for v in x.tolist()))) for x in allt]
+        # Nothing below is collective: the ranks part here, so that the measurement legs that only rank 0 runs (GEMM launch sampling, stage times)
+        # do not keep N - 1 processes waiting at a final barrier.
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        if rank != 0:
+            return
+
     prof = stage_ms = tok = None
     if not args.stub:
         if not args.no_gemm_profile:
             prof = H.gemm_profile()
-        if rank == 0 and not args.no_stage_times:
+        if not args.no_stage_times:
             stage_ms, tok = H.stage_times()
     roofline = build_roofline(args, prof, total, world, elapsed) if prof else None
 
@@ -527,6 +574,9 @@ def worker(args):
             "per_rank": {"ranks": [{"rank": r, "value": round(B * a.steps / t, 3), "ms_per_step": round(t / a.steps * 1e3, 3)} for r, t in enumerate(rank_times)],
                          "min_value": round(B * a.steps / max(rank_times), 3), "max_value": round(B * a.steps / min(rank_times), 3),
                          "note": "each rank's own clouds/s between the fences of the timed region; `value` uses the slowest rank's time"},
+            "startup_s": {"per_rank": startup, "max_total_s": max(x["total_s"] for x in startup),
+                          "note": "before the first step: seeded weights on the host, PointCloudSAM.__init__ (upload + packing of the GEMM weights), pipeline set-up "
+                                  "incl. HIP-graph capture; the ranks of a multi-GPU run do this concurrently on the shared host"},
         }
         if a.clicks > 1:
             res["config"]["clicks"] = a.clicks
@@ -536,10 +586,58 @@ def worker(args):
             res["data"] = "stub"
         elif world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = H.cpu_baseline(keep)
+        if not args.stub and world == 1 and a.workload == "cfg2" and a.other_workloads:
+            # BASELINE configs #3 / #5 as short legs of the SAME run, so that whoever runs the default command sees them (each is also a full
+            # contract line of its own under --workload)
+            del H
+            res["other_workloads"] = {w: other_leg(w, a, local) for w in a.other_workloads.split(",") if w in WORKLOADS and w != a.workload}
         print(json.dumps(res), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+
+
+def other_leg(name, base, local):
+    """One BASELINE configuration as a short leg: `--other-steps` timed passes after 2 warm-ups through the same pipeline classes as the main run,
+    the dominant GEMM's roofline fraction from sampled launches, the output of the last timed pass against the oracle (all clouds of the leg's
+    batch) and ONE oracle run timed as the CPU baseline."""
+    argv = ["--workload", name, "--steps", str(base.other_steps), "--warmup", "2", "--precision", base.precision, "--streams", str(base.streams),
+            "--slots", str(base.slots), "--sustained-steps", "0"]
+    if not base.graphs:
+        argv.append("--no-graphs")
+    a = parse_args(argv)
+    H = HipHarness(a, 0, local)
+
+    def run(n):
+        out = None
+        if H.inline:
+            for _ in range(n):
+                out = H.next()
+            return out
+        for _ in range(min(H.depth, n)):
+            H.submit()
+        for k in range(n):
+            out = H.next()
+            if k + H.depth < n:
+                H.submit()
+        return out
+
+    run(a.warmup)
+    H.sync()
+    t0 = time.perf_counter()
+    out = run(a.steps)
+    H.sync()
+    el = time.perf_counter() - t0
+    H.finalize()
+    keep = (out[0].clone(), out[1].clone())
+    leg = {"workload": f"{name}: ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={a.batch} "
+                       + (f"{a.clicks}-click session (encoder cached)" if a.clicks > 1 else "1 point prompt multimask"),
+           "value": round(a.batch * a.steps / el, 3), "unit": "sessions/s" if a.clicks > 1 else "point-clouds/s", "ms_per_step": round(el / a.steps * 1e3, 3),
+           "steps": a.steps, "warmup": a.warmup, "startup_s": H.startup}
+    if not base.no_gemm_profile:
+        roof = build_roofline(a, H.gemm_profile(), a.batch, 1, el)
+        if roof:
+            leg["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "sampled_launches", "avg_launch_ms", "avg_launch_gflop")}
+    if not base.no_cpu_baseline:
+        leg["cpu_baseline"], leg["parity"] = H.cpu_baseline(keep, iters=1)
+    return leg
 
 
 def build_roofline(args, prof, total, world, elapsed):

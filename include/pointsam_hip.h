@@ -147,13 +147,20 @@ void psam_gemm_f16x3p_force_epilogue(int32_t mode);
  * epilogue; no reduction launch), 0 = partial planes + reduction launch, -1 = the default (fix-up wherever the workspace and the stream's counters allow;
  * environment PSAM_GEMM_SPLITK_FIXUP=0 switches it off).  Tuning / test hook: both forms give the same bits for power-of-two scales. */
 void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
+/* The in-kernel fix-ups (split-K GEMM, key-split attention) keep arrival counters per (device, stream) that every launch leaves at zero.  After a
+ * FAILED launch on a stream (device fault, aborted process) call these before reusing the stream: they re-zero its counters, stream-ordered.  A HIP
+ * graph that captured such launches must replay on its capture stream (the counters' address is part of the captured launch). */
+int32_t psam_gemm_f16x3p_reset_splitk_state(psam_stream_t stream);
+int32_t psam_attention_f16x3_reset_keysplit_state(psam_stream_t stream);
 /* psam_attention_f16x3(_ex) with few workgroups (one cloud, head dim in (64, 128]): up to four workgroups per (query block, head) share the key tiles and
  * the last arrival combines their partial softmax states in split order.  0 = never split, 1 / -1 = the default (environment PSAM_ATTN_KEYSPLIT=0: off). */
 void psam_attention_f16x3_force_keysplit(int32_t mode);
 /* psam_twoway_decoder: 1 = the patch-side projections of a layer run on a side stream forked from (and joined back into) the caller's stream -- also
  * inside a graph capture --, 0 / -1 = everything in sequence on the caller's stream (the default: the fork measured slower, csrc/blocks.hip TwSide;
  * environment PSAM_TWOWAY_FORK=1 switches it on).  Same kernels, same bits. */
+#ifdef PSAM_BUILD_EXPERIMENTS      /* measured-and-rejected paths: built only with PSAM_BUILD_EXPERIMENTS=1 (point_sam_amd/build.py) */
 void psam_twoway_decoder_force_fork(int32_t mode);
+#endif
 /* 1 when psam_gemm_f16x3p_ex accepts psam_gemm_fuse_t.row_ln_* for N output columns (Linear -> LayerNorm -> activation in one GEMM; common.py:493-496,
  * mask_decoder.py:53-59): N == 256 always, N == 512 with the register epilogue (packed output scaled by the a-priori bound out_k2, out_k1 == 0). */
 int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N);
@@ -423,8 +430,10 @@ typedef struct {
     float *ktok, *vtok;
     float* ws; int64_t ws_floats;
 } psam_twoway_tokens_t;
+#ifdef PSAM_BUILD_EXPERIMENTS      /* the one-launch token side measured slower than the launches it replaces: experiments build only */
 int64_t psam_twoway_tokens_ws_floats(int32_t mlp);
 int32_t psam_twoway_tokens(const psam_twoway_tokens_t* args, psam_stream_t stream);
+#endif
 
 /* Voronoi variant (PointCloudSAMNN, configs/model/voronoi.yaml).  psam_nn_group_feats: per-point features relative to the nearest centre --
  * mode 0 = NNGrouper.forward (pc_sam/model/common.py:203-211): [unit offset 3 | distance 1 | feats C]; mode 1 = MaskEncoderNN.forward

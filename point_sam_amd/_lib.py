@@ -45,6 +45,8 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
     "psam_gemm_f16x3p_force_splitk_fixup": (None, [i32]),
+    "psam_gemm_f16x3p_reset_splitk_state": (i32, [ptr]),
+    "psam_attention_f16x3_reset_keysplit_state": (i32, [ptr]),
     "psam_attention_f16x3_force_keysplit": (None, [i32]),
     "psam_twoway_decoder_force_fork": (None, [i32]),
     "psam_attention_packed_force_variant": (None, [i32]),
@@ -206,10 +208,19 @@ class TwoWayTokens(ctypes.Structure):
 
 
 _lib = None
+# entry points of the experiments build only (PSAM_BUILD_EXPERIMENTS=1, point_sam_amd/build.py): bound when the library exports them
+EXPERIMENTAL = ("psam_twoway_decoder_force_fork", "psam_twoway_tokens_ws_floats", "psam_twoway_tokens")
+_has_experiments = False
 
 
 class PointSamHipError(RuntimeError):
     pass
+
+
+def has_experiments() -> bool:
+    """Whether the loaded library was built with PSAM_BUILD_EXPERIMENTS=1 (the measured-and-rejected paths and their entry points)."""
+    load()
+    return _has_experiments
 
 
 def load():
@@ -223,7 +234,11 @@ def load():
                 "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback on the product path."
             )
         lib = ctypes.CDLL(os.environ.get("PSAM_LIB_PATH", LIB_PATH))      # PSAM_LIB_PATH: an alternative build of the same library (A/B measurements)
+        global _has_experiments
+        _has_experiments = all(hasattr(lib, n) for n in EXPERIMENTAL)
         for name, (res, args) in SIGNATURES.items():
+            if name in EXPERIMENTAL and not _has_experiments:
+                continue
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

@@ -16,19 +16,24 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # (source, extra flags).  The tokenizer must not contract a*b+c into fma: FPS / kNN indices are bit-exact
 # against the oracle's fp32 arithmetic (oracle/tokenizer_oracle.c is built with -ffp-contract=off too).
+# PSAM_BUILD_EXPERIMENTS=1: also build the measured-and-rejected paths (the unit-ring GEMM gemm_f16x3q.hip, the one-launch token side twoway.hip, the
+# forked two-way decoder, the 128x512 row-LayerNorm GEMM tile) -- off by default: they are not on the product path, and their objects, exports, ISA
+# lint and tests cost every build and every test run (tests that need them skip unless the library was built with them).
+EXPERIMENTS = os.environ.get("PSAM_BUILD_EXPERIMENTS", "0") == "1"
 SOURCES = [
     ("tokenizer.hip", ["-ffp-contract=off"]),
     ("gemm.hip", []),
     ("gemm_split.hip", []),
     ("gemm_f16x3p.hip", []),
     ("gemm_f16x3pp.hip", []),
-    ("gemm_f16x3q.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
-    ("twoway.hip", []),
     ("blocks.hip", []),
     ("error.cpp", ["-x", "hip"]),
-]
+] + ([("gemm_f16x3q.hip", []), ("twoway.hip", [])] if EXPERIMENTS else [])
+if EXPERIMENTS:
+    COMMON = COMMON + ["-DPSAM_BUILD_EXPERIMENTS"]
+FLAGS_STAMP = os.path.join(CSRC, ".build_flags")
 
 
 def _stale(out, deps):
@@ -38,6 +43,11 @@ def _stale(out, deps):
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]   # every header: an edit to any rebuilds all objects
     hdrs.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "pointsam_hip.h"))   # the public ABI header is part of every translation unit (common.h)
+    flags = " ".join(COMMON)
+    # another flag set than the objects were built with (experiments on / off): every object is stale.  No stamp = a tree built before the stamp
+    # existed, or a snapshot that dropped it: the default flags are assumed (the GPU box must not spend minutes rebuilding a library that travelled).
+    if (open(FLAGS_STAMP).read() != flags) if os.path.exists(FLAGS_STAMP) else EXPERIMENTS:
+        force = True
     jobs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
@@ -55,18 +65,24 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     objs = [os.path.join(CSRC, os.path.splitext(s)[0] + ".o") for s, _ in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        # Link under a temporary name and move it into place only once the ISA lint has passed: a library that could not be linted (llvm-objdump
+        # missing, lint crashed) or that failed it never sits at LIB, where the next build_library() would find it "fresh" and return it unchecked.
+        tmp = LIB + ".unlinted"
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)
         # no packed-FP32 instruction with a non-uniform op_sel may ship: wrong lanes 48-63 beside another stream's GEMM workgroups (isa_lint.py)
         try:
             from . import isa_lint
         except ImportError:      # run as a script
             sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
             import isa_lint
-        bad = isa_lint.lint(LIB)
+        bad = isa_lint.lint(tmp)
         if bad:
-            os.replace(LIB, LIB + ".rejected")
+            os.replace(tmp, LIB + ".rejected")
             raise RuntimeError("libpointsam_hip.so contains packed-FP32 instructions with a non-uniform op_sel (see point_sam_amd/isa_lint.py):\n" +
                                "\n".join(f"  {k}: {i}" for k, i in bad))
+        os.replace(tmp, LIB)
+        with open(FLAGS_STAMP, "w") as f:
+            f.write(flags)
     return LIB
 
 

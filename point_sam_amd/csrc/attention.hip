@@ -654,6 +654,14 @@ static FaStreamBlock fa_stream_block(hipStream_t stream) {
     return b;
 }
 
+// The key-split counterpart of psam_gemm_f16x3p_reset_splitk_state: re-zeroes the stream's arrival counters after a failed launch (stream-ordered).
+PSAM_API int32_t psam_attention_f16x3_reset_keysplit_state(hipStream_t stream) {
+    const FaStreamBlock b = fa_stream_block(stream);
+    if (!b.count) return PSAM_OK;
+    PSAM_REQUIRE(hipMemsetAsync(b.count, 0, FA_SK_MAX_UNITS * sizeof(int), stream) == hipSuccess, PSAM_EINVAL, "psam_attention_f16x3_reset_keysplit_state: memset failed");
+    return PSAM_OK;
+}
+
 // Same contract as psam_attention_f32; head_dim 64, or a multiple of 8 in (64, 128] (computed zero-padded to 128: the giant encoder's 88).  a_scale != NULL: packed output (FlashArgs), o_scale [B*Lq] receives the row
 // scales; o must then be 32-byte aligned with ldo % 8 == 0 and H*hd % 8 == 0.
 PSAM_API int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
@@ -1031,7 +1039,7 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
     // two 128-row workgroups per CU on a two-tile ring where the 256-row grid is about one workgroup per CU (B = 8 clouds x 16 heads x 512 tokens: 256)
     const int variant = g_attn_variant >= 0 ? g_attn_variant : attn_variant_env();
     const int64_t wg4 = (int64_t)psam_cdiv(L, PA_BQ / 2) * H * B;
-    if (variant == 1 && L > PA_BQ / 2 && wg4 <= (int64_t)4 * ncu) {
+    if (variant == 1 && !force_nw && L > PA_BQ / 2 && wg4 <= (int64_t)4 * ncu) {      // (a forced workgroup shape -- PSAM_ATTN_PACKED_NW -- names the kernel: it wins)
         hipLaunchKernelGGL((flash_attn_packed_kernel<4, 2>), dim3((unsigned)wg4), dim3(256), 2 * 2 * PA_TILE, stream, p);
         return psam_launch_status("psam_attention_packed: launch failed");
     }

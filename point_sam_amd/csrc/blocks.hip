@@ -602,6 +602,9 @@ int32_t tw_lin(const TwLin& l, const float* x, int64_t M, float* y, int act, flo
 struct TwSide { hipStream_t side; hipEvent_t fork, join1, join2; };
 static int g_tw_fork = -1;
 static bool tw_fork_enabled() {
+#ifndef PSAM_BUILD_EXPERIMENTS
+    return false;      // the forked form lost (profiles/r04_twoway_fork.txt): reachable in experiments builds only
+#endif
     if (g_tw_fork >= 0) return g_tw_fork != 0;
     static int on = -1;
     if (on < 0) { const char* e = getenv("PSAM_TWOWAY_FORK"); on = e ? (atoi(e) != 0) : 0; }
@@ -626,7 +629,9 @@ static const TwSide* tw_side(hipStream_t stream) {
 }
 }  // namespace
 
+#ifdef PSAM_BUILD_EXPERIMENTS
 PSAM_API void psam_twoway_decoder_force_fork(int32_t mode) { g_tw_fork = mode; }
+#endif
 
 PSAM_API size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample) {
     if (depth <= 0 || dim <= 0 || mlp <= 0 || downsample <= 0) return 0;

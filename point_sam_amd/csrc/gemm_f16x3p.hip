@@ -69,6 +69,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r32 = lane & 31, h = lane >> 5;
+    // ABL & 64 (measurement builds): where a wave's cycles go.  Per slab six stamps -- slab top | DMA wait over | barrier passed | step-0 fragments in
+    // registers | step-0 MFMAs and step-1 reads issued | mid-slab barrier passed -- accumulated per wave into: vm, b1, f0, m0, b2, m1 (written at the end
+    // with the prologue / epilogue times, the absolute start / end stamps and HW_ID, 16 words per wave).
+    unsigned tb[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tk0 = 0, tk1 = 0, tq = 0;
+    if (ABL & 64) tk0 = gemm_now();
 
     // ---- DMA source offsets: piece b = wave + i NW covers rows 8b..8b+7 of the stage; lane -> (row b*8 + lane/8, slot lane%8),
     // which must receive chunk slot ^ swz(row) of that row.  Rows past M / N are clamped (their products are never stored).
@@ -163,8 +169,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
     auto body = [&](int t, auto waitn_c, auto issue_c, auto next_c) {
         constexpr int WAITN = decltype(waitn_c)::value;
         constexpr bool DO_ISSUE = decltype(issue_c)::value, HAS_NEXT = decltype(next_c)::value;
+        unsigned long long q0 = 0, q1 = 0;
+        if (ABL & 64) { q0 = gemm_now(); if (tq) tb[5] += (unsigned)(q0 - tq); }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        if (ABL & 64) { q1 = gemm_now(); tb[0] += (unsigned)(q1 - q0); }
         asm volatile("s_barrier" ::: "memory");
+        if (ABL & 64) { q0 = gemm_now(); tb[1] += (unsigned)(q0 - q1); }
         const int st_issue = st == 0 ? S - 1 : st - 1;          // stage of slab t-1 = stage of slab t+S-1
         const int st_next = st == S - 1 ? 0 : st + 1;
         if (PF == 1 && DO_ISSUE) {
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
 #pragma unroll
             for (int n = 0; n < NFR; ++n) read_frag(n, 0, st, f0a, f0w);
         }
+        if (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); q1 = gemm_now(); tb[2] += (unsigned)(q1 - q0); }
         __builtin_amdgcn_sched_barrier(0);
         // step 0: NMF MFMAs; behind them the NFR fragment reads of step 1 (all of them: step 1 needs them), then DMA issues
         constexpr int P0 = (NFR + NMF - 1) / NMF;                               // extra operations per MFMA slot in step 0
@@ -189,8 +200,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
                 else if (PF == 2 && DO_ISSUE && k - NFR < NL) issue_one(k - NFR, t + 2, st);
             }
             if (PF == 2 && (m + 1) * P0 >= NFR && m * P0 < NFR) {   // every step-1 fragment read is issued: wait for them, release the stage
+                if (ABL & 64) { q0 = gemm_now(); tb[3] += (unsigned)(q0 - q1); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
+                if (ABL & 64) { tq = gemm_now(); tb[4] += (unsigned)(tq - q0); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
     }
 
     // ---- epilogue (gemm_epilogue.h): every wave is done with the ring, no DMA in flight
+    if (ABL & 64) { tk1 = gemm_now(); if (tq) tb[5] += (unsigned)(tk1 - tq); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (ABL & 1) {
@@ -299,6 +313,21 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
     if constexpr (TR) gemm_store_tile_t<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, Cout, p.residual);
     else gemm_store_tile<TM, TN, true, true>(p, acc, reinterpret_cast<float*>(smem) + wave * gemm_epilogue_lds_floats_per_wave<TN>(), m0 + wm * TM * 32,
                                              n0 + wn * TN * 32, lane, Cout, p.residual, PREFETCH_EPI ? &epre : nullptr);
+    if ((ABL & 64) && p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's stores are acknowledged: the end of its epilogue
+        const unsigned long long te = gemm_now();
+        if (lane == 0) {
+            unsigned* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = tb[i];
+            d[6] = (unsigned)(tk1 - tk0) - (tb[0] + tb[1] + tb[2] + tb[3] + tb[4] + tb[5]);      // prologue: kernel entry -> top of the first slab
+            d[7] = (unsigned)(te - tk1);                                                          // epilogue incl. the final barrier and store acknowledgement
+            d[8] = (unsigned)tk0; d[9] = (unsigned)(tk0 >> 32); d[10] = (unsigned)te; d[11] = (unsigned)(te >> 32);
+            d[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+            d[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+            d[14] = (unsigned)nslabs; d[15] = (unsigned)blockIdx.x;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- row scales
@@ -448,6 +477,10 @@ PSAM_API int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const 
 // ---------------------------------------------------------------------------------------------- host
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
+#ifdef PSAM_GEMM_ABLATE
+static unsigned* g_f16x3p_dbg = nullptr;      // measurement builds: 16 words per wave of the timing instances (ABL & 64)
+extern "C" __attribute__((visibility("default"))) void psam_gemm_f16x3p_set_timing_buffer(void* buf) { g_f16x3p_dbg = (unsigned*)buf; }
+#endif
 // Epilogue of the packed-operand GEMMs: 1 = the register-only epilogue on transposed accumulator tiles (gemm_epilogue_t.h) wherever the launch's
 // options allow it, 0 = always the LDS-transposition epilogue (gemm_epilogue.h), -1 = the default (environment PSAM_GEMM_TR, else 1).
 static int g_f16x3p_tr = -1;
@@ -469,6 +502,9 @@ static int f16x3p_epilogue_mode() {
 // many resident workgroups.  Kept reachable, parity-tested (tests/test_gpu_kernels.py::test_gemm_row_ln_512).
 PSAM_API int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N) {
     if (N == 256) return 1;
+#ifndef PSAM_BUILD_EXPERIMENTS
+    return 0;      // the 128x512 full-row tile is an experiments-build configuration (measured slower, see above)
+#endif
     static int on = -1;
     if (on < 0) { const char* e = getenv("PSAM_GEMM_ROWLN512"); on = e ? atoi(e) : 0; }
     return N == 512 && on > 0 && f16x3p_epilogue_mode() > 0 ? 1 : 0;
@@ -603,6 +639,17 @@ static int* f16x3p_sk_counters(hipStream_t stream) {
     return c;
 }
 
+// After a FAILED or aborted launch on `stream` (a device fault, a killed process group) the arrival counters of the split-K fix-up may be left non-zero, and every
+// later split launch on that stream would then combine the wrong number of partials.  This re-zeroes the stream's block (stream-ordered).  Also the
+// documented constraint of graphs: the counters' address is baked into a captured launch, so a graph must replay on the stream it was captured on
+// (GraphPipeline does) -- replaying it elsewhere would race with eager split launches on the capture stream.
+PSAM_API int32_t psam_gemm_f16x3p_reset_splitk_state(hipStream_t stream) {
+    int* c = f16x3p_sk_counters(stream);
+    if (!c) return PSAM_OK;      // no block yet (or the stream is capturing: nothing to reset)
+    PSAM_REQUIRE(hipMemsetAsync(c, 0, SK_MAX_TILES * sizeof(int), stream) == hipSuccess, PSAM_EINVAL, "psam_gemm_f16x3p_reset_splitk_state: memset failed");
+    return PSAM_OK;
+}
+
 // Split-K factor for a shape (1: none).  A launch whose tiles cover less than half of the CUs (M = 512 rows of one cloud: 44 tiles of
 // 128x128 for the N = 1408 GEMMs of the giant encoder) leaves the rest of the chip idle for a K loop of up to 192 slabs; `ks` workgroups
 // per tile share the slabs (>= 8 each) and psam_gemm_f16x3p_ex adds the partial planes in a fixed order (deterministic).
@@ -670,7 +717,10 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     p.ln_mean = p.ln_rstd = p.ln_c = nullptr;
     p.gmax_out = nullptr; p.gmax_ld = 0; p.gmax_k = 0; p.no_store = 0;
     p.row_ln_g = p.row_ln_b = nullptr; p.row_ln_eps = 0.f; p.hyper = nullptr; p.masks = nullptr; p.hyper_c = 0; p.hyper_rows = 1; p.hyper_pstride = 0; p.epi_abl = 0;
-    p.ksplit = 1; p.plane = 0; p.sk_part = nullptr; p.sk_count = nullptr;
+    p.ksplit = 1; p.plane = 0; p.sk_part = nullptr; p.sk_count = nullptr; p.dbg = nullptr;
+#ifdef PSAM_GEMM_ABLATE
+    p.dbg = g_f16x3p_dbg;
+#endif
     int cfg = g_f16x3p_cfg;
     if (cfg < 0) cfg = f16x3p_pick(M, N, K, act, false);
     if (fuse && fuse->splitk > 1) {
@@ -723,6 +773,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         // M, so that a cloud's logits do not depend on how many clouds share the launch (tests/test_gpu_e2e.py::test_properties_full_size).
         if (g_f16x3p_cfg < 0 && f16x3p_use_register_epilogue(p)) cfg = 21;
         else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
+#ifdef PSAM_BUILD_EXPERIMENTS
     } else if (fuse && fuse->row_ln_g && N == 512) {
         // full-row tile 128x512 on the ping-pong kernel with the register epilogue: Linear (+ row bias per group) -> LayerNorm -> activation -> packed rows
         PSAM_REQUIRE(f16x3p_epilogue_mode() > 0, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm over N == 512 needs the register epilogue (psam_gemm_f16x3p_force_epilogue)");
@@ -737,6 +788,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         p.row_ln_g = fuse->row_ln_g; p.row_ln_b = fuse->row_ln_b; p.row_ln_eps = fuse->row_ln_eps;
         p.pack_out = fuse->pack_out; p.out_scale = fuse->out_scale; p.out_k1 = 0.f; p.out_k2 = fuse->out_k2;
         return launch_f16x3pp(70, p, stream);
+#endif
     } else if (fuse && (fuse->row_ln_g || fuse->hyper)) {
         // full-row epilogues: a wave owns whole rows of N == 256 columns (128x256 tiles, four waves of 32 rows)
         PSAM_REQUIRE(N == 256 && (M & 127) == 0 && act != 3, PSAM_EINVAL, "psam_gemm_f16x3p_ex: row LayerNorm / hyper products need N == 256, M % 128 == 0");
@@ -789,6 +841,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
             if (pp >= 0 && shape_ok && f16x3pp_supports(pp, act, w_stats, w_gmax, w_hyper)) cfg = pp;
         }
     }
+#ifdef PSAM_BUILD_EXPERIMENTS
     {   // unit-ring kernel (gemm_f16x3q.hip): a forced configuration 80 .., or the environment's choice for the large encoder GEMMs
         int q = (g_f16x3p_cfg >= 80 && g_f16x3p_cfg < 90) ? g_f16x3p_cfg : 0;
         if (!q && g_f16x3p_cfg < 0) {
@@ -797,8 +850,23 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
             if (envq >= 80 && M >= 2048 && N >= 1024 && K >= 512) q = (envq == 84 && (act == 3 || N % 192 != 0)) ? 80 : envq;
         }
         if (q && f16x3q_supports(q, p)) return launch_f16x3q(q, p, stream);
-        if (cfg >= 80 && cfg < 90) cfg = f16x3p_pick(M, N, K, act, true);
     }
+#endif
+    if (cfg >= 80 && cfg < 90) cfg = f16x3p_pick(M, N, K, act, true);      // (unit-ring configurations: experiments builds only)
+#ifdef PSAM_GEMM_ABLATE
+    if (cfg >= 3000 && cfg < 3100) {   // 3000 + ablation bits: the PRODUCTION instance (128x128, four waves, mid-slab release, register epilogue); 64 = timing
+        switch (cfg - 3000) {
+            case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2, 1>(p, stream);
+            case 64: return launch_f16x3p<2, 2, 2, 2, 2, 0, 64, 2, 1>(p, stream);
+            case 1: return launch_f16x3p<2, 2, 2, 2, 2, 0, 1, 2, 1>(p, stream);
+            case 2: return launch_f16x3p<2, 2, 2, 2, 2, 0, 2, 2, 1>(p, stream);
+            case 4: return launch_f16x3p<2, 2, 2, 2, 2, 0, 4, 2, 1>(p, stream);
+            case 5: return launch_f16x3p<2, 2, 2, 2, 2, 0, 5, 2, 1>(p, stream);
+            case 19: return launch_f16x3p<2, 2, 2, 2, 2, 0, 19, 2, 1>(p, stream);
+            default: break;
+        }
+    }
+#endif
     if (cfg >= 50 && (cfg < 100 || cfg >= 200)) return launch_f16x3pp(cfg, p, stream);
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 100) {   // 100 + 32 * which + ablation bits; which: 0 = 128x128 4 waves S2, 1 = 256x128 8 waves S3, 2 = 256x192 S2, 3 = 256x256 S2

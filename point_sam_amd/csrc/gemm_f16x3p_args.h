@@ -28,7 +28,15 @@ struct F16PArgs {
     float* sk_part; int* sk_count;    // split-K with the in-kernel fix-up: raw accumulator tiles [tile][split] and one arrival counter per tile (zero between launches);
                                       // the LAST workgroup of a tile adds the ksplit partials in split order and runs the whole epilogue on the sum
     int epi_abl;      // measurement builds (-DPSAM_GEMM_ABLATE): parts of the epilogue switched off (gemm_epilogue.h)
+    unsigned* dbg;    // measurement builds, ABL & 64: 16 words per wave (cycle budget of the K loop, gemm_f16x3p.hip); null otherwise
 };
+
+// s_memtime + the wait for it in ONE statement (hipcc does not count an asm SMEM operation; the stamps sit where no DS read is outstanding)
+__device__ __forceinline__ unsigned long long gemm_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t)::"memory");
+    return t;
+}
 
 #define P_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
 // LDS-DMA of 16 bytes per lane: LDS[dst + lane * 16] = buffer[voff(lane) + soff].  The builtin exists only in the device compilation

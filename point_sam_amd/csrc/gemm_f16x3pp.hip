@@ -32,8 +32,10 @@
 
 // ABL (measurement builds, -DPSAM_GEMM_ABLATE): 1 = no epilogue, 2 = no DMA after the prologue, 4 = no MFMA, 16 = no fragment reads after
 // the first phase.
-template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0, int TR = 0>
-__global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
+// OCC: waves per SIMD the register allocation must admit (2 = one 8-wave workgroup per CU, up to 256 registers; 4 = TWO workgroups per CU, 128 registers:
+// the 64x64 wave tile with single-step phases -- 64 accumulator + 32 fragment registers -- on a ring of three units (72 KiB)).
+template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0, int TR = 0, int OCC = 2>
+__global__ __launch_bounds__(512, OCC) void gemm_f16x3pp_kernel(const F16PArgs p) {
     static_assert(GWM * WN == 4, "four waves per group");
     static_assert((P == 1 || P == 2) && S >= 2 * P && S - 2 * P <= 4, "phase = one or two k16 steps; ring of at least two phases");
     constexpr int BM = 2 * GWM * TM * 32, BN = WN * TN * 32;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
     // the epilogue's operands (per-row inverse A scales / folded-LayerNorm statistics, the lane's column constants): loaded here, consumed
     // after the K loop
     // (not with two-step phases of the 128x64 wave tile: 128 accumulator + 96 fragment registers leave no room for them through the loop)
-    constexpr bool PREFETCH_EPI = !(P == 2 && TM * TN >= 8) && !CHUNKED && !TR;
+    constexpr bool PREFETCH_EPI = !(P == 2 && TM * TN >= 8) && !CHUNKED && !TR && OCC <= 2;
     EpPre<TM> epre;
     if constexpr (PREFETCH_EPI) epre = gemm_epilogue_prefetch<TM, TN, true, true>(p, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.C, p.residual);
     pf16x8 fa[P][TM][2], fw[P][TN][2];
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3pp_kernel(const F16PArgs p) {
 #undef PP_WAITV
 }
 
-template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0, int TR = 0>
+template <int GWM, int WN, int TM, int TN, int S, int P, int PRIO, int ABL = 0, int TR = 0, int OCC = 2>
 static int32_t launch_pp(F16PArgs& p, hipStream_t stream) {
     constexpr int BM = 2 * GWM * TM * 32, BN = WN * TN * 32;
     constexpr int ring = S * (BM + BN) * 64, epi = 8 * (TN > 4 ? gemm_epilogue_lds_floats_per_wave<2>() : gemm_epilogue_lds_floats_per_wave<TN>()) * 4;
@@ -277,11 +279,11 @@ static int32_t launch_pp(F16PArgs& p, hipStream_t stream) {
     p.tiles_n = (int)psam_cdiv(p.N, BN);
     p.panel = f16x3p_panel(p.tiles_m, p.tiles_n, BM, BN, p.K);
     static unsigned long long attr_done = 0;
-    if (!f16x3p_reserve_lds(&gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL, TR>, lds, attr_done)) {
+    if (!f16x3p_reserve_lds(&gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL, TR, OCC>, lds, attr_done)) {
         psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
         return PSAM_EINVAL;
     }
-    hipLaunchKernelGGL((gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL, TR>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16x3pp_kernel<GWM, WN, TM, TN, S, P, PRIO, ABL, TR, OCC>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, stream, p);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 
@@ -292,7 +294,7 @@ bool f16x3pp_supports(int cfg, int act, bool stats, bool gmax, bool hyper) {
     switch (cfg) {
         case 50: case 51: case 52: case 59: case 60: case 61: tm = 4; tn = 2; break;
         case 53: tm = 2; tn = 4; break;
-        case 55: case 56: tm = 2; tn = 2; break;
+        case 55: case 56: case 65: case 66: case 67: tm = 2; tn = 2; break;
         case 57: case 58: tm = 1; tn = 2; break;
         case 62: case 63: case 64: tm = 1; tn = 2; break;      // wide wave tiles run the two-tile epilogue chunk by chunk (odd widths: no SwiGLU, checked at launch)
         default: return false;
@@ -334,6 +336,13 @@ int f16x3pp_pick(int M, int N, int K, int act) {
         }
         return best;
     }
+    if (mode >= 5 && mode <= 8) {
+        // round 5: two ping-pong workgroups per CU.  5 = the wide encoder GEMMs (qkv, fc1: N >= 2048) on 256x128 tiles (cfg 65); 6 = the narrow ones (proj,
+        // fc2) on the 128x128 two-per-CU tile (cfg 58) as well; 7 = as 5 with priority around the MFMAs (cfg 66); 8 = as 5 on 128x256 tiles (cfg 67)
+        if (M < 2048 || (M & 255) || (N & 255)) return -1;
+        if (N >= 2048) return mode == 7 ? 66 : (mode == 8 ? 67 : 65);
+        return mode == 6 ? 58 : -1;
+    }
     if (M >= 2048 && (M & 255) == 0 && (N & 127) == 0) {
         if (act == 3) return 55;                                                     // fc1 (SwiGLU): 256x128 tiles
         if (mode == 3) return (N & 255) == 0 ? 51 : 55;
@@ -360,6 +369,16 @@ int32_t launch_f16x3pp(int cfg, F16PArgs& p, hipStream_t stream) {
 #undef PP_ABL
     }
 #endif
+#ifdef PSAM_PP_ONLY      // probe builds (scripts/kernel_resources.py -DPSAM_PP_ONLY=65 -save-temps): one configuration, seconds to compile
+    if (cfg == PSAM_PP_ONLY) {
+        switch (PSAM_PP_ONLY) {
+            case 65: return launch_pp<2, 2, 2, 2, 3, 1, 0, 0, 0, 4>(p, stream);
+            case 58: return launch_pp<2, 2, 1, 2, 4, 2, 1>(p, stream);
+            default: break;
+        }
+    }
+    return PSAM_EINVAL;
+#else
     switch (cfg) {
         case 50: return launch_pp<1, 4, 4, 2, 5, 1, 1>(p, stream);      // 256x256, waves of 128x64, 5 units (160 KiB), priority around the MFMAs
         case 51: return f16x3p_use_register_epilogue(p) ? launch_pp<1, 4, 4, 2, 5, 1, 0, 0, 1>(p, stream) : launch_pp<1, 4, 4, 2, 5, 1, 0>(p, stream);      //   no priority changes
@@ -374,13 +393,20 @@ int32_t launch_f16x3pp(int cfg, F16PArgs& p, hipStream_t stream) {
         case 57: return f16x3p_use_register_epilogue(p) ? launch_pp<2, 2, 1, 2, 8, 2, 1, 0, 1>(p, stream)
                                                         : launch_pp<2, 2, 1, 2, 8, 2, 1>(p, stream);      // 128x128, waves of 32x64, 8 units (128 KiB), two-step phases (12 MFMAs)
         case 58: return launch_pp<2, 2, 1, 2, 4, 2, 1>(p, stream);      //   4 units (64 KiB): two workgroups per CU
+        // round 5: TWO ping-pong workgroups per CU (72 KiB, 128 registers): four waves per SIMD, two of them in a compute interval at any time
+        case 65: return launch_pp<2, 2, 2, 2, 3, 1, 0, 0, 0, 4>(p, stream);      // 256x128, waves of 64x64, 3 units, one-step phases (12 MFMAs)
+        case 66: return launch_pp<2, 2, 2, 2, 3, 1, 1, 0, 0, 4>(p, stream);      //   priority around the MFMAs
+        case 67: return launch_pp<1, 4, 2, 2, 3, 1, 0, 0, 0, 4>(p, stream);      // 128x256, waves of 64x64
         // right-sized tiles (round 4): eight waves of 32 rows x the whole tile width, so that a launch's tiles fill #CU - 8 workgroup slots in whole rounds
         case 62: return launch_pp<4, 1, 1, 7, 5, 1, 1>(p, stream);      // 256x224 (150 KiB): qkv 4096x3072 = 224 tiles, one round
         case 63: return launch_pp<4, 1, 1, 6, 5, 1, 1>(p, stream);      // 256x192 (140 KiB): fc1 4096x5504 = 464 tiles, two rounds
         case 64: return launch_pp<4, 1, 1, 8, 5, 1, 1>(p, stream);      // 256x256 with the same wave layout (160 KiB)
+#ifdef PSAM_BUILD_EXPERIMENTS
         case 70: return launch_pp<1, 4, 2, 4, 3, 1, 1, 0, 2>(p, stream);      // 128x512 full-row tile, waves of 64x128, 3 units (120 KiB): row LayerNorm epilogue (N == 512)
+#endif
         default: break;
     }
     psam_set_error("psam_gemm_f16x3p: unknown ping-pong config");
     return PSAM_EINVAL;
+#endif
 }

@@ -269,7 +269,7 @@ class PointCloudSAM:
         # group sizes 32 / 64: the GEMM epilogues pool whole groups; multiples of 64 (cfg #3: 256): they pool 64-row parts, a small pass pools the parts
         fused = (self.precision == "f16x3" and self.fuse_patch and (K in (32, 64) or K % 64 == 0) and ops.fuse_supported(rows, 128) and prefix in self.pe_bound
                  and all((prefix + n) in self.fw for n in (".conv1.3.weight", ".conv2.0.weight#x", ".conv2.3.weight")))
-        if fused and self.c_blocks and prefix in getattr(self, "c_patch", {}) and ops.GEMM_MODE == "f16x3":
+        if fused and self.c_blocks and prefix in getattr(self, "c_patch", {}) and ops.current_gemm_mode() == "f16x3":
             return self.c_patch[prefix].run(coords, feats, centers, knn_idx, radius=radius, center_idx=center_idx)      # psam_patch_encoder: the same six launches
         if fused:
             # every hand-over stays in the GEMMs' packed form and both max-pools happen in GEMM epilogues: the [rows, 128] / [rows, 512]
@@ -329,7 +329,7 @@ class PointCloudSAM:
         # the scale and (when the float4 LN path applies) the packed planes directly, so the GEMM does no split arithmetic for A
         f16 = self.precision == "f16x3"
         if (f16 and self.c_blocks and hasattr(blk, "c_block") and self.fuse_mlp and self.fuse_attn_pack and self.fuse_attn_operands
-                and self.row_bounds and ops.GEMM_MODE == "f16x3" and x.is_contiguous()
+                and self.row_bounds and ops.current_gemm_mode() == "f16x3" and x.is_contiguous()
                 and (x.shape[0] % 256 == 0 if vit.swiglu else x.shape[0] >= ops.SPLIT_MIN_M)):
             return blk.c_block.run(x, B, L)
         pk = f16 and x.shape[0] >= ops.SPLIT_MIN_M and isinstance(blk.wqkv, ops.F16Weight) and ops.layernorm_can_pack(D)
@@ -491,7 +491,7 @@ class PointCloudSAM:
         """TwoWayTransformer.forward (transformer.py:61-100).  src [Z*G,E] (overwritten), pos [B,G,E], tokens [Z*T,E]."""
         cfg, E, eps = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps
         P = "mask_decoder.transformer"
-        if self.c_blocks and getattr(self, "c_twoway", None) is not None and ops.GEMM_MODE == "f16x3" and not self.fuse_tokens:
+        if self.c_blocks and getattr(self, "c_twoway", None) is not None and ops.current_gemm_mode() == "f16x3" and not self.fuse_tokens:
             return self.c_twoway.run(tokens, src, pos, rep, Z, T, G)      # psam_twoway_decoder: the same launches, sequenced by the library
         if self.fuse_tokens and ops.TwoWayLayerWeights.supported(E, self.w[P + ".layers.0.cross_attn_token_to_image.q_proj.weight"].shape[0], cfg.dec_heads, Z, T, G):
             return self._two_way_fused(src, pos, tokens, Z, G, T, rep)
@@ -548,7 +548,7 @@ class PointCloudSAM:
         U0, U3 = "mask_decoder.output_upscaling.0", "mask_decoder.output_upscaling.3"
         packed_interp = self.precision == "f16x3" and self.fuse_upscale and E == 256 and Z * N >= ops.SPLIT_MIN_M and (U0 + ".weight") in self.fw
         if (self.upscale_linear_first and E == 256 and self.c_blocks and getattr(self, "c_upscale", None) is not None and packed_interp and self.fuse_hyper
-                and (U3 + ".weight") in self.fw and (Z * N) % 256 == 0 and N % 32 == 0 and C <= 4 and ops.GEMM_MODE == "f16x3" and keys.is_contiguous()):
+                and (U3 + ".weight") in self.fw and (Z * N) % 256 == 0 and N % 32 == 0 and C <= 4 and ops.current_gemm_mode() == "f16x3" and keys.is_contiguous()):
             self.c_upscale.run(keys.view(Z * G, E), st.interp_index, st.interp_weight, hyper, masks, rep, Z, N, G, C)      # psam_upscale_masks: the same launches
             return masks, sel
         if self.upscale_linear_first and E == 256:

@@ -60,6 +60,20 @@ def __getattr__(name):
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
+class _OpsModule(__import__("types").ModuleType):
+    """`ops.GEMM_MODE = ...` (the pre-round-4 interface) would create a real module attribute that shadows __getattr__ for good: every later read of
+    ops.GEMM_MODE would then return that stale value while the launches follow the context variable.  Assignment is refused; use `with ops.gemm_mode(m):`."""
+
+    def __setattr__(self, name, value):
+        if name == "GEMM_MODE":
+            raise AttributeError("ops.GEMM_MODE is read-only (it reflects a context variable): use `with ops.gemm_mode(mode):`")
+        super().__setattr__(name, value)
+
+
+import sys as _sys
+_sys.modules[__name__].__class__ = _OpsModule
+
+
 # Key split of the fp16-pipe attention for single-cloud shapes (csrc/attention.hip, psam_attention_f16x3_ex2): 4 = up to four workgroups per
 # (query block, head), combined in the kernel -- the latency of ONE stream of work; 1 = off, what the multi-stream pipelines use (their other streams
 # fill the idle CUs and the split's extra work costs throughput: 133 -> 129 sessions/s at cfg #5, while the encoder latency drops 8.7 -> 8.1 ms).
@@ -660,8 +674,11 @@ class EvaGeluBlock:
         need = int(lib.psam_eva_gelu_block_ws_bytes(M, self.dim, self.hidden))
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        self.plan.attn_keysplit = current_attention_keysplit()
-        check(lib.psam_eva_gelu_block(ctypes.byref(self.plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), _stream()), "psam_eva_gelu_block")
+        # the key-split cap is per CONTEXT (a latency caller next to a multi-stream pipeline on the same model): a private copy of the plan (a small
+        # POD the library reads during the call only) carries it; the shared plan is never written after _prepare
+        plan = _lib.EvaGeluBlockPlan.from_buffer_copy(self.plan)
+        plan.attn_keysplit = current_attention_keysplit()
+        check(lib.psam_eva_gelu_block(ctypes.byref(plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), _stream()), "psam_eva_gelu_block")
         return x
 
 
@@ -827,7 +844,13 @@ class TwoWayLayerWeights:
         return E == 256 and inner_cross == 128 and heads in (1, 2, 4, 8, 16, 32) and Z * T <= 64 and max(T, G) <= 4096
 
 
+def _need_experiments(what: str):
+    if not _lib.has_experiments():
+        raise _lib.PointSamHipError(f"{what} is a measured-and-rejected path: build the library with PSAM_BUILD_EXPERIMENTS=1 (python -m point_sam_amd.build)")
+
+
 def twoway_tokens_ws(mlp: int, device) -> torch.Tensor:
+    _need_experiments("psam_twoway_tokens")
     return torch.empty(int(_lib.load().psam_twoway_tokens_ws_floats(int(mlp))), dtype=torch.float32, device=device)
 
 
@@ -836,6 +859,7 @@ def twoway_tokens(lw: TwoWayLayerWeights, queries, pe, kimg, vimg, Z, T, G, head
     token embeddings (query_pe); kimg / vimg [Z*G, 128] row views of the patch tokens' k / v projections; ktok / vtok [Z*T, 128] receive the
     k / v projections for the image -> token attention (not for the final attention)."""
     import ctypes
+    _need_experiments("psam_twoway_tokens")
     a = lw.args
     _chk(queries, name="queries"); _chk(pe, name="pe")
     kp, ldk = _row_view(kimg, "kimg"); vp, ldv = _row_view(vimg, "vimg")

@@ -40,6 +40,10 @@ def _check(res, world, steps, warmup, sustained, batch):
     pr = res["per_rank"]
     assert [r["rank"] for r in pr["ranks"]] == list(range(world)) and all(r["value"] > 0 and r["ms_per_step"] > 0 for r in pr["ranks"])
     assert pr["min_value"] <= pr["max_value"] and abs(pr["min_value"] * world - res["value"]) <= 1e-2 * res["value"]
+    # every rank reports what it spent before its first step (the stub's stand-in: 1 ms x (rank + 1)), gathered in rank order
+    su = res["startup_s"]
+    assert len(su["per_rank"]) == world and [round(x["total_s"] * 1e3) for x in su["per_rank"]] == list(range(1, world + 1))
+    assert su["max_total_s"] == pytest.approx(1e-3 * world)
 
 
 def test_bench_self_spawns_two_ranks():
@@ -54,6 +58,15 @@ def test_bench_under_torch_distributed_run():
     res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                 "bench.py", "--gpus", "2", "--stub", "--steps", "5", "--warmup", "1", "--sustained-steps", "4", "--batch", "2", "--slots", "2"])
     _check(res, 2, 5, 1, 4, 2)
+
+
+def test_bench_eight_ranks_end_to_end():
+    """BASELINE config #4's launch shape (`bench.py --gpus 8`, what the driver runs on an 8-GPU node) through the REAL file on CPU / gloo: eight
+    self-spawned ranks, every step's gathered results complete and in rank order, eight distinct ranks in the collective, per-rank fields for
+    all eight, one JSON line."""
+    res = _run([sys.executable, "bench.py", "--gpus", "8", "--stub", "--steps", "4", "--warmup", "1", "--sustained-steps", "2", "--batch", "2"])
+    _check(res, 8, 4, 1, 2, 2)
+    assert res["rccl"]["ranks_seen"] == 8 and res["config"]["global_batch"] == 16
 
 
 def test_bench_single_rank_stub():
