@@ -75,7 +75,7 @@ def parse_args(argv=None):
                     help="with the default workload on one GPU: BASELINE configurations run as short extra legs after the main measurement and reported under "
                          "`other_workloads` (value, ms_per_step, roofline.frac, parity, a one-run cpu_baseline); '' or --no-other-workloads skips them")
     ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_const", const="")
-    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each extra leg")
+    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each extra leg (after 3 warm-ups, as a default run of that workload)")
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "ply"],
                     help="synthetic: uniform clouds in the unit ball; ply: the reference's six demo clouds tiled / jittered to N points (SURVEY.md 8(d))")
     args = ap.parse_args(argv)
@@ -595,10 +595,10 @@ def worker(args):
 
 
 def other_leg(name, base, local):
-    """One BASELINE configuration as a short leg: `--other-steps` timed passes after 2 warm-ups through the same pipeline classes as the main run,
+    """One BASELINE configuration as a short leg: `--other-steps` timed passes after 3 warm-ups through the same pipeline classes as the main run,
     the dominant GEMM's roofline fraction from sampled launches, the output of the last timed pass against the oracle (all clouds of the leg's
     batch) and ONE oracle run timed as the CPU baseline."""
-    argv = ["--workload", name, "--steps", str(base.other_steps), "--warmup", "2", "--precision", base.precision, "--streams", str(base.streams),
+    argv = ["--workload", name, "--steps", str(base.other_steps), "--warmup", "3", "--precision", base.precision, "--streams", str(base.streams),
             "--slots", str(base.slots), "--sustained-steps", "0"]
     if not base.graphs:
         argv.append("--no-graphs")
@@ -627,6 +627,8 @@ def other_leg(name, base, local):
     el = time.perf_counter() - t0
     H.finalize()
     keep = (out[0].clone(), out[1].clone())
+    if not (bool(torch.isfinite(keep[0]).all()) and bool(torch.isfinite(keep[1]).all())):
+        raise SystemExit(f"other_workloads[{name}]: non-finite output")
     leg = {"workload": f"{name}: ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={a.batch} "
                        + (f"{a.clicks}-click session (encoder cached)" if a.clicks > 1 else "1 point prompt multimask"),
            "value": round(a.batch * a.steps / el, 3), "unit": "sessions/s" if a.clicks > 1 else "point-clouds/s", "ms_per_step": round(el / a.steps * 1e3, 3),

@@ -26,6 +26,7 @@ SOURCES = [
     ("gemm_split.hip", []),
     ("gemm_f16x3p.hip", []),
     ("gemm_f16x3pp.hip", []),
+    ("gemm_f16x3s.hip", []),
     ("attention.hip", []),
     ("rowops.hip", []),
     ("blocks.hip", []),

@@ -59,7 +59,9 @@ __device__ __forceinline__ float ept_segment_sum(float s0, float s1, float s2, f
 }
 
 // F >= 0: the option set of the launch as EP_* bits (gemm_epilogue.h), every option test folds at compile time; F < 0: run-time tests.
-template <int TM, int TN, int F, typename ArgsT>
+// FENCE = false (the persistent kernel's 64-accumulator wave tile, which has the registers): no scheduling fences between the tiles -- the scheduler
+// may issue every tile's constant and residual loads at the top, one memory latency for the whole epilogue instead of one per tile.
+template <int TM, int TN, int F, typename ArgsT, bool FENCE = true>
 __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16 (&acc)[TM][TN], int row_base, int col_base, int lane, float* __restrict__ C,
                                                        const float* __restrict__ R, bool interior) {
 #pragma clang fp contract(off)
@@ -130,7 +132,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
     for (int j0 = 0; j0 < TN; ++j0) {
         if (swiglu && (j0 & 1)) continue;
         const int j = j0;
-        ept_fence();
+        if (FENCE) ept_fence();
         const int pcol = col_base + j * 32 + 4 * h;                 // run g starts at pcol + 8 g
         const int ocol = swiglu ? (col_base >> 1) + (j >> 1) * 32 + 4 * h : pcol;
         // column constants of the tile (and of its partner tile when gated)
@@ -152,7 +154,7 @@ __device__ __forceinline__ void gemm_store_tile_t_impl(const ArgsT& p, ep_f32x16
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (i > 0) ept_fence();
+            if (FENCE && i > 0) ept_fence();
             const int row = row_base + i * 32 + r32;
             ep_f32x4 res[4];
             if (o_res) {

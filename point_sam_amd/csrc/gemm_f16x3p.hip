@@ -477,6 +477,16 @@ PSAM_API int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const 
 // ---------------------------------------------------------------------------------------------- host
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
+// Persistent stream-K form of the 128x128 register-epilogue configuration (gemm_f16x3s.hip) for batch-sized launches: -1 = default (environment
+// PSAM_GEMM_STREAMK, else on), 0 = never, 1 = wherever it applies.
+static int g_f16x3p_streamk = -1;
+PSAM_API void psam_gemm_f16x3p_force_streamk(int32_t mode) { g_f16x3p_streamk = mode; }
+static bool f16x3p_streamk_enabled() {
+    if (g_f16x3p_streamk >= 0) return g_f16x3p_streamk != 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_GEMM_STREAMK"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
 #ifdef PSAM_GEMM_ABLATE
 static unsigned* g_f16x3p_dbg = nullptr;      // measurement builds: 16 words per wave of the timing instances (ABL & 64)
 extern "C" __attribute__((visibility("default"))) void psam_gemm_f16x3p_set_timing_buffer(void* buf) { g_f16x3p_dbg = (unsigned*)buf; }
@@ -644,6 +654,7 @@ static int* f16x3p_sk_counters(hipStream_t stream) {
 // documented constraint of graphs: the counters' address is baked into a captured launch, so a graph must replay on the stream it was captured on
 // (GraphPipeline does) -- replaying it elsewhere would race with eager split launches on the capture stream.
 PSAM_API int32_t psam_gemm_f16x3p_reset_splitk_state(hipStream_t stream) {
+    f16x3s_reset_state(stream);
     int* c = f16x3p_sk_counters(stream);
     if (!c) return PSAM_OK;      // no block yet (or the stream is capturing: nothing to reset)
     PSAM_REQUIRE(hipMemsetAsync(c, 0, SK_MAX_TILES * sizeof(int), stream) == hipSuccess, PSAM_EINVAL, "psam_gemm_f16x3p_reset_splitk_state: memset failed");
@@ -881,6 +892,13 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
 #undef ABL_CASE
     }
 #endif
+    // persistent stream-K form of cfg 21 (gemm_f16x3s.hip): a forced configuration 90, or -- PSAM_GEMM_STREAMK, default on -- the batch-sized launches
+    // (M >= 2048) that cfg 21 with the register epilogue would take
+    if (cfg == 90 || (cfg == 21 && g_f16x3p_cfg < 0 && M >= 2048 && f16x3p_streamk_enabled())) {
+        int32_t rc = PSAM_OK;
+        if (f16x3p_use_register_epilogue(p) && launch_f16x3s(p, stream, rc)) return rc;
+        if (cfg == 90) cfg = 21;
+    }
     switch (cfg) {   // the configurations that won somewhere in the sweeps (profiles/r02_gemm_p_sweep_*.log); numbering kept from the sweeps
         case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);            // 128x128, 4 waves of 64x64, 2 stages (64 KiB): 2 workgroups per CU
         case 4: return launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream);            // 256x128, 8 waves, 3 stages (144 KiB)

@@ -839,7 +839,13 @@ class GraphPipeline:
         """session=True: prompt_coords [B, T, 3] / prompt_labels [B, T] are the T clicks of an interactive session; the dense graph is encode +
         PointCloudSAM.click_session (T decodes on the cached state) and next() returns the LAST click's (masks, iou)."""
         from collections import deque
-        self.model, self.depth, self.count = model, max(1, slots), 0
+        # A slot's dense graph is captured on ONE dense stream and must replay there: kernels with in-kernel fix-ups (split-K / stream-K GEMMs, key-split
+        # attention) use arrival counters that belong to the (device, stream) they were captured on, and two graphs sharing a counter block must never run
+        # concurrently.  Slot s is therefore bound to stream s % streams, and the number of slots is a multiple of the number of streams, so that
+        # consecutive batches always alternate streams.  (Until round 5 the replay stream was `count % streams`: with 3 slots on 2 streams every third
+        # batch replayed beside a graph holding the same counters -- garbage partial sums whenever two split launches overlapped.)
+        nstreams = max(1, min(dense_streams, max(1, slots)))
+        self.model, self.depth, self.count = model, (max(1, slots) + nstreams - 1) // nstreams * nstreams, 0
         self.session = bool(session)
         if session and prompt_masks is not None:
             raise ValueError("GraphPipeline(session=True) feeds each click's best mask forward itself: prompt_masks must be None")
@@ -848,7 +854,7 @@ class GraphPipeline:
         self.queue = deque()
         dev = model.device
         self.tok_stream = torch.cuda.Stream(device=dev, priority=-1)
-        self.dense = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(dense_streams, self.depth)))]
+        self.dense = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
         self.multimask = multimask_output
         conv = lambda t, dt: None if t is None else t.to(dev, dt).contiguous().clone()
         self.slots = []
@@ -856,7 +862,7 @@ class GraphPipeline:
         for s in range(self.depth):
             st = SimpleNamespace(coords=conv(coords, torch.float32), features=conv(features, torch.float32), pc=conv(prompt_coords, torch.float32),
                                  pl=conv(prompt_labels, torch.int64), pm=conv(prompt_masks, torch.float32))
-            ds = self.dense[s % len(self.dense)]
+            ds = st.ds = self.dense[s % len(self.dense)]
             st.busy = False
             # one eager pass first: every kernel's one-time set-up (LDS attributes, library loading) must not happen inside a capture
             self.tok_stream.wait_stream(main); ds.wait_stream(main)
@@ -899,7 +905,7 @@ class GraphPipeline:
                 raise ValueError(f"GraphPipeline: {name} has shape {tuple(src.shape)}, the graphs were captured for {tuple(dst.shape)}")
         if st.busy:
             raise RuntimeError("GraphPipeline: the slot's previous batch has not been taken with next() yet (at most `slots` batches in flight)")
-        ds = self.dense[self.count % len(self.dense)]
+        ds = st.ds      # the stream the slot's dense graph was captured on
         self.count += 1
         st.busy = True
         main = torch.cuda.current_stream(self.model.device)

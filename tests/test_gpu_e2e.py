@@ -776,6 +776,36 @@ def test_evaluation_harness(gpu):
     assert np.allclose(res["per_cloud"], np.array(want), atol=2e-3), (res["per_cloud"], want)
 
 
+def test_graph_pipeline_with_in_kernel_fixups_matches_eager(gpu):
+    """Graphs whose kernels carry per-stream fix-up state -- the split-K GEMMs and the key-split attention of a single cloud through the giant
+    encoder's width (arrival counters per (device, stream), csrc/gemm_f16x3p.hip / attention.hip) -- replayed with more slots than dense streams: every
+    step's result must be the eager path's bits.  (Until round 5 a slot's graph could replay on another stream than it was captured on; two graphs
+    holding the same counters then ran concurrently and a tile could be combined before all of its parts had arrived.)"""
+    from point_sam_amd.model import GraphPipeline
+    cfg = _giant_slim()
+    model = gpu(cfg, random_state_dict(cfg, 14), precision="f16x3")
+    batches = []
+    for i in range(14):
+        xyz, rgb, prompt, labels = O.synthetic_batch(1, 4096, seed=60 + i)
+        batches.append(tuple(t.cuda() for t in (xyz, rgb, prompt, labels)))
+    from point_sam_amd import ops
+    with ops.attention_keysplit(1):      # what the multi-stream pipelines run with
+        want = [model.predict_masks(*b) for b in batches]
+    pipe = GraphPipeline(model, *batches[0], None, True, slots=3, dense_streams=2)
+    assert pipe.depth % len(pipe.dense) == 0 and all(st.ds is pipe.dense[k % len(pipe.dense)] for k, st in enumerate(pipe.slots))
+    got = []
+    for k in range(min(pipe.depth, len(batches))):
+        pipe.submit(*batches[k])
+    for k in range(len(batches)):
+        m, i = pipe.next()
+        got.append((m.clone(), i.clone()))
+        if k + pipe.depth < len(batches):
+            pipe.submit(*batches[k + pipe.depth])
+    torch.cuda.synchronize()
+    for k, ((m1, i1), (m2, i2)) in enumerate(zip(want, got)):
+        assert torch.equal(m1, m2) and torch.equal(i1, i2), (k, _maxerr(m1, m2))
+
+
 def test_graph_pipeline_matches_eager(gpu):
     """The two stages of a batch replayed as captured HIP graphs (GraphPipeline: static buffers, `slots` batches in flight) give
     bit-identical results to the eager path, also when the inputs change from step to step."""
