@@ -864,6 +864,13 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     }
 #endif
     if (cfg >= 80 && cfg < 90) cfg = f16x3p_pick(M, N, K, act, true);      // (unit-ring configurations: experiments builds only)
+    // persistent stream-K form of cfg 21 (gemm_f16x3s.hip): a forced configuration 90 (91 / 92: its measurement variants), or -- PSAM_GEMM_STREAMK,
+    // default on -- the batch-sized launches (M >= 2048) that cfg 21 with the register epilogue would take
+    if ((cfg >= 90 && cfg <= 93) || (cfg == 21 && g_f16x3p_cfg < 0 && M >= 2048 && f16x3p_streamk_enabled())) {
+        int32_t rc = PSAM_OK;
+        if (f16x3p_use_register_epilogue(p) && launch_f16x3s(p, stream, rc, cfg >= 90 ? cfg - 90 : 0)) return rc;
+        if (cfg >= 90) cfg = 21;
+    }
 #ifdef PSAM_GEMM_ABLATE
     if (cfg >= 3000 && cfg < 3100) {   // 3000 + ablation bits: the PRODUCTION instance (128x128, four waves, mid-slab release, register epilogue); 64 = timing
         switch (cfg - 3000) {
@@ -892,13 +899,6 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
 #undef ABL_CASE
     }
 #endif
-    // persistent stream-K form of cfg 21 (gemm_f16x3s.hip): a forced configuration 90, or -- PSAM_GEMM_STREAMK, default on -- the batch-sized launches
-    // (M >= 2048) that cfg 21 with the register epilogue would take
-    if (cfg == 90 || (cfg == 21 && g_f16x3p_cfg < 0 && M >= 2048 && f16x3p_streamk_enabled())) {
-        int32_t rc = PSAM_OK;
-        if (f16x3p_use_register_epilogue(p) && launch_f16x3s(p, stream, rc)) return rc;
-        if (cfg == 90) cfg = 21;
-    }
     switch (cfg) {   // the configurations that won somewhere in the sweeps (profiles/r02_gemm_p_sweep_*.log); numbering kept from the sweeps
         case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);            // 128x128, 4 waves of 64x64, 2 stages (64 KiB): 2 workgroups per CU
         case 4: return launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream);            // 256x128, 8 waves, 3 stages (144 KiB)

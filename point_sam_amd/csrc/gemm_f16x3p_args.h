@@ -91,7 +91,7 @@ bool f16x3pp_supports(int cfg, int act, bool stats, bool gmax, bool hyper);
 int f16x3pp_pick(int M, int N, int K, int act);      // -1: keep the lock-step kernel
 bool f16x3p_use_register_epilogue(const F16PArgs& p);      // gemm_f16x3p.hip: whether this launch may run the register-only epilogue (gemm_epilogue_t.h)
 // gemm_f16x3s.hip: persistent stream-K form of the 128x128 register-epilogue configuration; true = it took the launch (rc = status)
-bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc);
+bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc, int mode = 0);
 void f16x3s_reset_state(hipStream_t stream);
 // gemm_f16x3q.hip: lock-step kernel on a ring of k16 units (cfg 80 ..), register epilogue only
 int32_t launch_f16x3q(int cfg, F16PArgs& p, hipStream_t stream);

@@ -49,29 +49,41 @@ struct F16SArgs {
     int nslabs;        // K / 32
     int units;         // tiles * nslabs
     int per_xcd;       // grid / 8
+    unsigned inv_per_xcd;     // ceil(2^32 / per_xcd), inv_nslabs = ceil(2^32 / nslabs): v / d == umulhi(v, inv_d) for v * d < 2^32 (the host checks the ranges)
+    unsigned inv_nslabs;
+    int whole;         // 1: no tile is split -- workgroup q runs the tiles q, q + grid, ... (persistence and the pipelined prologue only: A/B against the shares)
 };
 
 // first unit of workgroup q (linear order: XCD-major) -- q in [0, grid]; boundaries closer than SK_MINS slabs to a tile boundary snap onto it
-__device__ __forceinline__ int sk_bound(const F16SArgs& a, int q) {
-    const int x = q / a.per_xcd, j = q - x * a.per_xcd;
-    const int lo = (int)((int64_t)x * a.units / 8), hi = (int)((int64_t)(x + 1) * a.units / 8);
-    int u = lo + (int)((int64_t)j * (hi - lo) / a.per_xcd);
-    const int r = u % a.nslabs;
+__device__ __forceinline__ int sk_bound(const F16SArgs& a, int q) {      // multiply-high by precomputed inverses: no division
+    const int x = (int)__umulhi((unsigned)q, a.inv_per_xcd), j = q - x * a.per_xcd;
+    const int lo = (int)(((int64_t)x * a.units) >> 3), hi = (int)(((int64_t)(x + 1) * a.units) >> 3);
+    int u = lo + (int)__umulhi((unsigned)j * (unsigned)(hi - lo), a.inv_per_xcd);
+    const int r = u - (int)__umulhi((unsigned)u, a.inv_nslabs) * a.nslabs;
     if (r < SK_MINS) u -= r;
     else if (a.nslabs - r < SK_MINS) u += a.nslabs - r;
     return u;
 }
 
-template <int F>
+// TIMING (measurement builds, -DPSAM_GEMM_ABLATE): s_memtime stamps per wave -> a.g.dbg, 16 words per wave: cycles in [0] K loops, [1] issuing the next
+// piece's first slabs, [2] parking a part, [3] counting in, [4] combining the parts, [5] epilogues, [6] kernel entry -> first loop; [7] pieces,
+// [8] slabs, [9] tiles finished, [10..13] absolute start / end stamps, [14] HW_ID, [15] XCC_ID.
+template <int F, bool TIMING = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
     const F16PArgs& p = a.g;
+    unsigned tb[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk0 = 0, tq = 0;
+    if (TIMING) tk0 = gemm_now();
+#define SK_STAMP(slot) do { if (TIMING) { const unsigned long long _t = gemm_now(); tb[slot] += (unsigned)(_t - tq); tq = _t; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
     const int q = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);      // this workgroup in the XCD-major order
-    const int u_begin = sk_bound(a, q), u_end = sk_bound(a, q + 1);
+    const int grid = 8 * a.per_xcd;
+    const int u_begin = a.whole ? q * a.nslabs : sk_bound(a, q);
+    const int u_end = a.whole ? (q * a.nslabs < a.units ? a.units : u_begin) : sk_bound(a, q + 1);      // (whole: the end of the last tile; pieces end at tile boundaries)
 
     // fragment offsets inside a stage: row r32 of a 32-row tile, chunk 4 s + 2 h + pl (s = k16 step, pl = hi / lo plane), swizzled as the DMA stores them
     int fa_off[2][2], fw_off[2][2];
@@ -88,10 +100,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
     struct Piece { int tile, s0, s1, m0, n0; };
     auto piece_at = [&](int u) {
         Piece pc;
-        pc.tile = u / a.nslabs;
+        pc.tile = (int)__umulhi((unsigned)u, a.inv_nslabs);
         pc.s0 = u - pc.tile * a.nslabs;
         const int left = u_end - u;
-        pc.s1 = pc.s0 + left < a.nslabs ? pc.s0 + left : a.nslabs;
+        pc.s1 = (!a.whole && pc.s0 + left < a.nslabs) ? pc.s0 + left : a.nslabs;
         const int pfull = p.tiles_m * p.panel, pn = pc.tile / pfull, prem = pc.tile - pn * pfull;
         const int pw = p.tiles_n - pn * p.panel < p.panel ? p.tiles_n - pn * p.panel : p.panel;
         pc.m0 = (prem / pw) * SK_BM;
@@ -176,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
     Piece cur = piece_at(u_begin);
     dma_setup(cur);
     issue_two();
+    if (TIMING) { tq = gemm_now(); tb[6] = (unsigned)(tq - tk0); }
     for (;;) {
         const int n = cur.s1 - cur.s0;
 #pragma unroll
@@ -192,8 +205,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
         body(t, integral_constant<int, SK_NL>{}, integral_constant<bool, false>{});
         body(t + 1, integral_constant<int, 0>{}, integral_constant<bool, false>{});
         // ---- every wave is done with the ring: the next piece's first two slabs go out before this piece's epilogue
-        const int u_next = cur.tile * a.nslabs + cur.s1;
+        const int u_next = a.whole ? (cur.tile + grid) * a.nslabs : cur.tile * a.nslabs + cur.s1;
         const bool more = u_next < u_end;
+        if (TIMING) { tb[7] += 1; tb[8] += (unsigned)(cur.s1 - cur.s0); }
+        SK_STAMP(0);
         const Piece done = cur;
         // (no barrier: after the last slab's mid-slab barrier no wave reads the ring any more -- its step-1 fragments are in registers)
         if (more) {
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
             dma_setup(cur);
             issue_two();
         }
+        SK_STAMP(1);
         // ---- whole tile: the epilogue; part of a tile: park, count in, and the last arrival combines
         bool finish = true;
         if (done.s0 != 0 || done.s1 != a.nslabs) {
@@ -226,12 +242,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
                         }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part is acknowledged by the memory side
+            SK_STAMP(2);
             __syncthreads();
             if (tid == 0) *flag = (int)__hip_atomic_fetch_add(a.count + done.tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const int arrived = *flag;
             __syncthreads();      // (the flag word is rewritten by the next partial piece)
             finish = arrived == nparts - 1;
+            SK_STAMP(3);
             if (finish) {
                 if (tid == 0) __hip_atomic_store(a.count + done.tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -256,11 +274,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3s_kernel(const F16SArgs a) {
                                 for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
                             }
                 }
+                SK_STAMP(4);
             }
         }
-        if (finish) gemm_store_tile_t_impl<2, 2, F, F16PArgs, false>(p, acc, done.m0 + wm * 64, done.n0 + wn * 64, lane, p.C, p.residual, true);
+        if (finish) {
+            gemm_store_tile_t_impl<2, 2, F, F16PArgs, false>(p, acc, done.m0 + wm * 64, done.n0 + wn * 64, lane, p.C, p.residual, true);
+            if (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tb[9] += 1; }
+            SK_STAMP(5);
+        }
         if (!more) break;
     }
+    if (TIMING && p.dbg) {
+        const unsigned long long te = gemm_now();
+        if (lane == 0) {
+            unsigned* d = p.dbg + ((size_t)blockIdx.x * SK_NW + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) d[i] = tb[i];
+            d[10] = (unsigned)tk0; d[11] = (unsigned)(tk0 >> 32); d[12] = (unsigned)te; d[13] = (unsigned)(te >> 32);
+            d[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+            d[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        }
+    }
+#undef SK_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -291,14 +326,17 @@ static SkBlock sk_block(hipStream_t stream, int grid) {
     return b;
 }
 
-template <int F>
+template <int F, bool TIMING = false>
 static int32_t launch_s(const F16SArgs& a, int grid, hipStream_t stream) {
+#ifdef PSAM_GEMM_ABLATE
+    if (!TIMING && a.g.dbg) return launch_s<F, true>(a, grid, stream);      // a timing buffer is set (psam_gemm_f16x3p_set_timing_buffer): the stamped instance
+#endif
     static unsigned long long attr_done = 0;
-    if (!f16x3p_reserve_lds(&gemm_f16x3s_kernel<F>, SK_LDS, attr_done)) {
+    if (!f16x3p_reserve_lds(&gemm_f16x3s_kernel<F, TIMING>, SK_LDS, attr_done)) {
         psam_set_error("psam_gemm_f16x3p: cannot reserve LDS");
         return PSAM_EINVAL;
     }
-    hipLaunchKernelGGL((gemm_f16x3s_kernel<F>), dim3((unsigned)grid), dim3(256), SK_LDS, stream, a);
+    hipLaunchKernelGGL((gemm_f16x3s_kernel<F, TIMING>), dim3((unsigned)grid), dim3(256), SK_LDS, stream, a);
     return psam_launch_status("psam_gemm_f16x3p: launch failed");
 }
 }  // namespace
@@ -310,13 +348,17 @@ static int f16x3s_option_set(const F16PArgs& p) {
     const int opt = (swiglu ? EP_SWIGLU : 0) | ((p.residual && !swiglu) ? EP_RES : 0) | (!swiglu && p.act == 1 ? EP_GELU : 0) | (!swiglu && p.act == 2 ? EP_RELU : 0) |
                     ((swiglu && p.stats) ? EP_STATS : 0) | (p.pack_out ? EP_PACK : 0) | (p.ln_c ? EP_LNC : 0) | ((p.pack_out && !p.ln_c && p.out_bound) ? EP_BND : 0);
     switch (opt) {
-        case 0: case EP_RES: case EP_PACK: case EP_LNC | EP_RES: case EP_GELU: case EP_SWIGLU | EP_STATS | EP_PACK | EP_BND: case EP_SWIGLU | EP_STATS | EP_PACK: return opt;
+        case 0: case EP_RES: case EP_PACK: case EP_LNC | EP_RES: case EP_GELU: case EP_SWIGLU | EP_STATS | EP_PACK | EP_BND: case EP_SWIGLU | EP_STATS | EP_PACK: case EP_SWIGLU: return opt;
         default: return -1;
     }
 }
 
 // gemm_f16x3p.hip calls this for the launches its 128x128 register-epilogue configuration would take: true = launched here (rc holds the status).
-bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc) {
+// mode: 0 = even shares of the K slabs (stream-K) on 2 x (#CU - reserve) workgroups, 1 = whole tiles dealt round-robin to the persistent workgroups,
+// 2 = even shares on one workgroup per CU, 3 = even shares on 2 x #CU workgroups -- 1 .. 3 are measurement variants (psam_gemm_f16x3p_force_config 91 .. 93).
+// reserve (PSAM_GEMM_RESERVE_CUS, default 8): the tokenizer of the next batch (FPS: one 1024-thread workgroup per cloud, a whole CU each for ~1.3 ms of a
+// 10 ms step) runs beside the dense stage; a persistent grid that counts on every CU would leave 16 of its workgroups waiting for a second round then.
+bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc, int mode) {
     const int opt = f16x3s_option_set(p);
     if (opt < 0 || (p.M & 127) || (p.N & 127) || (p.K & 31) || p.K < 512) return false;
     // interior-tile conditions of the register epilogue (alignment of C / residual / bias rows), checked once for the launch
@@ -335,10 +377,18 @@ bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc) {
     a.nslabs = p.K / 32;
     if (tiles > SK_MAX_TILES_S || tiles * a.nslabs >= ((int64_t)1 << 30)) return false;
     a.units = (int)(tiles * a.nslabs);
-    int grid = 2 * ncu;
+    static int reserve = -1;
+    if (reserve < 0) { const char* e = getenv("PSAM_GEMM_RESERVE_CUS"); reserve = e ? atoi(e) : 8; }
+    const int cus = (mode == 0 && ncu > 2 * reserve) ? ncu - reserve : ncu;
+    int grid = mode == 2 ? cus : 2 * cus;
     if ((int64_t)grid * 16 > a.units) grid = a.units / 16;      // at least 16 slabs per workgroup
+    if (mode == 1 && grid > tiles) grid = (int)tiles;
     grid &= ~7;
-    if (grid < 8) return false;
+    // ranges of the multiply-high divisions in sk_bound / piece_at: u * nslabs, (j * span) * per_xcd < 2^32
+    if (grid < 8 || (int64_t)a.units * a.nslabs >= ((int64_t)1 << 32) || (int64_t)(grid / 8) * (grid / 8) * (a.units / 8 + 1) >= ((int64_t)1 << 32)) return false;
+    a.inv_nslabs = (unsigned)((((uint64_t)1 << 32) + a.nslabs - 1) / a.nslabs);
+    a.inv_per_xcd = (unsigned)((((uint64_t)1 << 32) + grid / 8 - 1) / (grid / 8));
+    a.whole = mode == 1 ? 1 : 0;
     const SkBlock blk = sk_block(stream, 2 * ncu);
     if (!blk.part) return false;
     a.g = p; a.part = blk.part; a.count = blk.count; a.per_xcd = grid / 8;
@@ -350,6 +400,7 @@ bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc) {
         case EP_GELU: rc = launch_s<EP_GELU>(a, grid, stream); break;
         case EP_SWIGLU | EP_STATS | EP_PACK | EP_BND: rc = launch_s<EP_SWIGLU | EP_STATS | EP_PACK | EP_BND>(a, grid, stream); break;
         case EP_SWIGLU | EP_STATS | EP_PACK: rc = launch_s<EP_SWIGLU | EP_STATS | EP_PACK>(a, grid, stream); break;
+        case EP_SWIGLU: rc = launch_s<EP_SWIGLU>(a, grid, stream); break;
         default: return false;
     }
     return true;

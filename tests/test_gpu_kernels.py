@@ -695,7 +695,7 @@ def _unpack_g8(P, scale):
     return (h[:, :, 0] + h[:, :, 1]).reshape(M, Kp) / scale[:, None]
 
 
-@pytest.mark.parametrize("M,D,H", [(4096, 1024, 2730), (2048, 1024, 2730), (2048, 512, 4064)])
+@pytest.mark.parametrize("M,D,H", [(4096, 1024, 2730), (2048, 1024, 2730), (2048, 512, 4090)])
 def test_gemm_f16x3_streamk(ops, M, D, H):
     """The persistent stream-K kernel (csrc/gemm_f16x3s.hip: 2 x #CU resident workgroups share the launch's K slabs; a tile covered by several of them is
     combined in the kernel, in K order, by the last arrival) against the one-workgroup-per-tile kernel on the encoder's four fused GEMMs -- packed q|k|v,
