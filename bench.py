@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3"],
                     help="arithmetic of the large GEMMs; all three are fp32-grade and pass the same parity tests (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle run (drops cpu_baseline and parity)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=3, help="timed oracle runs (median); 1 = the single cold run is the sample (the extra legs use it)")
     ap.add_argument("--streams", type=int, default=2, help="dense-stage HIP streams: batches in flight (1 = only the tokenizer of the next batch overlaps)")
     ap.add_argument("--no-pipeline", action="store_true", help="run FPS/kNN of each batch inline instead of one batch ahead on a side stream")
     ap.add_argument("--no-gemm-profile", action="store_true", help="skip the per-launch HIP-event timing of the GEMM kernel")
@@ -585,7 +586,7 @@ def worker(args):
             res["config"]["stub"] = dict(checks, taken=H.taken)
             res["data"] = "stub"
         elif world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"], res["parity"] = H.cpu_baseline(keep)
+            res["cpu_baseline"], res["parity"] = H.cpu_baseline(keep, iters=a.cpu_baseline_iters)
         if not args.stub and world == 1 and a.workload == "cfg2" and a.other_workloads:
             # BASELINE configs #3 / #5 as short legs of the SAME run, so that whoever runs the default command sees them (each is also a full
             # contract line of its own under --workload)
@@ -595,50 +596,31 @@ def worker(args):
 
 
 def other_leg(name, base, local):
-    """One BASELINE configuration as a short leg: `--other-steps` timed passes after 3 warm-ups through the same pipeline classes as the main run,
-    the dominant GEMM's roofline fraction from sampled launches, the output of the last timed pass against the oracle (all clouds of the leg's
-    batch) and ONE oracle run timed as the CPU baseline."""
-    argv = ["--workload", name, "--steps", str(base.other_steps), "--warmup", "3", "--precision", base.precision, "--streams", str(base.streams),
-            "--slots", str(base.slots), "--sustained-steps", "0"]
-    if not base.graphs:
-        argv.append("--no-graphs")
-    a = parse_args(argv)
-    H = HipHarness(a, 0, local)
-
-    def run(n):
-        out = None
-        if H.inline:
-            for _ in range(n):
-                out = H.next()
-            return out
-        for _ in range(min(H.depth, n)):
-            H.submit()
-        for k in range(n):
-            out = H.next()
-            if k + H.depth < n:
-                H.submit()
-        return out
-
-    run(a.warmup)
-    H.sync()
-    t0 = time.perf_counter()
-    out = run(a.steps)
-    H.sync()
-    el = time.perf_counter() - t0
-    H.finalize()
-    keep = (out[0].clone(), out[1].clone())
-    if not (bool(torch.isfinite(keep[0]).all()) and bool(torch.isfinite(keep[1]).all())):
-        raise SystemExit(f"other_workloads[{name}]: non-finite output")
-    leg = {"workload": f"{name}: ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={a.batch} "
-                       + (f"{a.clicks}-click session (encoder cached)" if a.clicks > 1 else "1 point prompt multimask"),
-           "value": round(a.batch * a.steps / el, 3), "unit": "sessions/s" if a.clicks > 1 else "point-clouds/s", "ms_per_step": round(el / a.steps * 1e3, 3),
-           "steps": a.steps, "warmup": a.warmup, "startup_s": H.startup}
-    if not base.no_gemm_profile:
-        roof = build_roofline(a, H.gemm_profile(), a.batch, 1, el)
-        if roof:
-            leg["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "sampled_launches", "avg_launch_ms", "avg_launch_gflop")}
-    if not base.no_cpu_baseline:
-        leg["cpu_baseline"], leg["parity"] = H.cpu_baseline(keep, iters=1)
+    """One BASELINE configuration as a short leg: `python bench.py --workload <name>` in a FRESH process (its own HIP context: a leg run inside this
+    process, after the main workload's streams and graphs, measured 1.3 - 2 x slower than the same command on its own -- profiles/r05_bench_legs.txt),
+    `--other-steps` timed passes after 3 warm-ups, one oracle run as the CPU baseline; its contract line is cut down to the leg's fields."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(base.other_steps), "--warmup", "3", "--precision", base.precision,
+           "--streams", str(base.streams), "--slots", str(base.slots), "--sustained-steps", "0", "--no-other-workloads", "--cpu-baseline-iters", "1", "--no-stage-times"]
+    for flag, on in (("--no-graphs", not base.graphs), ("--no-gemm-profile", base.no_gemm_profile), ("--no-cpu-baseline", base.no_cpu_baseline)):
+        if on:
+            cmd.append(flag)
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(local))
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    d = json.loads(lines[-1])
+    leg = {"workload": d["config"]["workload"], "value": d["value"], "unit": "sessions/s" if d["config"].get("clicks", 1) > 1 else d["unit"], "ms_per_step": d["ms_per_step"],
+           "steps": d["steps"], "warmup": d["warmup"], "batches_in_flight": d["config"]["batches_in_flight"], "startup_s": d["startup_s"]["per_rank"][0]}
+    if d.get("roofline"):
+        leg["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "sampled_launches", "avg_launch_ms", "avg_launch_gflop")}
+    for k in ("cpu_baseline", "parity"):
+        if k in d:
+            leg[k] = d[k]
     return leg
 
 

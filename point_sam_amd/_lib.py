@@ -45,7 +45,7 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_config": (None, [i32]),
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
     "psam_gemm_f16x3p_force_splitk_fixup": (None, [i32]),
-    "psam_gemm_f16x3p_force_streamk": (None, [i32]),
+    "psam_gemm_f16x3p_force_continuous": (None, [i32]),
     "psam_gemm_f16x3p_reset_splitk_state": (i32, [ptr]),
     "psam_attention_f16x3_reset_keysplit_state": (i32, [ptr]),
     "psam_attention_f16x3_force_keysplit": (None, [i32]),

@@ -90,6 +90,10 @@ int32_t launch_f16x3pp(int cfg, F16PArgs& p, hipStream_t stream);
 bool f16x3pp_supports(int cfg, int act, bool stats, bool gmax, bool hyper);
 int f16x3pp_pick(int M, int N, int K, int act);      // -1: keep the lock-step kernel
 bool f16x3p_use_register_epilogue(const F16PArgs& p);      // gemm_f16x3p.hip: whether this launch may run the register-only epilogue (gemm_epilogue_t.h)
+// gemm_f16x3c.hip: persistent form of the 128x128 register-epilogue configuration -- whole tiles from a queue, one continuous stream of K slabs per
+// workgroup; true = it took the launch (rc = status)
+bool launch_f16x3c(F16PArgs& p, hipStream_t stream, int32_t& rc, int wgs_per_cu = 2);
+void f16x3c_reset_state(hipStream_t stream);
 // gemm_f16x3s.hip: persistent stream-K form of the 128x128 register-epilogue configuration; true = it took the launch (rc = status)
 bool launch_f16x3s(F16PArgs& p, hipStream_t stream, int32_t& rc, int mode = 0);
 void f16x3s_reset_state(hipStream_t stream);

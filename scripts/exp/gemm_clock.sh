@@ -13,7 +13,7 @@ dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r
 cnt = collections.defaultdict(dict)
 for r in csv.DictReader(open(cc)):
     cnt[r["Dispatch_Id"]][r["Counter_Name"]] = cnt[r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-rows = [(int(d), dur[d], c) for d, c in cnt.items() if d in dur and "gemm_f16x3p_kernel" in dur[d][1]]
+rows = [(int(d), dur[d], c) for d, c in cnt.items() if d in dur and ("gemm_f16x3p_kernel" in dur[d][1] or "gemm_f16x3c_kernel" in dur[d][1])]
 rows.sort()
 out = ["f16x3p GEMM (128x128 tile, cfg 21), 30 back-to-back launches per (shape, operand fill); rocprofv3 --pmc, one pass; mean of the last 20 launches of each group.",
        "clock = (GRBM_GUI_ACTIVE / 8 XCDs) / kernel duration; matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).", "",

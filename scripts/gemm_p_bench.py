@@ -17,7 +17,7 @@ NAMES = {0: "128x128 4w S2", 1: "128x128 4w S3", 2: "128x128 4w S3 LA", 3: "128x
          80: "q 128x256 4w(64x128) S3", 81: "q 128x128 S3", 82: "q 128x128 S4", 83: "q 128x256 4w(32x256)", 84: "q 128x192 4w(64x96)",
          62: "pp 256x224 (32x224)", 63: "pp 256x192 (32x192)", 64: "pp 256x256 (32x256)",
          55: "pp 256x128 S6 P2", 56: "pp 256x128 S6 P1", 57: "pp 128x128 S8 P2", 58: "pp 128x128 S4 P2",
-         90: "stream-K 128x128 persistent",
+         90: "stream-K 128x128 persistent", 94: "continuous 128x128 persistent (queue)", 95: "continuous, one per CU",
          65: "pp 256x128 S3 P1 2/CU", 66: "pp 256x128 S3 P1 2/CU prio", 67: "pp 128x256 S3 P1 2/CU"}
 ODD_TN = (12, 23, 30, 62, 84)
 # per-shape configuration maps for the two-stream layer loop (qkv, proj, fc1, fc2)
@@ -31,6 +31,7 @@ COMBOS = {"all c0": (0, 0, 0, 0), "all c4": (4, 4, 4, 4), "all c14": (14, 14, 14
           "c21 c57 c21 c57": (21, 57, 21, 57), "all c60": (60, 60, 60, 60), "c60 c57 c60 c57": (60, 57, 60, 57), "c60 c57 c55 c57": (60, 57, 55, 57), "c60 c21 c60 c21": (60, 21, 60, 21), "c21 c57 c55 c57": (21, 57, 55, 57),
           "c62 c21 c63 c21": (62, 21, 63, 21), "c62 c57 c63 c57": (62, 57, 63, 57), "c62 c21 c21 c21": (62, 21, 21, 21), "c21 c21 c63 c21": (21, 21, 63, 21),
           "c64 c21 c64 c21": (64, 21, 64, 21), "all c80": (80, 80, 80, 80), "c80 c21 c80 c21": (80, 21, 80, 21), "c84 c21 c80 c21": (84, 21, 80, 21),
+          "all c94": (94, 94, 94, 94), "c94 c21 c94 c21": (94, 21, 94, 21), "c94 c21 c94 c94": (94, 21, 94, 94), "c94 c94 c94 c21": (94, 94, 94, 21),
           "all c90": (90, 90, 90, 90), "c90 c21 c90 c21": (90, 21, 90, 21), "c90 c21 c90 c90": (90, 21, 90, 90),
           "all c65": (65, 65, 65, 65), "c65 c21 c65 c21": (65, 21, 65, 21), "c65 c58 c65 c58": (65, 58, 65, 58), "c66 c21 c66 c21": (66, 21, 66, 21),
           "c67 c21 c67 c21": (67, 21, 67, 21), "all c58": (58, 58, 58, 58), "c21 c58 c21 c58": (21, 58, 21, 58), "c55 c21 c55 c21": (55, 21, 55, 21),
