@@ -147,10 +147,12 @@ void psam_gemm_f16x3p_force_epilogue(int32_t mode);
  * epilogue; no reduction launch), 0 = partial planes + reduction launch, -1 = the default (fix-up wherever the workspace and the stream's counters allow;
  * environment PSAM_GEMM_SPLITK_FIXUP=0 switches it off).  Tuning / test hook: both forms give the same bits for power-of-two scales. */
 void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
+#ifdef PSAM_BUILD_EXPERIMENTS
 /* psam_gemm_f16x3p(_ex), launches of >= 2048 rows on the 128x128 register-epilogue configuration: the persistent kernel (csrc/gemm_f16x3c.hip: resident
- * workgroups draw whole tiles from per-XCD queues and keep one continuous stream of K slabs going across tile boundaries) -- -1 = default (environment
- * PSAM_GEMM_CONTINUOUS, else on), 0 = never, 1 = wherever it applies.  Same products in the same order per tile: the same bits either way. */
+ * workgroups draw whole tiles from per-XCD queues and keep one continuous stream of K slabs going across tile boundaries; the same bits, measured the same
+ * time: profiles/r05_continuous_sweep.txt) -- -1 = default (environment PSAM_GEMM_CONTINUOUS, else off), 0 = never, 1 = wherever it applies. */
 void psam_gemm_f16x3p_force_continuous(int32_t mode);
+#endif
 /* The in-kernel fix-ups (split-K GEMM, key-split attention) keep arrival counters per (device, stream) that every launch leaves at zero.  After a
  * FAILED launch on a stream (device fault, aborted process) call these before reusing the stream: they re-zero its counters, stream-ordered.  A HIP
  * graph that captured such launches must replay on its capture stream (the counters' address is part of the captured launch). */

@@ -210,7 +210,7 @@ class TwoWayTokens(ctypes.Structure):
 
 _lib = None
 # entry points of the experiments build only (PSAM_BUILD_EXPERIMENTS=1, point_sam_amd/build.py): bound when the library exports them
-EXPERIMENTAL = ("psam_twoway_decoder_force_fork", "psam_twoway_tokens_ws_floats", "psam_twoway_tokens")
+EXPERIMENTAL = ("psam_twoway_decoder_force_fork", "psam_twoway_tokens_ws_floats", "psam_twoway_tokens", "psam_gemm_f16x3p_force_continuous")
 _has_experiments = False
 
 

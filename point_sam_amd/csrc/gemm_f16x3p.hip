@@ -477,16 +477,18 @@ PSAM_API int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const 
 // ---------------------------------------------------------------------------------------------- host
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
+#ifdef PSAM_BUILD_EXPERIMENTS
 // Persistent form of the 128x128 register-epilogue configuration (gemm_f16x3c.hip: whole tiles from a queue, one continuous slab stream per workgroup)
-// for batch-sized launches: -1 = default (environment PSAM_GEMM_CONTINUOUS, else on), 0 = never, 1 = wherever it applies.
+// for batch-sized launches: -1 = default (environment PSAM_GEMM_CONTINUOUS, else OFF: measured neutral), 0 = never, 1 = wherever it applies.
 static int g_f16x3p_continuous = -1;
 PSAM_API void psam_gemm_f16x3p_force_continuous(int32_t mode) { g_f16x3p_continuous = mode; }
 static bool f16x3p_continuous_enabled() {
     if (g_f16x3p_continuous >= 0) return g_f16x3p_continuous != 0;
     static int on = -1;
-    if (on < 0) { const char* e = getenv("PSAM_GEMM_CONTINUOUS"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = getenv("PSAM_GEMM_CONTINUOUS"); on = e ? (atoi(e) != 0) : 0; }
     return on != 0;
 }
+#endif
 #ifdef PSAM_GEMM_ABLATE
 static unsigned* g_f16x3p_dbg = nullptr;      // measurement builds: 16 words per wave of the timing instances (ABL & 64)
 extern "C" __attribute__((visibility("default"))) void psam_gemm_f16x3p_set_timing_buffer(void* buf) { g_f16x3p_dbg = (unsigned*)buf; }
@@ -654,8 +656,8 @@ static int* f16x3p_sk_counters(hipStream_t stream) {
 // documented constraint of graphs: the counters' address is baked into a captured launch, so a graph must replay on the stream it was captured on
 // (GraphPipeline does) -- replaying it elsewhere would race with eager split launches on the capture stream.
 PSAM_API int32_t psam_gemm_f16x3p_reset_splitk_state(hipStream_t stream) {
-    f16x3c_reset_state(stream);
 #ifdef PSAM_BUILD_EXPERIMENTS
+    f16x3c_reset_state(stream);
     f16x3s_reset_state(stream);
 #endif
     int* c = f16x3p_sk_counters(stream);
@@ -867,15 +869,15 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
     }
 #endif
     if (cfg >= 80 && cfg < 90) cfg = f16x3p_pick(M, N, K, act, true);      // (unit-ring configurations: experiments builds only)
-    // persistent forms of cfg 21 (whole tiles from a queue, one continuous slab stream per workgroup: gemm_f16x3c.hip): a forced configuration 94 (95: one
-    // workgroup per CU), or -- PSAM_GEMM_CONTINUOUS, default on -- the batch-sized launches (M >= 2048) that cfg 21 with the register epilogue would take
+#ifdef PSAM_BUILD_EXPERIMENTS
+    // persistent forms of cfg 21, both measured and not adopted (profiles/r05_continuous_sweep.txt, r05_streamk_sweep.txt): 94 = whole tiles from per-XCD
+    // queues, one continuous slab stream per workgroup (gemm_f16x3c.hip: the same bits as cfg 21, the same time; 95: one workgroup per CU; PSAM_GEMM_CONTINUOUS=1
+    // switches it in for the batch-sized launches), 90 .. 93 = even shares of the K slabs (stream-K, gemm_f16x3s.hip: slower)
     if (cfg == 94 || cfg == 95 || (cfg == 21 && g_f16x3p_cfg < 0 && M >= 2048 && f16x3p_continuous_enabled())) {
         int32_t rc = PSAM_OK;
         if (f16x3p_use_register_epilogue(p) && launch_f16x3c(p, stream, rc, cfg == 95 ? 1 : 2)) return rc;
         if (cfg >= 90) cfg = 21;
     }
-#ifdef PSAM_BUILD_EXPERIMENTS
-    // even shares of the K slabs (stream-K, gemm_f16x3s.hip: measured slower, profiles/r05_streamk_sweep.txt): forced configurations 90 .. 93 only
     if (cfg >= 90 && cfg <= 93) {
         int32_t rc = PSAM_OK;
         if (f16x3p_use_register_epilogue(p) && launch_f16x3s(p, stream, rc, cfg - 90)) return rc;
