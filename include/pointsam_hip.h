@@ -148,7 +148,7 @@ void psam_gemm_f16x3p_force_epilogue(int32_t mode);
  * environment PSAM_GEMM_SPLITK_FIXUP=0 switches it off).  Tuning / test hook: both forms give the same bits for power-of-two scales. */
 void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
 #ifdef PSAM_BUILD_EXPERIMENTS
-/* psam_gemm_f16x3p(_ex), launches of >= 2048 rows on the 128x128 register-epilogue configuration: the persistent kernel (csrc/gemm_f16x3c.hip: resident
+/* Batch-sized launches (>= 2048 rows) of the packed-operand GEMM on the 128x128 register-epilogue configuration: the persistent kernel (csrc/gemm_f16x3c.hip: resident
  * workgroups draw whole tiles from per-XCD queues and keep one continuous stream of K slabs going across tile boundaries; the same bits, measured the same
  * time: profiles/r05_continuous_sweep.txt) -- -1 = default (environment PSAM_GEMM_CONTINUOUS, else off), 0 = never, 1 = wherever it applies. */
 void psam_gemm_f16x3p_force_continuous(int32_t mode);
