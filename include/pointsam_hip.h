@@ -55,6 +55,8 @@ void psam_fps_set_cooperative(int32_t on); /* test hook: 0 = never use the multi
  * materialised.  Replaces knn_points(centers, xyz, K) = torch.cdist + torch.topk: pc_sam/model/common.py:27-56,97.
  *   centers [B,G,3], xyz [B,N,3] -> knn_idx [B,G,K] int64.  K <= 1024. */
 int32_t psam_knn(const float* centers, const float* xyz, int32_t B, int32_t G, int32_t N, int32_t K, int64_t* knn_idx, psam_stream_t stream);
+/* tuning / test hook: 1 = the band kernel (one or two distance evaluations per pair; default), 0 = the four-pass kernel, -1 = default (environment PSAM_KNN_BAND) */
+void psam_knn_force_band(int32_t mode);
 
 /* 3 nearest centers of every point + normalised 1/max(d^2, eps) weights.
  * Replaces compute_interp_weights(query, key): pc_sam/model/common.py:238-255 (called from mask_decoder.py:151-156).

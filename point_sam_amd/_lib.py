@@ -21,6 +21,7 @@ SIGNATURES = {
     "psam_fps_set_cooperative": (None, [i32]),
     "psam_fps": (i32, [ptr, i32, i32, i32, ptr, ptr, ptr, size_t, ptr]),
     "psam_knn": (i32, [ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
+    "psam_knn_force_band": (None, [i32]),
     "psam_three_nn": (i32, [ptr, ptr, i32, i32, i32, f32, ptr, ptr, ptr]),
     "psam_group_gather": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, ptr]),
     "psam_group_gather_r": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, f32, ptr, ptr]),

@@ -536,17 +536,12 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* s_wave, int& tota
     return off + inc - v;
 }
 
-__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ centers, const float* __restrict__ xyz,
-                                                          int G, int N, int K, int64_t* __restrict__ out_idx) {
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const float* P = xyz + (int64_t)b * N * 3;
-    const float* c = centers + ((int64_t)b * G + g) * 3;
-    const float cx = c[0], cy = c[1], cz = c[2];
-
-    __shared__ unsigned hist[2048];
-    __shared__ unsigned long long keys[KNN_MAXK];
-    __shared__ int s_wave[4];
-    __shared__ int s_bin, s_below, s_cnt_less, s_cnt_eq;
+// The whole selection for one center with every pass over the whole cloud (four distance evaluations per point): the general path -- any band size, ties
+// at the K-th value cut by index.  LDS arrays are the caller's (hist[2048], keys[KNN_MAXK], s_wave[4], sm[4] = bin / below / count-less / count-equal).
+__device__ __forceinline__ void knn_select_full(const float* __restrict__ P, float cx, float cy, float cz, int N, int K, int64_t* __restrict__ out, unsigned* hist,
+                                                unsigned long long* keys, int* s_wave, int* sm) {
+    const int tid = threadIdx.x;
+    int& s_bin = sm[0]; int& s_below = sm[1]; int& s_cnt_less = sm[2]; int& s_cnt_eq = sm[3];
 
     unsigned prefix_mask = 0, prefix_val = 0;
     int remaining = K;  // rank (1-based) of the K-th smallest inside the current candidate set
@@ -638,9 +633,186 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
             __syncthreads();
         }
     }
-    int64_t* out = out_idx + ((int64_t)b * G + g) * K;
     for (int i = tid; i < K; i += KNN_THREADS) out[i] = (int64_t)(keys[i] & 0xffffffffull);
 }
+
+__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ centers, const float* __restrict__ xyz,
+                                                          int G, int N, int K, int64_t* __restrict__ out_idx) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const float* c = centers + ((int64_t)b * G + g) * 3;
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long keys[KNN_MAXK];
+    __shared__ int s_wave[4];
+    __shared__ int sm[4];
+    knn_select_full(xyz + (int64_t)b * N * 3, c[0], c[1], c[2], N, K, out_idx + ((int64_t)b * G + g) * K, hist, keys, s_wave, sm);
+}
+
+// Round 5: the same selection with TWO distance evaluations per (center, point) pair instead of four.
+// knn_kernel above evaluates every distance in each of its three radix passes and once more to collect.  But after the first pass (the top 11 bits of the
+// fp32 pattern of d2) the answer is known up to a BAND: every point whose top bits lie below the selected bin belongs to it (fewer than K of them), no point
+// above does, and the K-th distance lies among the bin's own points -- typically N / 2048 .. a few hundred.  So: sweep 1 builds the histogram; sweep 2
+// appends the points below the bin to the answer and the bin's points (pattern, index) to a candidate list in LDS; the two remaining radix passes, the
+// cut at the K-th value and the collection run on that list.  (Keeping a thread's sweep-1 distances in registers for sweep 2 -- one evaluation per pair --
+// needs 128 registers at N = 32768 and left one workgroup per CU: slower than recomputing.)  Points are read four at a time as three 16-byte loads.
+// Same comparisons on the same fp32 patterns, same final bitonic sort by (d2, index): bit-identical output.
+// A band that overflows the list (more than KNN_CAND points share the top 11 bits: clouds of duplicates) or a tie at the K-th value that has to be cut by
+// index sends the WORKGROUP (uniformly) through knn_select_full: the general path, same LDS, same result.
+constexpr int KNN_CAND = 2048;      // candidate capacity (16 KiB of LDS: a band holds roughly 0.2 K .. 0.4 K points of a uniform cloud)
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(KNN_THREADS) void knn_band_kernel(const float* __restrict__ centers, const float* __restrict__ xyz, int G, int N, int K,
+                                                               int64_t* __restrict__ out_idx) {
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* P = xyz + (int64_t)b * N * 3;
+    const float* c = centers + ((int64_t)b * G + g) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long keys[KNN_MAXK];
+    __shared__ unsigned cand_u[KNN_CAND];
+    __shared__ int cand_n[KNN_CAND];
+    __shared__ int s_wave[4];
+    __shared__ int sm[4];
+    __shared__ int s_cnt_cand;
+    int& s_bin = sm[0]; int& s_below = sm[1]; int& s_cnt_less = sm[2];
+    int64_t* const out = out_idx + ((int64_t)b * G + g) * K;
+
+    // points in groups of four (48 contiguous bytes = three 16-byte loads when the cloud is 16-byte aligned); group q = i * 256 + tid
+    const int ngroups = (N + 3) >> 2;
+    const bool vec = (((uintptr_t)P) & 15) == 0;
+    auto dist4 = [&](int q, unsigned (&u)[4]) {
+        const int n0 = q * 4;
+        if (vec && n0 + 4 <= N) {
+            const knn_f32x4* p4 = reinterpret_cast<const knn_f32x4*>(P + (int64_t)n0 * 3);
+            const knn_f32x4 a = p4[0], bb = p4[1], cc = p4[2];
+            u[0] = __float_as_uint(dist2_exact(cx, cy, cz, a[0], a[1], a[2]));
+            u[1] = __float_as_uint(dist2_exact(cx, cy, cz, a[3], bb[0], bb[1]));
+            u[2] = __float_as_uint(dist2_exact(cx, cy, cz, bb[2], bb[3], cc[0]));
+            u[3] = __float_as_uint(dist2_exact(cx, cy, cz, cc[1], cc[2], cc[3]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + e;
+                u[e] = n < N ? __float_as_uint(dist2_exact(cx, cy, cz, P[n * 3 + 0], P[n * 3 + 1], P[n * 3 + 2])) : 0xffffffffu;      // past the end: never selected (d2 patterns are < 0x7f800000)
+            }
+        }
+    };
+    // ---- sweep 1: histogram of the top 11 bits
+    for (int i = tid; i < 2048; i += KNN_THREADS) hist[i] = 0;
+    if (tid == 0) { s_cnt_less = 0; s_cnt_cand = 0; }
+    __syncthreads();
+    for (int q = tid; q < ngroups; q += KNN_THREADS) {
+        unsigned u[4];
+        dist4(q, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (u[e] != 0xffffffffu) atomicAdd(&hist[u[e] >> 21], 1u);
+    }
+    __syncthreads();
+    int remaining = K;
+    {
+        int loc[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { loc[i] = (int)hist[tid * 8 + i]; sum += loc[i]; }
+        int total;
+        int before = block_excl_scan_256(sum, s_wave, total);
+        if (remaining > before && remaining <= before + sum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (remaining > before && remaining <= before + loc[i]) { s_bin = tid * 8 + i; s_below = before; }
+                before += loc[i];
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned bin0 = (unsigned)s_bin;
+    const int n_band = (int)hist[bin0];
+    remaining -= s_below;      // rank of the K-th smallest inside the band
+    if (n_band > KNN_CAND) {      // uniform: the band does not fit the list
+        __syncthreads();
+        knn_select_full(P, cx, cy, cz, N, K, out, hist, keys, s_wave, sm);
+        return;
+    }
+    // ---- sweep 2: below the band -> the answer; in the band -> the candidate list
+    auto place = [&](unsigned u, int n) {
+        const unsigned top = u >> 21;
+        if (top < bin0) { const int p = atomicAdd(&s_cnt_less, 1); keys[p] = ((unsigned long long)u << 32) | (unsigned)n; }
+        else if (top == bin0) { const int p = atomicAdd(&s_cnt_cand, 1); cand_u[p] = u; cand_n[p] = n; }
+    };
+    for (int q = tid; q < ngroups; q += KNN_THREADS) {
+        unsigned u[4];
+        dist4(q, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) place(u[e], q * 4 + e);
+    }
+    __syncthreads();
+    // ---- the two lower radix passes on the candidates
+    unsigned prefix_mask = 0x7ffu << 21, prefix_val = bin0 << 21;
+    int eq_total = n_band;
+    for (int pass = 1; pass < 3; ++pass) {
+        const int shift = pass == 1 ? 10 : 0;
+        const int nb = pass == 2 ? 1024 : 2048;
+        for (int i = tid; i < 2048; i += KNN_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n_band; i += KNN_THREADS) {
+            const unsigned u = cand_u[i];
+            if ((u & prefix_mask) == prefix_val) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        int loc[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { loc[i] = (int)hist[tid * 8 + i]; sum += loc[i]; }
+        int total;
+        int before = block_excl_scan_256(sum, s_wave, total);
+        if (remaining > before && remaining <= before + sum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (remaining > before && remaining <= before + loc[i]) { s_bin = tid * 8 + i; s_below = before; }
+                before += loc[i];
+            }
+        }
+        __syncthreads();
+        const int bin = s_bin;
+        remaining -= s_below;
+        eq_total = (int)hist[bin];
+        prefix_val |= (unsigned)bin << shift;
+        prefix_mask |= (unsigned)(nb - 1) << shift;
+        __syncthreads();
+    }
+    const unsigned T = prefix_val;     // bit pattern of the K-th smallest d2
+    const int need_eq = remaining;     // how many of the points with d2 == T belong to the answer (lowest indices)
+    if (eq_total != need_eq) {         // uniform: a tie at the K-th value must be cut by index
+        __syncthreads();
+        knn_select_full(P, cx, cy, cz, N, K, out, hist, keys, s_wave, sm);
+        return;
+    }
+    for (int i = tid; i < n_band; i += KNN_THREADS) {
+        const unsigned u = cand_u[i];
+        if (u <= T) { const int p = atomicAdd(&s_cnt_less, 1); keys[p] = ((unsigned long long)u << 32) | (unsigned)cand_n[i]; }
+    }
+    // ---- bitonic sort of K keys padded to a power of two (as knn_kernel)
+    int P2 = 1;
+    while (P2 < K) P2 <<= 1;
+    __syncthreads();
+    for (int i = K + tid; i < P2; i += KNN_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < P2; i += KNN_THREADS) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], bb = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > bb) == up) { keys[i] = bb; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < K; i += KNN_THREADS) out[i] = (int64_t)(keys[i] & 0xffffffffull);
+}
+
+static int g_knn_band = -1;      // -1: environment PSAM_KNN_BAND (default 1); 0 = always the four-pass kernel (A/B, tests)
+PSAM_API void psam_knn_force_band(int32_t mode) { g_knn_band = mode; }
 
 // centers [B,G,3], xyz [B,N,3] -> knn_idx [B,G,K] i64 ascending by (squared distance, index).
 PSAM_API int32_t psam_knn(const float* centers, const float* xyz, int32_t B, int32_t G, int32_t N, int32_t K, int64_t* knn_idx,
@@ -649,7 +821,14 @@ PSAM_API int32_t psam_knn(const float* centers, const float* xyz, int32_t B, int
     PSAM_REQUIRE(B > 0 && G > 0 && N > 0 && K > 0 && K <= N, PSAM_EINVAL, "psam_knn: need 0<K<=N");
     PSAM_REQUIRE(K <= KNN_MAXK, PSAM_EINVAL, "psam_knn: K > 1024 unsupported");
     PSAM_REQUIRE(B <= 65535, PSAM_EINVAL, "psam_knn: B > 65535 unsupported");
-    hipLaunchKernelGGL(knn_kernel, dim3(G, B), dim3(KNN_THREADS), 0, stream, centers, xyz, G, N, K, knn_idx);
+    int band = g_knn_band;
+    if (band < 0) {
+        static int env = -1;
+        if (env < 0) { const char* e = getenv("PSAM_KNN_BAND"); env = e ? atoi(e) : 1; }
+        band = env;
+    }
+    if (!band) hipLaunchKernelGGL(knn_kernel, dim3(G, B), dim3(KNN_THREADS), 0, stream, centers, xyz, G, N, K, knn_idx);
+    else hipLaunchKernelGGL(knn_band_kernel, dim3(G, B), dim3(KNN_THREADS), 0, stream, centers, xyz, G, N, K, knn_idx);
     return psam_launch_status("psam_knn: launch failed");
 }
 

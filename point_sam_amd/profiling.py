@@ -97,8 +97,9 @@ def tokenizer_metrics(stage_ms: dict, B: int, N: int, G: int, K: int) -> dict:
                            {"us_per_iteration": round(stage_ms["fps"] * 1e3 / G, 3), "iterations": G,
                             "bound": "dependent iterations: distance update (VALU) + workgroup arg-max (DPP / LDS / barrier latency) per iteration"})
     if stage_ms.get("knn"):
-        out["knn"] = entry(stage_ms["knn"], float(B) * G * N * 4, CHIP_CUS,
-                           {"bound": "VALU + L2 stream: 3 radix-select passes + 1 collect pass over the cloud per center (4 distance evaluations per point-center pair)"})
+        out["knn"] = entry(stage_ms["knn"], float(B) * G * N * 2, CHIP_CUS,
+                           {"bound": "VALU + L2 stream: one histogram sweep + one collection sweep over the cloud per center (2 distance evaluations per point-center pair; "
+                                     "the two lower radix passes run on the selected bin's points only -- round 5, was 4 evaluations)"})
     if stage_ms.get("three_nn"):
         out["three_nn"] = entry(stage_ms["three_nn"], float(B) * N * G, CHIP_CUS, {"bound": "VALU: one distance + top-3 insertion per point-center pair"})
     return out

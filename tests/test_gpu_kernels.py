@@ -114,6 +114,28 @@ def test_knn_bit_exact(ops, B, N, G, K, dup):
         raise AssertionError(f"kNN differs in {len(rows)} of {B * G} groups; first {rows[0].tolist()}: got {got[tuple(rows[0])][:8]} want {want[tuple(rows[0])][:8]}")
 
 
+@pytest.mark.parametrize("B,N,G,K,dup", [(2, 32768, 512, 64, 0), (3, 4999, 64, 37, 0), (1, 131072, 96, 256, 0), (2, 6000, 128, 64, 2500), (1, 3001, 16, 3001, 0), (1, 2600, 8, 100, 2590)])
+def test_knn_band_kernel_equals_four_pass_kernel(ops, B, N, G, K, dup):
+    """The band kernel (csrc/tokenizer.hip knn_band_kernel: one histogram sweep, then the two lower radix passes and the cut on the selected bin's points
+    only -- two distance evaluations per pair instead of four; common.py:27-56) gives the four-pass kernel's indices bit for bit: aligned and unaligned
+    clouds (a batch whose clouds start off 16-byte boundaries, N % 4 != 0), K = N, and clouds of duplicates whose band overflows the candidate list or
+    whose K-th distance is tied (the general path inside the same kernel)."""
+    L = ops._lib.load()
+    xyz, _ = _cloud(B, N, seed=11 * N + K, dup=dup)
+    if N == 2600:
+        xyz[:, :dup] = xyz[:, :1]      # 2590 copies of one point: every distance to them is equal -- the band overflows the candidate list and the K-th value is tied
+    centers = O.batch_index_select(xyz, O.fps(xyz, G))
+    out = {}
+    try:
+        for mode in (0, 1):
+            L.psam_knn_force_band(mode)
+            out[mode] = ops.knn(cu(centers), cu(xyz), K)
+        torch.cuda.synchronize()
+    finally:
+        L.psam_knn_force_band(-1)
+    assert torch.equal(out[0], out[1]), f"{(out[0] != out[1]).any(-1).sum().item()} of {B * G} groups differ"
+
+
 def test_knn_all_points_identical(ops):
     """Degenerate tie: every distance equal -> the K lowest indices."""
     xyz = torch.full((1, 500, 3), 0.25)
@@ -684,13 +706,6 @@ def test_gemm_f16x3_register_epilogue_bitwise(ops):
             assert ((a - b).abs().max() / a.abs().max()).item() < 2e-6
         else:
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{k}: {(a.view(torch.int32) != b.view(torch.int32)).sum().item()} words differ"
-
-
-def _unpack_g8(P, scale):
-    """fp32 values of g8-packed rows: every 8 containers hold [hi x 8 | lo x 8] fp16 of scale[row] * x."""
-    M, Kp = P.shape
-    h = P.contiguous().view(torch.float16).view(M, Kp // 8, 2, 8).float()
-    return (h[:, :, 0] + h[:, :, 1]).reshape(M, Kp) / scale[:, None]
 
 
 @pytest.mark.parametrize("M,D,H", [(4096, 1024, 2730), (2048, 1024, 2730), (2048, 512, 4090), (8192, 1024, 2730)])
