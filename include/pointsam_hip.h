@@ -50,6 +50,9 @@ size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G);
 int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws, size_t ws_bytes,
                  psam_stream_t stream);
 void psam_fps_set_cooperative(int32_t on); /* test hook: 0 = never use the multi-workgroup kernel for N > 32768, 2 = use it without the one-XCD placement */
+void psam_fps_set_pruning(int32_t mode);   /* A/B and test hook: 0 = the multi-workgroup kernel scans every point in every iteration, 1 = it buckets the cloud by
+                                            * grid cell and skips, exactly, the waves whose bounding box the new centre cannot reach; -1 = default
+                                            * (environment PSAM_FPS_PRUNE, else 1) */
 
 /* K nearest points of each center, ascending by (squared distance, index); the [G,N] distance matrix is never
  * materialised.  Replaces knn_points(centers, xyz, K) = torch.cdist + torch.topk: pc_sam/model/common.py:27-56,97.
@@ -282,22 +285,47 @@ void psam_attention_packed_force_variant(int32_t v); /* tuning hook: -1 default,
 int32_t psam_linear_skinny(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                            float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, psam_stream_t stream);
 
-/* Up to three skinny Linears over the same M <= 64 input rows in one launch: y_i = act_i((x_i + xadd_i) W_i^T + bias_i), xadd optional (the
+/* Up to PSAM_SKINNY_MAX_JOBS skinny Linears over the same M <= 64 input rows in one launch: y_i = act_i((x_i + xadd_i) W_i^T + bias_i), xadd optional (the
  * decoder's q = k = queries + query_pe, v = queries: transformer.py:153-170,214-236).  All jobs share ldx (x rows), ldxadd, ldw, M and K. */
 typedef struct {
     const float* x; const float* xadd; const float* W; const float* bias; float* y;
     int64_t ldy;
     int32_t N, act;
 } psam_skinny_job_t;
+#define PSAM_SKINNY_MAX_JOBS 6
 typedef struct {
-    psam_skinny_job_t job[3];
+    psam_skinny_job_t job[PSAM_SKINNY_MAX_JOBS];
     int32_t n;
 } psam_skinny_jobs_t;
 int32_t psam_linear_skinny_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int64_t ldxadd, int64_t ldw, int32_t M, int32_t K, psam_stream_t stream);
+/* The same for ANY number of rows (a few hundred to a few thousand: the decoder's patch rows), exact fp32 products, 32 x 32 tiles: y_i [M, N_i] =
+ * act_i((x_i + xadd_i) W_i^T + bias_i).  xadd_i (optional) holds sets of rows_per_set rows; row r adds row (r / (rep * rows_per_set)) * rows_per_set +
+ * r % rows_per_set (key_pe of the cloud, shared by its rep prompt sets: transformer.py:160-175). */
+int32_t psam_linear_rows_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int64_t ldxadd, int32_t rows_per_set, int32_t rep, int64_t ldw, int64_t M, int32_t K,
+                               psam_stream_t stream);
+/* Skinny Linear + residual + LayerNorm in one launch: y [M, 256] = LayerNorm(x W^T + bias + residual) * ln_w + ln_b, M <= 64 rows, N == 256 -- the
+ * `queries = norm(queries + out_proj(attn))` / `norm3(queries + mlp(queries))` steps of the decoder's token side (transformer.py:153-176).  The last
+ * workgroup to finish its columns normalises the rows (arrival counter of the stream; psam_stream_has_arrival_counters(stream) == 0 while a stream
+ * that never ran an eager launch is being captured: the call is then refused and the caller issues the two launches).  K is split over up to 8
+ * workgroup rows (lin2 of the token MLP: K = 2048).  tmp: psam_linear_skinny_ln_tmp_floats(M, K) floats. */
+size_t psam_linear_skinny_ln_tmp_floats(int32_t M, int32_t K);
+int32_t psam_linear_skinny_ln(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
+                              const float* ln_w, const float* ln_b, float eps, float* tmp, float* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                              psam_stream_t stream);
+int32_t psam_stream_has_arrival_counters(psam_stream_t stream);
+/* The same for ANY number of rows and a short K (K % 16 == 0, K <= 512): y [M, 256] = LayerNorm(x W^T + bias + residual) * ln_w + ln_b, a workgroup per
+ * 16 whole rows, exact fp32 products -- `keys = norm4(keys + out_proj(attn))` of the decoder's patch side (transformer.py:170-175; K = 128). */
+int32_t psam_linear_ln256(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, const float* ln_w,
+                          const float* ln_b, float eps, float* y, int64_t ldy, int64_t M, int32_t N, int32_t K, psam_stream_t stream);
 /* psam_scale_pack_rows_g8 of X + add[(row / (rep * rows_per_set)) * rows_per_set + row % rows_per_set]: the broadcast positional add of the decoder's
  * keys (k = keys + key_pe, transformer.py:160-170) folded into the pass that scales and packs the rows for the k / q projection GEMMs. */
 int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const float* add, int64_t ldadd, int32_t rows_per_set, int32_t rep, int32_t rows, int32_t K,
                                     void* P, int64_t ldp, float* scale, psam_stream_t stream);
+
+/* Both packed forms of the decoder's patch rows in one pass (K <= 256): P_sum / scale_sum = psam_scale_pack_rows_g8_add's output (keys + key_pe, the
+ * operand of the k / q projections), P_x / scale_x = psam_scale_pack_rows_g8 of X alone (the operand of the v projection); transformer.py:160-170. */
+int32_t psam_scale_pack_rows_g8_add_dual(const float* X, int64_t ldx, const float* add, int64_t ldadd, int32_t rows_per_set, int32_t rep, int32_t rows, int32_t K,
+                                         void* P_sum, float* scale_sum, void* P_x, float* scale_x, int64_t ldp, psam_stream_t stream);
 
 /* ONE EVA02 (SwiGLU) transformer block of the patch encoder in one call (csrc/blocks.hip) -- timm's block as the reference runs it
  * (pc_sam/model/pc_encoder.py:138-139, no rope): x += proj(SDPA(LN1 x)); x += fc2(LN(SiLU(fc1_g h) * fc1_x h)), h = LN2 x.  "f16x3" arithmetic with
@@ -411,6 +439,7 @@ typedef struct {
     psam_twoway_weights_t weights;
     psam_twoway_layer_weights_t layers[PSAM_TWOWAY_MAX_DEPTH];
     int64_t o_packed[14 * PSAM_TWOWAY_MAX_DEPTH + 4], o_scales[14 * PSAM_TWOWAY_MAX_DEPTH + 4];
+    int64_t o_cat_packed[PSAM_TWOWAY_MAX_DEPTH], o_cat_scales[PSAM_TWOWAY_MAX_DEPTH], o_cat_bias[PSAM_TWOWAY_MAX_DEPTH];      /* per layer: [t2i.k_proj | i2t.q_proj] as one weight */
 } psam_twoway_plan_t;
 size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample);
 int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* weights, psam_twoway_plan_t* plan, void* prepared, size_t prepared_bytes, psam_stream_t stream);
@@ -418,6 +447,9 @@ size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, int32_t dim
 /* tokens [Z*T, dim] (= query_pe), keys [Z*G, dim] in / out (src -> the transformer's second output), pos [Z / rep, G, dim] -> queries [Z*T, dim] */
 int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void* prepared, const float* tokens, float* keys, const float* pos, int32_t rep, int64_t Z,
                             int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, psam_stream_t stream);
+/* A/B and test hook: 0 = the operator-by-operator launch sequence (what the Python host issues), 1 = the regrouped sequence (fused Linear + LayerNorm
+ * launches of the token side, merged projections; csrc/blocks.hip), -1 = default (environment PSAM_TWOWAY_FAST, else 1). */
+void psam_twoway_decoder_force_fast(int32_t mode);
 
 /* Token side of one TwoWayAttentionBlock in ONE launch (csrc/twoway.hip): self-attention + norm1, token -> image attention + norm2, the MLP
  * + norm3 on the Z * T <= 64 output-token rows, and the k / v projections of the image -> token attention that follows -- what
@@ -461,11 +493,24 @@ int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float* w1, cons
                   const float* w3, const float* b3, float* out, int64_t ldo, int64_t so, int32_t Z, int32_t M, int32_t din, int32_t dh,
                   int32_t dout, psam_stream_t stream);
 
+/* Two psam_mlp3 stacks over the same Z rows in ONE launch -- the hyper-networks (mask tokens) and the IoU head (token 0) both read the transformer's
+ * token output (mask_decoder.py:167-182).  Fields as the arguments of psam_mlp3; the same bits as two psam_mlp3 calls. */
+typedef struct {
+    const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
+    float* out;
+    int64_t ldx, sx, ldo, so;
+    int32_t M, din, dh, dout;
+} psam_mlp3_args_t;
+int32_t psam_mlp3_pair(const psam_mlp3_args_t* a, const psam_mlp3_args_t* b, int32_t Z, psam_stream_t stream);
+
 /* Same contraction for the decoder's token-sized problems (any hd, few queries or few keys).
  * Replaces Attention.forward's matmul-softmax-matmul: pc_sam/model/transformer.py:226-233. */
 int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                              int64_t sv, float* out, int64_t ldo, int64_t so, int64_t Z, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
                              float scale, psam_stream_t stream);
+/* Test / A-B hook: 0 = psam_attention_small always runs one wave per query; 1 (default) = few queries against >= 128 keys run one workgroup per query,
+ * the keys split over its four waves. */
+void psam_attention_small_force_split(int32_t on);
 
 /* ---------------------------------------------------------------- encodings, token assembly, upsampling */
 

@@ -19,6 +19,7 @@ SIGNATURES = {
     "psam_last_error_string": (ctypes.c_char_p, []),
     "psam_fps_workspace_bytes": (size_t, [i32, i32, i32]),
     "psam_fps_set_cooperative": (None, [i32]),
+    "psam_fps_set_pruning": (None, [i32]),
     "psam_fps": (i32, [ptr, i32, i32, i32, ptr, ptr, ptr, size_t, ptr]),
     "psam_knn": (i32, [ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
     "psam_knn_force_band": (None, [i32]),
@@ -62,6 +63,15 @@ SIGNATURES = {
     "psam_eva_block_ws_bytes": (size_t, [i64, i32, i32]),
     "psam_eva_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
     "psam_linear_skinny_multi": (i32, [ptr, i64, i64, i64, i32, i32, ptr]),
+    "psam_linear_skinny_ln": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr, f32, ptr, ptr, i64, i32, i32, i32, ptr]),
+    "psam_stream_has_arrival_counters": (i32, [ptr]),
+    "psam_linear_rows_multi": (i32, [ptr, i64, i64, i32, i32, i64, i64, i32, ptr]),
+    "psam_linear_ln256": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, i64, i32, i32, ptr]),
+    "psam_twoway_decoder_force_fast": (None, [i32]),
+    "psam_scale_pack_rows_g8_add_dual": (i32, [ptr, i64, ptr, i64, i32, i32, i32, i32, ptr, ptr, ptr, ptr, i64, ptr]),
+    "psam_mlp3_pair": (i32, [ptr, ptr, i32, ptr]),
+    "psam_attention_small_force_split": (None, [i32]),
+    "psam_linear_skinny_ln_tmp_floats": (ctypes.c_size_t, [i32, i32]),
     "psam_scale_pack_rows_g8_add": (i32, [ptr, i64, ptr, i64, i32, i32, i32, i32, ptr, i64, ptr, ptr]),
     "psam_eva_gelu_block_prepared_bytes": (size_t, [i32, i32]),
     "psam_eva_gelu_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
@@ -129,6 +139,11 @@ class EvaBlockPlan(ctypes.Structure):
                 [(n, i64) for n in ("o_wqkv", "o_sqkv", "o_bqkv", "o_wproj", "o_sproj", "o_w1", "o_s1", "o_b1", "o_w2g", "o_s2g", "o_lnc", "o_lnd")])
 
 
+class Mlp3Args(ctypes.Structure):
+    """psam_mlp3_args_t (include/pointsam_hip.h)."""
+    _fields_ = [(n, ptr) for n in ("x", "w1", "b1", "w2", "b2", "w3", "b3", "out")] + [(n, i64) for n in ("ldx", "sx", "ldo", "so")] + [(n, i32) for n in ("M", "din", "dh", "dout")]
+
+
 class SkinnyJob(ctypes.Structure):
     """psam_skinny_job_t (include/pointsam_hip.h)."""
     _fields_ = [(n, ptr) for n in ("x", "xadd", "W", "bias", "y")] + [("ldy", i64), ("N", i32), ("act", i32)]
@@ -136,7 +151,7 @@ class SkinnyJob(ctypes.Structure):
 
 class SkinnyJobs(ctypes.Structure):
     """psam_skinny_jobs_t (include/pointsam_hip.h)."""
-    _fields_ = [("job", SkinnyJob * 3), ("n", i32)]
+    _fields_ = [("job", SkinnyJob * 6), ("n", i32)]      # PSAM_SKINNY_MAX_JOBS
 
 
 class EvaGeluBlockWeights(ctypes.Structure):
@@ -198,7 +213,8 @@ class TwoWayWeights(ctypes.Structure):
 class TwoWayPlan(ctypes.Structure):
     """psam_twoway_plan_t."""
     _fields_ = [("weights", TwoWayWeights), ("layers", TwoWayLayerW * TWOWAY_MAX_DEPTH), ("o_packed", i64 * (14 * TWOWAY_MAX_DEPTH + 4)),
-                ("o_scales", i64 * (14 * TWOWAY_MAX_DEPTH + 4))]
+                ("o_scales", i64 * (14 * TWOWAY_MAX_DEPTH + 4)), ("o_cat_packed", i64 * TWOWAY_MAX_DEPTH), ("o_cat_scales", i64 * TWOWAY_MAX_DEPTH),
+                ("o_cat_bias", i64 * TWOWAY_MAX_DEPTH)]
 
 
 class TwoWayTokens(ctypes.Structure):

@@ -27,6 +27,24 @@ struct Carve {      // bump allocator over a caller-provided buffer
     template <typename T> T* take(int64_t count) { T* r = reinterpret_cast<T*>(base + off); off += align256(count * (int64_t)sizeof(T)); return r; }
 };
 
+// A Linear on a few hundred to ~2000 rows (one or two clouds' patch tokens): the exact-fp32 32 x 64-tile kernel (psam_linear_rows_multi) beats the
+// packing pass + packed-operand GEMM there (5-6 us against 5 + 8-10 us: tiles of 128 rows leave a handful of workgroups, all latency).
+// PSAM_ROWS_MULTI=0 switches it off (A/B).
+static bool rows_multi_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_ROWS_MULTI"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
+static bool rows_multi_fits(int64_t M, int K) { return rows_multi_enabled() && M > 64 && M <= 2048 && (K & 15) == 0; }
+static int32_t rows_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream) {
+    psam_skinny_jobs_t jobs;
+    std::memset(&jobs, 0, sizeof(jobs));
+    jobs.n = 1;
+    jobs.job[0].x = x; jobs.job[0].W = w; jobs.job[0].bias = b; jobs.job[0].y = y; jobs.job[0].ldy = ldy; jobs.job[0].N = N;
+    return psam_linear_rows_multi(&jobs, ldx, ldx, 1, 1, ldw, M, K, stream);
+}
+
+
 double row_norm(const float* w, int k) {
     double s = 0.0;
     for (int i = 0; i < k; ++i) s += (double)w[i] * (double)w[i];
@@ -462,7 +480,9 @@ PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const
     rc = psam_gemm_f16x3p_ex(x1, a, s1, P(plan->o_w13), a, P(plan->o_s13), x2, a, plan->c13_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, h0, a, 1.f, 0, &f, stream);
     if (rc) return rc;
     if (parts > 1) { rc = psam_group_max(part1, h0, y1, h0, groups, parts, h0, stream); if (rc) return rc; }
-    if (groups >= 256) {      // the pooled half of conv2.0, one row per group
+    if (rows_multi_fits(groups, h0)) {      // the pooled half of conv2.0, one row per group: a cloud or two
+        rc = rows_linear(y1, h0, plan->c20_w, 2 * h0, plan->c20_b, g1, h1, groups, h1, h0, stream);
+    } else if (groups >= 256) {
         rc = psam_scale_pack_rows_g8(y1, h0, (int32_t)groups, h0, y1p, a, sy, stream);
         if (!rc) rc = psam_gemm_f16x3p_ex(y1p, a, sy, P(plan->o_w20m), a, P(plan->o_s20m), g1, h1, plan->c20_b, nullptr, 0, nullptr, 0, 0, (int32_t)groups, h1, a, 1.f, 0, nullptr, stream);
     } else if (groups <= 64) {      // the host's dispatch (point_sam_amd/ops.py linear): a handful of rows -> the skinny kernel
@@ -546,7 +566,9 @@ PSAM_API int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void*
     float* up = cv.take<float>(Z * N * a); float* s1 = cv.take<float>(Z * N);
     float* parts = cv.take<float>(planes * count);
     int32_t rc;
-    if (Z * G >= 256) {
+    if (rows_multi_fits(Z * G, E)) {
+        rc = rows_linear(keys, E, plan->u0_w, E, plan->u0_b, k1, E, Z * G, E, E, stream);
+    } else if (Z * G >= 256) {
         rc = psam_scale_pack_rows_g8(keys, E, (int32_t)(Z * G), E, kp, a, sk, stream);
         if (!rc) rc = psam_gemm_f16x3p_ex(kp, a, sk, P(plan->o_w0), a, P(plan->o_s0), k1, E, plan->u0_b, nullptr, 0, nullptr, 0, 0, (int32_t)(Z * G), E, a, 1.f, 0, nullptr, stream);
     } else if (Z * G <= 64) {
@@ -632,13 +654,25 @@ static const TwSide* tw_side(hipStream_t stream) {
 #ifdef PSAM_BUILD_EXPERIMENTS
 PSAM_API void psam_twoway_decoder_force_fork(int32_t mode) { g_tw_fork = mode; }
 #endif
+// The regrouped launch sequence of psam_twoway_decoder (see there): -1 = environment PSAM_TWOWAY_FAST (default on), 0 = the operator-by-operator
+// sequence, 1 = on.
+static int g_tw_fast = -1;
+PSAM_API void psam_twoway_decoder_force_fast(int32_t mode) { g_tw_fast = mode; }
+static int tw_fast_mode() {      // 0 operator sequence, 1 regrouped with packed-operand GEMMs on the patch side, 2 (default) regrouped with the exact-fp32 row kernel there
+    if (g_tw_fast >= 0) return g_tw_fast;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_TWOWAY_FAST"); on = e ? atoi(e) : 2; }
+    return on;
+}
+static bool tw_fast_enabled() { return tw_fast_mode() != 0; }
 
 PSAM_API size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample) {
     if (depth <= 0 || dim <= 0 || mlp <= 0 || downsample <= 0) return 0;
     const int64_t E = dim, IX = dim / downsample;
     auto one = [](int64_t n, int64_t k) { return align256(n * kpad((int)k) * 4) + align256(n * 4); };
     const int64_t self_attn = 4 * one(E, E), cross = 3 * one(IX, E) + one(E, IX), mlpb = one(mlp, E) + one(E, mlp);
-    return (size_t)(depth * (self_attn + 2 * cross + mlpb) + cross);
+    const int64_t cat = one(2 * IX, E) + align256(2 * IX * 4);      // [k of tokens -> patches | q of patches -> tokens] as one weight (they share their input rows)
+    return (size_t)(depth * (self_attn + 2 * cross + mlpb + cat) + cross);
 }
 
 PSAM_API int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* wt, psam_twoway_plan_t* plan, void* prepared, size_t prepared_bytes, hipStream_t stream) {
@@ -669,6 +703,21 @@ PSAM_API int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* wt, ps
         pack_attn(L.self_attn, E); pack_attn(L.t2i, IX); pack(L.m1_w, wt->mlp, E); pack(L.m2_w, E, wt->mlp); pack_attn(L.i2t, IX);
     }
     pack_attn(wt->final_attn, IX);
+    // k_proj of cross_attn_token_to_image and q_proj of cross_attn_image_to_token both read keys + key_pe (transformer.py:160-175): one [2 IX, E] weight
+    for (int i = 0; i < wt->depth && !rc; ++i) {
+        const psam_twoway_layer_weights_t& L = wt->layers[i];
+        const int kp = kpad(E);
+        float* p = cv.take<float>((int64_t)2 * IX * kp); float* sc = cv.take<float>(2 * IX); float* bc = cv.take<float>(2 * IX);
+        plan->o_cat_packed[i] = (char*)p - cv.base; plan->o_cat_scales[i] = (char*)sc - cv.base; plan->o_cat_bias[i] = (char*)bc - cv.base;
+        const float* ws_[2] = {L.t2i.k_w, L.i2t.q_w};
+        const float* bs_[2] = {L.t2i.k_b, L.i2t.q_b};
+        for (int h = 0; h < 2 && !rc; ++h) {
+            if (!ws_[h] || !bs_[h]) { psam_set_error("psam_twoway_decoder_prepare: null weight pointer"); rc = PSAM_EINVAL; break; }
+            rc = psam_row_scale_f16(ws_[h], E, IX, E, sc + h * IX, stream);
+            if (!rc) rc = psam_pack_rows_f16x2_g8(ws_[h], E, sc + h * IX, IX, E, p + (int64_t)h * IX * kp, kp, stream);
+            if (!rc && hipMemcpyAsync(bc + h * IX, bs_[h], (size_t)IX * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) { psam_set_error("psam_twoway_decoder_prepare: bias copy failed"); rc = PSAM_EINVAL; }
+        }
+    }
     if (!rc && hipStreamSynchronize(stream) != hipSuccess) { psam_set_error("psam_twoway_decoder_prepare: packing failed"); rc = PSAM_EINVAL; }
     return rc;
 }
@@ -677,7 +726,8 @@ PSAM_API size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, in
     if (Z <= 0 || T <= 0 || G <= 0 || dim <= 0 || mlp <= 0) return 0;
     const int64_t R = Z * T, I = Z * G, E = dim, big = R > I ? R : I, wide = mlp > E ? mlp : E;
     return (size_t)(6 * align256(R * E * 4) + align256(R * mlp * 4) + 6 * align256(I * E * 4) + align256(big * kpad((int)wide) * 4) + align256(big * 4) +
-                    align256(I * kpad((int)E) * 4) + align256(I * 4));      // + the packed keys + key_pe rows (shared by two projections per layer) and their scales
+                    align256(I * kpad((int)E) * 4) + align256(I * 4) +      // + the packed keys + key_pe rows (shared by two projections per layer) and their scales
+                    3 * align256(R * E * 4) + align256(8 * R * 256 * 4) + align256(I * kpad((int)E) * 4) + align256(I * 4));      // fast sequence: next projections, Linear + LN scratch, packed keys
 }
 
 // tokens [Z*T, dim] (output tokens + sparse prompt embeddings = the point embedding `query_pe`), keys [Z*G, dim] (src = image embedding + dense
@@ -706,6 +756,8 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
     float* ia = cv.take<float>(I * E); float* iy = cv.take<float>(I * E);
     float* pack_buf = cv.take<float>((R > I ? R : I) * kpad(mlp > E ? mlp : E)); float* scale_buf = cv.take<float>(R > I ? R : I);
     float* kin_p = cv.take<float>(I * kpad(E)); float* kin_s = cv.take<float>(I);
+    float* nq = cv.take<float>(R * E); float* nk = cv.take<float>(R * E); float* nv = cv.take<float>(R * E); float* lntmp = cv.take<float>(8 * R * 256);
+    float* kv_p = cv.take<float>(I * kpad(E)); float* kv_s = cv.take<float>(I);
     int32_t rc = PSAM_OK;
     // Round 4, fewer and wider launches with the same arithmetic (the same bits as the per-operator sequence the Python host issues):
     //  * token side (R <= 64 rows): the q / k / v projections of an attention are ONE psam_linear_skinny_multi launch, `queries + query_pe` is added
@@ -740,6 +792,128 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
                                          Lk, hd, 1.0f / std::sqrt((float)hd), stream);
         return r;
     };
+    // ---- Round 5: the short sequence (36 launches for depth 2 against 50; profiles/r05_click_kernels_*.txt).  Same operators, regrouped along their
+    // data dependences:
+    //  * every `queries = norm(queries + Linear(..))` of the token side is ONE launch (psam_linear_skinny_ln: the last workgroup of the Linear
+    //    normalises the rows; lin2 of the MLP, K = 2048, split over 8 workgroup rows instead of walking K in 16 dependent rounds);
+    //  * the token projections that read the layer's final `queries` -- k / v of patches -> tokens AND the next layer's self-attention q / k / v (or
+    //    the final attention's q) -- are one psam_linear_skinny_multi launch (the patch -> token attention in between only changes `keys`);
+    //  * patch side: keys + key_pe and keys are packed in one pass (psam_scale_pack_rows_g8_add_dual), the k projection of tokens -> patches and the
+    //    q projection of patches -> tokens are one GEMM on the concatenated weight (both read keys + key_pe).
+    // Needs the stream's arrival counters (not while a stream that never ran eagerly is being captured) and embedding_dim 256.
+    const bool fast = tok_fast && !sd && tw_fast_enabled() && E == 256 && IX >= 128 && 2 * IX <= E && IX <= 512 && I >= 256 && (mlp & 15) == 0 && (IX & 15) == 0 && plan->o_cat_packed[0] != 0 &&
+                      psam_stream_arrival_counters(stream) != nullptr;
+    if (fast) {
+        auto LS = [&](int sl, const float* w, const float* b, int n, int k) {
+            TwLin l{w, b, nullptr, nullptr, n, k};
+            if (n >= 128 && k >= 128) { l.packed = reinterpret_cast<const float*>(pb + plan->o_packed[sl]); l.scales = reinterpret_cast<const float*>(pb + plan->o_scales[sl]); }
+            return l;
+        };
+        auto multi = [&](int n, const TwLin* ls, const float* x, const float* const* xadds, float* const* ys) -> int32_t {
+            psam_skinny_jobs_t jobs;
+            std::memset(&jobs, 0, sizeof(jobs));
+            jobs.n = n;
+            for (int j = 0; j < n; ++j) { jobs.job[j].x = x; jobs.job[j].xadd = xadds[j]; jobs.job[j].W = ls[j].w; jobs.job[j].bias = ls[j].b; jobs.job[j].y = ys[j]; jobs.job[j].ldy = ls[j].N; jobs.job[j].N = ls[j].N; jobs.job[j].act = 0; }
+            return psam_linear_skinny_multi(&jobs, E, E, E, (int32_t)R, E, stream);
+        };
+        auto lin_ln = [&](const TwLin& l, const float* x, const float* res, const float* nw, const float* nb) -> int32_t {
+            return psam_linear_skinny_ln(x, l.K, l.w, l.K, l.b, res, E, nw, nb, W.eps, lntmp, queries, E, (int32_t)R, E, l.K, stream);
+        };
+        auto sattn = [&](int inner, const float* oq, int64_t ldq, const float* ok, int64_t ldk, const float* ov, int64_t ldv, float* out, int Lq, int Lk) -> int32_t {
+            return psam_attention_small(oq, ldq, Lq * ldq, ok, ldk, Lk * ldk, ov, ldv, Lk * ldv, out, inner, (int64_t)Lq * inner, Z, H, Lq, Lk, inner / H,
+                                        1.0f / std::sqrt((float)(inner / H)), stream);
+        };
+        const bool small_rows = tw_fast_mode() >= 2 && rows_multi_fits(I, E);
+        auto rows_multi = [&](int n, const TwLin* ls, const float* const* xadds, float* const* ys, const int64_t* ldys) -> int32_t {
+            psam_skinny_jobs_t jobs;
+            std::memset(&jobs, 0, sizeof(jobs));
+            jobs.n = n;
+            for (int j = 0; j < n; ++j) { jobs.job[j].x = keys; jobs.job[j].xadd = xadds[j]; jobs.job[j].W = ls[j].w; jobs.job[j].bias = ls[j].b; jobs.job[j].y = ys[j]; jobs.job[j].ldy = ldys[j]; jobs.job[j].N = ls[j].N; }
+            return psam_linear_rows_multi(&jobs, E, E, G, rep, E, I, E, stream);
+        };
+        auto dual_pack = [&]() -> int32_t { return psam_scale_pack_rows_g8_add_dual(keys, E, pos, E, G, rep, (int32_t)I, E, kin_p, kin_s, kv_p, kv_s, kpad(E), stream); };
+        float *aq = pq, *ak = pk, *av = pv;      // self-attention projections of the layer at hand
+        float *cqo = nq, *jko = nk, *jvo = nv;   // q of tokens -> patches (and of the final attention); k / v of patches -> tokens
+        {   // first layer: q = k = v = the tokens, no positional encoding (skip_first_layer_pe)
+            const psam_twoway_layer_weights_t& L0 = plan->layers[0];
+            const TwLin ls[3] = {LS(0, L0.self_attn.q_w, L0.self_attn.q_b, E, E), LS(1, L0.self_attn.k_w, L0.self_attn.k_b, E, E), LS(2, L0.self_attn.v_w, L0.self_attn.v_b, E, E)};
+            const float* xa[3] = {nullptr, nullptr, nullptr};
+            float* ys[3] = {aq, ak, av};
+            TWCK(multi(3, ls, tokens, xa, ys));
+        }
+        for (int i = 0; i < W.depth; ++i) {
+            const psam_twoway_layer_weights_t& Lw = plan->layers[i];
+            const int b0 = 14 * i;
+            const TwLin so = LS(b0 + 3, Lw.self_attn.o_w, Lw.self_attn.o_b, E, E);
+            const TwLin cq = LS(b0 + 4, Lw.t2i.q_w, Lw.t2i.q_b, IX, E), cvl = LS(b0 + 6, Lw.t2i.v_w, Lw.t2i.v_b, IX, E), co = LS(b0 + 7, Lw.t2i.o_w, Lw.t2i.o_b, E, IX);
+            const TwLin m1 = LS(b0 + 8, Lw.m1_w, Lw.m1_b, mlp, E), m2 = LS(b0 + 9, Lw.m2_w, Lw.m2_b, E, mlp);
+            const TwLin jk = LS(b0 + 11, Lw.i2t.k_w, Lw.i2t.k_b, IX, E), jv = LS(b0 + 12, Lw.i2t.v_w, Lw.i2t.v_b, IX, E), jo = LS(b0 + 13, Lw.i2t.o_w, Lw.i2t.o_b, E, IX);
+            const TwLin cat{nullptr, reinterpret_cast<const float*>(pb + plan->o_cat_bias[i]), reinterpret_cast<const float*>(pb + plan->o_cat_packed[i]),
+                            reinterpret_cast<const float*>(pb + plan->o_cat_scales[i]), 2 * IX, E};
+            // patch side: k of tokens -> patches | q of patches -> tokens (both from keys + key_pe; ik: row stride 2 IX) and v (from keys)
+            if (small_rows) {      // one launch, exact fp32 products, key_pe added on load
+                const TwLin ck = LS(b0 + 5, Lw.t2i.k_w, Lw.t2i.k_b, IX, E), jq = LS(b0 + 10, Lw.i2t.q_w, Lw.i2t.q_b, IX, E);
+                const TwLin ls[3] = {ck, jq, cvl};
+                const float* xa[3] = {pos, pos, nullptr};
+                float* ys[3] = {ik, ik + IX, iv};
+                const int64_t lds_[3] = {2 * IX, 2 * IX, IX};
+                TWCK(rows_multi(3, ls, xa, ys, lds_));
+            } else {               // both packed forms of the keys in one pass, [k | q] as one GEMM on the concatenated weight
+                TWCK(dual_pack());
+                TWCK(gemm_packed(cat, kin_p, kin_s, I, ik, stream));
+                TWCK(gemm_packed(cvl, kv_p, kv_s, I, iv, stream));
+            }
+            // self-attention of the tokens + norm1 (the first layer replaces the queries: no residual)
+            TWCK(sattn(E, aq, E, ak, E, av, E, ta, T, T));
+            TWCK(lin_ln(so, ta, i == 0 ? nullptr : queries, Lw.n1_w, Lw.n1_b));
+            // tokens attend to the patch tokens + norm2
+            {
+                const TwLin ls[1] = {cq};
+                const float* xa[1] = {tokens};
+                float* ys[1] = {cqo};
+                TWCK(multi(1, ls, queries, xa, ys));
+            }
+            TWCK(sattn(IX, cqo, IX, ik, 2 * IX, iv, IX, ta, T, G));
+            TWCK(lin_ln(co, ta, queries, Lw.n2_w, Lw.n2_b));
+            // token MLP + norm3
+            TWCK(psam_linear_skinny(queries, E, m1.w, E, m1.b, nullptr, 0, tm, mlp, (int32_t)R, mlp, E, PSAM_ACT_RELU, stream));
+            TWCK(lin_ln(m2, tm, queries, Lw.n3_w, Lw.n3_b));
+            // every projection of the finished queries: k / v of patches -> tokens, and what the NEXT attention of the token side needs
+            if (i + 1 < W.depth) {
+                const psam_twoway_layer_weights_t& Ln = plan->layers[i + 1];
+                const TwLin ls[5] = {jk, jv, LS(b0 + 14, Ln.self_attn.q_w, Ln.self_attn.q_b, E, E), LS(b0 + 15, Ln.self_attn.k_w, Ln.self_attn.k_b, E, E),
+                                     LS(b0 + 16, Ln.self_attn.v_w, Ln.self_attn.v_b, E, E)};
+                const float* xa[5] = {tokens, nullptr, tokens, tokens, nullptr};
+                float* ys[5] = {jko, jvo, aq, ak, av};
+                TWCK(multi(5, ls, queries, xa, ys));
+            } else {
+                const TwLin ls[3] = {jk, jv, LS(b0 + 14, W.final_attn.q_w, W.final_attn.q_b, IX, E)};
+                const float* xa[3] = {tokens, nullptr, tokens};
+                float* ys[3] = {jko, jvo, cqo};
+                TWCK(multi(3, ls, queries, xa, ys));
+            }
+            // patch tokens attend to the tokens + norm4
+            TWCK(sattn(IX, ik + IX, 2 * IX, jko, IX, jvo, IX, ia, G, T));
+            TWCK(psam_linear_ln256(ia, IX, jo.w, IX, jo.b, keys, E, Lw.n4_w, Lw.n4_b, W.eps, keys, E, I, E, IX, stream));      // out_proj + residual + norm4: one launch, 16 whole rows per workgroup
+        }
+        const int bf = 14 * W.depth;
+        const TwLin fk = LS(bf + 1, W.final_attn.k_w, W.final_attn.k_b, IX, E), fv = LS(bf + 2, W.final_attn.v_w, W.final_attn.v_b, IX, E),
+                    fo = LS(bf + 3, W.final_attn.o_w, W.final_attn.o_b, E, IX);
+        if (small_rows) {
+            const TwLin ls[2] = {fk, fv};
+            const float* xa[2] = {pos, nullptr};
+            float* ys[2] = {ik, iv};
+            const int64_t lds_[2] = {IX, IX};
+            TWCK(rows_multi(2, ls, xa, ys, lds_));
+        } else {
+            TWCK(dual_pack());
+            TWCK(gemm_packed(fk, kin_p, kin_s, I, ik, stream));
+            TWCK(gemm_packed(fv, kv_p, kv_s, I, iv, stream));
+        }
+        TWCK(sattn(IX, cqo, IX, ik, IX, iv, IX, ta, T, G));
+        TWCK(lin_ln(fo, ta, queries, W.nf_w, W.nf_b));
+        return PSAM_OK;
+    }
     const float* cur = tokens;      // queries start as the tokens themselves (transformer.py:84)
     for (int i = 0; i < W.depth; ++i) {
         const psam_twoway_layer_weights_t& Lw = plan->layers[i];

@@ -127,4 +127,9 @@ __device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float
     s = s + u;
     return s;
 }
+
+// Arrival counters for in-kernel "last workgroup finishes the job" fix-ups (split-K GEMM, skinny Linear + LayerNorm): a block of zeroed ints per
+// (device, stream), every launch leaves it zero; launches on one stream are ordered, so they may share words.  nullptr: the stream has no block yet
+// and is being captured (csrc/gemm_f16x3p.hip).
+int* psam_stream_arrival_counters(hipStream_t stream);
 #endif

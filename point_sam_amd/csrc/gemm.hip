@@ -249,22 +249,26 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
     const int row = wave * 16 + r, col = blockIdx.x * 16 + r;
     const float* xp = x + (int64_t)(row < M ? row : 0) * ldx + 4 * g;
     const float* wp = W + (int64_t)(col < N ? col : 0) * ldw + 4 * g;
-    const bool rok = row < M, cok = col < N;
+    const bool cok = col < N;
     sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     sk_f32x4 xa[SK_CH], wb[SK_CH], xn[SK_CH], wn[SK_CH];
+    // Loads are UNCONDITIONAL (rows / columns past the end read a clamped row and are never stored; a 16-k slot past K -- K % 16 == 0: inside or outside
+    // as a whole -- reads slot 0 and gets a zero weight): a load under a branch costs a full wait at the join, and the sixteen loads of a round became
+    // sixteen round trips (round 5: linear_skinny 5.6 -> see profiles/r05_click_kernels_*.txt).
     auto load = [&](sk_f32x4 (&xr)[SK_CH], sk_f32x4 (&wr)[SK_CH], int kc) {
 #pragma unroll
         for (int s = 0; s < SK_CH; ++s) {
-            const int k = kc + 16 * s;
-            const bool in = k < K;      // K % 16 == 0: a 16-k slot is inside or outside as a whole
-            xr[s] = (in && rok) ? *reinterpret_cast<const sk_f32x4*>(xp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
-            wr[s] = (in && cok) ? *reinterpret_cast<const sk_f32x4*>(wp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+            const int k = kc + 16 * s, kk = k < K ? k : 0;
+            xr[s] = *reinterpret_cast<const sk_f32x4*>(xp + kk);
+            wr[s] = *reinterpret_cast<const sk_f32x4*>(wp + kk);
+            if (k >= K) wr[s] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     load(xa, wb, 0);
     for (int kc = 0; kc < K; kc += 16 * SK_CH) {
         const bool more = kc + 16 * SK_CH < K;
         if (more) load(xn, wn, kc + 16 * SK_CH);
+        __builtin_amdgcn_sched_barrier(0);      // the loads of a round are all in flight before the MFMAs start waiting
 #pragma unroll
         for (int s = 0; s < SK_CH; ++s)
 #pragma unroll
@@ -304,18 +308,26 @@ __global__ __launch_bounds__(256) void linear_skinny_multi_kernel(const psam_ski
     const float* xp = jb.x + (int64_t)(row < M ? row : 0) * ldx + 4 * g;
     const float* xa = jb.xadd ? jb.xadd + (int64_t)(row < M ? row : 0) * ldxa + 4 * g : nullptr;
     const float* wp = jb.W + (int64_t)(col < N ? col : 0) * ldw + 4 * g;
-    const bool rok = row < M, cok = col < N;
+    const bool cok = col < N;
     sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     sk_f32x4 xr[SK_CH], wr[SK_CH];
     for (int kc = 0; kc < K; kc += 16 * SK_CH) {
 #pragma unroll
-        for (int s = 0; s < SK_CH; ++s) {
-            const int k = kc + 16 * s;
-            const bool in = k < K;
-            xr[s] = (in && rok) ? *reinterpret_cast<const sk_f32x4*>(xp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (xa && in && rok) xr[s] += *reinterpret_cast<const sk_f32x4*>(xa + k);
-            wr[s] = (in && cok) ? *reinterpret_cast<const sk_f32x4*>(wp + k) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < SK_CH; ++s) {      // unconditional loads, see linear_skinny_kernel
+            const int k = kc + 16 * s, kk = k < K ? k : 0;
+            xr[s] = *reinterpret_cast<const sk_f32x4*>(xp + kk);
+            wr[s] = *reinterpret_cast<const sk_f32x4*>(wp + kk);
+            if (k >= K) wr[s] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (xa) {      // one uniform branch around the addend's loads, all issued before the first addition waits
+            sk_f32x4 ad[SK_CH];
+#pragma unroll
+            for (int s = 0; s < SK_CH; ++s) { const int k = kc + 16 * s; ad[s] = *reinterpret_cast<const sk_f32x4*>(xa + (k < K ? k : 0)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < SK_CH; ++s) xr[s] += ad[s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < SK_CH; ++s)
 #pragma unroll
@@ -336,8 +348,101 @@ __global__ __launch_bounds__(256) void linear_skinny_multi_kernel(const psam_ski
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Several Linears over the same few hundred to few thousand input rows in ONE launch, exact fp32 products: the patch side of a decoder layer projects
+// its 512 rows per cloud three times (k of tokens -> patches and q of patches -> tokens from keys + key_pe, v from keys: transformer.py:160-175;
+// N = 128, K = 256).  As packed-operand GEMMs that was a packing pass and two or three launches of 8-10 us each (tiles of 128 rows: four to eight
+// workgroups, all latency); here a workgroup owns 32 rows x 32 columns of one job (wave: one 16 x 16 tile, v_mfma_f32_16x16x4_f32 as in
+// linear_skinny_kernel), grid = (rows / 32, columns / 32, jobs) -- 192 workgroups for the three projections of one cloud --, the positional addend
+// (broadcast over `rep` row sets) is added while the rows are loaded, and K runs in double-buffered rounds of 128.
+// ------------------------------------------------------------------------------------------------
+template <bool FULL>      // FULL: K % 128 == 0 -- every load of a round is inside K, none sits under a condition (a load under a branch makes the compiler wait for it at the join)
+__global__ __launch_bounds__(256) void linear_rows_multi_kernel(const psam_skinny_jobs_t jobs, int64_t ldx, int64_t ldxa, int rows_per_set, int rep, int64_t ldw,
+                                                                int M, int K) {
+    const psam_skinny_job_t jb = jobs.job[blockIdx.z];
+    const int N = jb.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 32 + (wave & 1) * 16, col0 = blockIdx.y * 32 + (wave >> 1) * 16;
+    if (row0 >= M || col0 >= N) return;      // wave-uniform
+    const int row = row0 + r < M ? row0 + r : M - 1, colc = col0 + r < N ? col0 + r : N - 1;
+    const float* xp = jb.x + (int64_t)row * ldx + 4 * g;
+    const float* xa = jb.xadd ? jb.xadd + ((int64_t)(row / (rep * rows_per_set)) * rows_per_set + row % rows_per_set) * ldxa + 4 * g : nullptr;
+    const float* wp = jb.W + (int64_t)colc * ldw + 4 * g;
+    sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    sk_f32x4 xr[SK_CH], wr[SK_CH], xn[SK_CH], wn[SK_CH];
+    auto load = [&](sk_f32x4 (&xv)[SK_CH], sk_f32x4 (&wv)[SK_CH], int kc) {
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s) {
+            const int k = kc + 16 * s;
+            const int kk = FULL || k < K ? k : 0;      // K % 16 == 0: a 16-k slot is inside or outside as a whole; outside: any address, the weight is zeroed
+            xv[s] = *reinterpret_cast<const sk_f32x4*>(xp + kk);
+            wv[s] = *reinterpret_cast<const sk_f32x4*>(wp + kk);
+            if (!FULL && k >= K) wv[s] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (xa) {      // one uniform branch around the eight addend loads, all issued before the first addition waits
+            sk_f32x4 ad[SK_CH];
+#pragma unroll
+            for (int s = 0; s < SK_CH; ++s) { const int k = kc + 16 * s; ad[s] = *reinterpret_cast<const sk_f32x4*>(xa + (FULL || k < K ? k : 0)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < SK_CH; ++s) xv[s] += ad[s];
+        }
+    };
+    load(xr, wr, 0);
+    for (int kc = 0; kc < K; kc += 16 * SK_CH) {
+        const bool more = kc + 16 * SK_CH < K;
+        if (more) load(xn, wn, kc + 16 * SK_CH);
+        __builtin_amdgcn_sched_barrier(0);      // the next round's loads are all in flight before this round's MFMAs start
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[s][e], wr[s][e], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < SK_CH; ++s) { xr[s] = xn[s]; wr[s] = wn[s]; }
+        }
+    }
+    // D layout: lane holds rows 4g .. 4g+3 of the wave's 16, column r
+    const int col = col0 + r;
+    if (col < N) {
+        const float bv = jb.bias ? jb.bias[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int orow = row0 + 4 * g + v;
+            if (orow < M) {
+                float val = acc[v] + bv;
+                if (jb.act == 1) val = gelu_erf(val);
+                else if (jb.act == 2) val = fmaxf(val, 0.f);
+                jb.y[(int64_t)orow * jb.ldy + col] = val;
+            }
+        }
+    }
+}
+
+// jobs->n Linears y_i [M, N_i] = act_i((x_i + xadd_i[broadcast]) W_i^T + bias_i) over the same M rows in one launch (any M; K % 16 == 0), exact fp32
+// products.  xadd_i (optional) has rows_per_set-row sets, set (row / (rep * rows_per_set)) is added to row `row`: the decoder's key_pe, shared by the
+// `rep` prompt sets of a cloud.
+PSAM_API int32_t psam_linear_rows_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int64_t ldxadd, int32_t rows_per_set, int32_t rep, int64_t ldw, int64_t M, int32_t K,
+                                        hipStream_t stream) {
+    PSAM_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= PSAM_SKINNY_MAX_JOBS, PSAM_EINVAL, "psam_linear_rows_multi: one to PSAM_SKINNY_MAX_JOBS jobs");
+    PSAM_REQUIRE(M > 0 && M < ((int64_t)1 << 31) - 32 && K > 0 && (K & 15) == 0 && ((ldx | ldw | ldxadd) & 3) == 0 && rows_per_set > 0 && rep > 0, PSAM_EINVAL,
+                 "psam_linear_rows_multi: need M > 0, K % 16 == 0, rows 16-byte aligned");
+    int nmax = 0;
+    for (int i = 0; i < jobs->n; ++i) {
+        const psam_skinny_job_t& j = jobs->job[i];
+        PSAM_REQUIRE(j.x && j.W && j.y && j.N > 0 && j.act >= 0 && j.act <= 2, PSAM_EINVAL, "psam_linear_rows_multi: bad job");
+        PSAM_REQUIRE((((uintptr_t)j.x | (uintptr_t)j.W | (uintptr_t)j.xadd) & 15) == 0, PSAM_EALIGN, "psam_linear_rows_multi: rows must be 16-byte aligned");
+        nmax = j.N > nmax ? j.N : nmax;
+    }
+    const dim3 grid((unsigned)psam_cdiv(M, 32), (unsigned)psam_cdiv(nmax, 32), (unsigned)jobs->n);
+    if ((K & 127) == 0) hipLaunchKernelGGL(linear_rows_multi_kernel<true>, grid, dim3(256), 0, stream, *jobs, ldx, ldxadd, rows_per_set, rep, ldw, (int)M, K);
+    else hipLaunchKernelGGL(linear_rows_multi_kernel<false>, grid, dim3(256), 0, stream, *jobs, ldx, ldxadd, rows_per_set, rep, ldw, (int)M, K);
+    return psam_launch_status("psam_linear_rows_multi: launch failed");
+}
+
 PSAM_API int32_t psam_linear_skinny_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int64_t ldxadd, int64_t ldw, int32_t M, int32_t K, hipStream_t stream) {
-    PSAM_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= 3, PSAM_EINVAL, "psam_linear_skinny_multi: one to three jobs");
+    PSAM_REQUIRE(jobs && jobs->n >= 1 && jobs->n <= PSAM_SKINNY_MAX_JOBS, PSAM_EINVAL, "psam_linear_skinny_multi: one to PSAM_SKINNY_MAX_JOBS jobs");
     PSAM_REQUIRE(M > 0 && M <= 64 && K > 0 && (K & 15) == 0 && ((ldx | ldw | ldxadd) & 3) == 0, PSAM_EINVAL, "psam_linear_skinny_multi: need 0 < M <= 64, K % 16 == 0, rows 16-byte aligned");
     int nmax = 0;
     for (int i = 0; i < jobs->n; ++i) {
@@ -348,6 +453,184 @@ PSAM_API int32_t psam_linear_skinny_multi(const psam_skinny_jobs_t* jobs, int64_
     }
     hipLaunchKernelGGL(linear_skinny_multi_kernel, dim3((unsigned)psam_cdiv(nmax, 16), (unsigned)jobs->n), dim3(256), 0, stream, *jobs, ldx, ldxadd, ldw, M, K);
     return psam_launch_status("psam_linear_skinny_multi: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny Linear + residual + LayerNorm in ONE launch: the token side of the two-way decoder ends every attention and its MLP with
+// `queries = norm(queries + out_proj(a))` / `norm3(queries + lin2(relu(lin1 queries)))` (transformer.py:153-176) on <= 64 rows of 256 columns -- two
+// launches of ~5 us each whose second one only waits for the first, and for lin2 (K = 2048) a Linear whose 16 workgroups walk K in 16 dependent
+// load rounds (23 us).  Here grid = (16 column blocks, ksplit K ranges): every workgroup does the arithmetic of linear_skinny_kernel on its K range
+// (one or two load rounds), parks its 16 columns in `tmp` with device-coherent stores (sc1: written through the XCD's L2), counts itself in, and the
+// LAST workgroup to arrive adds the ksplit partials in fixed order, the bias and the residual and normalises the rows (a wave per row, float4 per
+// lane: the arithmetic of layernorm_v4_kernel<1>) -- the in-kernel fix-up of the split-K GEMM (gemm_f16x3p.hip) applied to a row operation.  The
+// counter is left at zero for the next launch.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_skinny_ln_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                                                               const float* __restrict__ bias, const float* __restrict__ res, int64_t ldr,
+                                                               const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, float* __restrict__ tmp,
+                                                               float* __restrict__ y, int64_t ldy, int M, int K, int kper, int* __restrict__ counter) {
+    constexpr int N = 256, SC1 = 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int row = wave * 16 + r, col = blockIdx.x * 16 + r;
+    const int k0 = blockIdx.y * kper, k1 = k0 + kper < K ? k0 + kper : K;
+    const float* xp = x + (int64_t)(row < M ? row : 0) * ldx + 4 * g;
+    const float* wp = W + (int64_t)col * ldw + 4 * g;
+    sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    sk_f32x4 xr[SK_CH], wr[SK_CH];
+    for (int kc = k0; kc < k1; kc += 16 * SK_CH) {
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s) {      // unconditional loads, see linear_skinny_kernel
+            const int k = kc + 16 * s, kk = k < k1 ? k : k0;
+            xr[s] = *reinterpret_cast<const sk_f32x4*>(xp + kk);
+            wr[s] = *reinterpret_cast<const sk_f32x4*>(wp + kk);
+            if (k >= k1) wr[s] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[s][e], wr[s][e], acc, 0, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tmp, 0, 0x7fffffff, 0x00020000);
+    const int plane = M * N;      // floats per K range
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int orow = wave * 16 + 4 * g + v;
+        const float av = acc[v];      // (into a float first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 every time)
+        if (orow < M) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, av), rs, ((int)blockIdx.y * plane + orow * N + col) * 4, 0, SC1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's columns are acknowledged by the memory side
+    __shared__ int flag;
+    __syncthreads();
+    if (threadIdx.x == 0) flag = (int)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag != (int)(gridDim.x * gridDim.y) - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
+    const float inv = 1.0f / (float)N;
+    const sk_f32x4 w4 = *reinterpret_cast<const sk_f32x4*>(lnw + lane * 4), b4 = *reinterpret_cast<const sk_f32x4*>(lnb + lane * 4);
+    const sk_f32x4 bv = bias ? *reinterpret_cast<const sk_f32x4*>(bias + lane * 4) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ksplit = (int)gridDim.y;
+    for (int orow = wave; orow < M; orow += 4) {
+        sk_f32x4 v = __builtin_bit_cast(sk_f32x4, (sk_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (orow * N + lane * 4) * 4, 0, SC1));
+        for (int ks = 1; ks < ksplit; ++ks)
+            v += __builtin_bit_cast(sk_f32x4, (sk_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (ks * plane + orow * N + lane * 4) * 4, 0, SC1));
+        v += bv;
+        if (res) v += *reinterpret_cast<const sk_f32x4*>(res + (int64_t)orow * ldr + lane * 4);
+        const float s = (v[0] + v[1]) + (v[2] + v[3]);
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+        const sk_f32x4 o = (v - mean) * rstd * w4 + b4;
+        *reinterpret_cast<sk_f32x4*>(y + (int64_t)orow * ldy + lane * 4) = o;
+    }
+}
+
+// K ranges of psam_linear_skinny_ln: one per 256 k (two load rounds), at most 8
+static int skinny_ln_ksplit(int K) { const int s = (K + 255) / 256; return s < 1 ? 1 : (s > 8 ? 8 : s); }
+PSAM_API size_t psam_linear_skinny_ln_tmp_floats(int32_t M, int32_t K) { return M > 0 && K > 0 ? (size_t)skinny_ln_ksplit(K) * (size_t)M * 256 : 0; }
+
+// y [M, 256] = LayerNorm_256(x [M, K] W [256, K]^T + bias + residual) * ln_w + ln_b for M <= 64 rows (residual optional, may alias y), one launch.
+// tmp: psam_linear_skinny_ln_tmp_floats(M, K) floats of scratch.  The arrival counter is the stream's (psam_stream_arrival_counters): refused
+// (PSAM_EINVAL) when the stream has none yet and is being captured (psam_stream_has_arrival_counters tells) -- the caller then issues
+// psam_linear_skinny + psam_layernorm.
+PSAM_API int32_t psam_linear_skinny_ln(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
+                                       const float* ln_w, const float* ln_b, float eps, float* tmp, float* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                                       hipStream_t stream) {
+    PSAM_REQUIRE(x && W && y && ln_w && ln_b && tmp, PSAM_EINVAL, "psam_linear_skinny_ln: null pointer");
+    PSAM_REQUIRE(M > 0 && M <= 64 && N == 256 && K > 0 && (K & 15) == 0, PSAM_EINVAL, "psam_linear_skinny_ln: need 0 < M <= 64, N == 256, K % 16 == 0");
+    PSAM_REQUIRE(((ldx | ldw | ldy | (residual ? ldr : 0)) & 3) == 0 &&
+                     (((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)tmp | (uintptr_t)bias) & 15) == 0,
+                 PSAM_EALIGN, "psam_linear_skinny_ln: rows must be 16-byte aligned");
+    int* counter = psam_stream_arrival_counters(stream);
+    PSAM_REQUIRE(counter, PSAM_EINVAL, "psam_linear_skinny_ln: the stream has no arrival counters yet and is being captured");
+    const int ksplit = skinny_ln_ksplit(K);
+    const int kper = ((K + ksplit - 1) / ksplit + 15) & ~15;
+    hipLaunchKernelGGL(linear_skinny_ln_kernel, dim3(N / 16, ksplit), dim3(256), 0, stream, x, ldx, W, ldw, bias, residual, ldr, ln_w, ln_b, eps, tmp, y, ldy, M, K, kper,
+                       counter);
+    return psam_launch_status("psam_linear_skinny_ln: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear (K small) + residual + LayerNorm over MANY rows of 256 columns in one launch: `keys = norm4(keys + out_proj(attn))` of the decoder's patch
+// side (transformer.py:170-175: 512 rows per cloud, K = 128) was pack + packed GEMM + LayerNorm = three launches of 5 + 8 + 5 us.  Here a workgroup
+// owns 16 whole rows: wave w of eight computes columns 32 w .. 32 w + 31 (two 16 x 16 tiles, v_mfma_f32_16x16x4_f32: exact fp32 products as in
+// linear_skinny_kernel), the tile is staged in LDS and every wave normalises two of the rows (float4 per lane, the arithmetic of
+// layernorm_v4_kernel<1>).  The weight (K * 1 KiB) is read once per 16 rows, from L2.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void linear_ln256_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                                                           const float* __restrict__ bias, const float* __restrict__ res, int64_t ldr,
+                                                           const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, float* __restrict__ y,
+                                                           int64_t ldy, int M, int K) {
+    constexpr int N = 256, LD = N + 4;
+    __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;      // 8 waves: wave w owns columns 32 w .. 32 w + 31
+    const int row0 = blockIdx.x * 16, row = row0 + r;
+    const float* xp = x + (int64_t)(row < M ? row : M - 1) * ldx + 4 * g;
+    const float* wp = W + (int64_t)(wave * 32 + r) * ldw + 4 * g;
+    sk_f32x4 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < K; kc += 16 * SK_CH) {
+        sk_f32x4 xr[SK_CH], wr[2][SK_CH];
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s) {
+            const int k = kc + 16 * s;
+            const int kk = k < K ? k : 0;      // unconditional loads (K % 16 == 0: a 16-k slot is inside or outside as a whole; outside: the weight is zeroed)
+            xr[s] = *reinterpret_cast<const sk_f32x4*>(xp + kk);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                wr[t][s] = *reinterpret_cast<const sk_f32x4*>(wp + (int64_t)t * 16 * ldw + kk);
+                if (k >= K) wr[t][s] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // all 24 loads of the round are issued before the first MFMA waits (left alone, the scheduler interleaves three loads, a full wait, eight MFMAs: eight round trips)
+#pragma unroll
+        for (int s = 0; s < SK_CH; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[s][e], wr[t][s][e], acc[t], 0, 0, 0);
+    }
+    // D layout: lane holds rows 4g .. 4g+3, column r of each 16-column tile
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s_t[(4 * g + v) * LD + wave * 32 + t * 16 + r] = acc[t][v];
+    __syncthreads();
+    const float inv = 1.0f / (float)N;
+    const sk_f32x4 w4 = *reinterpret_cast<const sk_f32x4*>(lnw + lane * 4), b4 = *reinterpret_cast<const sk_f32x4*>(lnb + lane * 4);
+    const sk_f32x4 bv = bias ? *reinterpret_cast<const sk_f32x4*>(bias + lane * 4) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = wave * 2 + i, orow = row0 + lr;
+        if (orow >= M) break;      // wave-uniform
+        sk_f32x4 v = *reinterpret_cast<const sk_f32x4*>(s_t + lr * LD + lane * 4);
+        v += bv;
+        if (res) v += *reinterpret_cast<const sk_f32x4*>(res + (int64_t)orow * ldr + lane * 4);
+        const float sm = (v[0] + v[1]) + (v[2] + v[3]);
+        const float mean = wave_sum(sm) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+        const sk_f32x4 o = (v - mean) * rstd * w4 + b4;
+        *reinterpret_cast<sk_f32x4*>(y + (int64_t)orow * ldy + lane * 4) = o;
+    }
+}
+
+// y [M, 256] = LayerNorm_256(x [M, K] W [256, K]^T + bias + residual) * ln_w + ln_b for any M (residual optional, may alias y), K % 16 == 0, K <= 512.
+PSAM_API int32_t psam_linear_ln256(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
+                                   const float* ln_w, const float* ln_b, float eps, float* y, int64_t ldy, int64_t M, int32_t N, int32_t K, hipStream_t stream) {
+    PSAM_REQUIRE(x && W && y && ln_w && ln_b, PSAM_EINVAL, "psam_linear_ln256: null pointer");
+    PSAM_REQUIRE(M > 0 && M < ((int64_t)1 << 31) - 16 && N == 256 && K > 0 && K <= 512 && (K & 15) == 0, PSAM_EINVAL, "psam_linear_ln256: need N == 256, K % 16 == 0, K <= 512");
+    PSAM_REQUIRE(((ldx | ldw | ldy | (residual ? ldr : 0)) & 3) == 0 &&
+                     (((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)bias) & 15) == 0,
+                 PSAM_EALIGN, "psam_linear_ln256: rows must be 16-byte aligned");
+    hipLaunchKernelGGL(linear_ln256_kernel, dim3((unsigned)psam_cdiv(M, 16)), dim3(512), 0, stream, x, ldx, W, ldw, bias, residual, ldr, ln_w, ln_b, eps, y, ldy, (int)M, K);
+    return psam_launch_status("psam_linear_ln256: launch failed");
 }
 
 // y [M, N] = act(x [M, K] W [N, K]^T + bias) + residual for M <= 64, K % 16 == 0, 16-byte aligned rows (ld % 4 == 0).

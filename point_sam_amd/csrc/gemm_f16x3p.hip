@@ -474,6 +474,48 @@ PSAM_API int32_t psam_scale_pack_rows_g8_add(const float* X, int64_t ldx, const 
     return psam_launch_status("psam_scale_pack_rows_g8_add: launch failed");
 }
 
+// Both packed forms of the decoder's patch rows in one pass: P_sum / scale_sum = the rows of X + add (k = keys + key_pe, the A operand of the k / q
+// projections), P_x / scale_x = the rows of X alone (the A operand of the v projection) -- transformer.py:160-170.  K <= 256: a float4 per lane.
+__global__ __launch_bounds__(256) void scale_pack_rows_g8_dual_kernel(const float* __restrict__ X, int64_t ldx, int rows, int K, const float* __restrict__ add,
+                                                                      int64_t ldadd, int rows_per_set, int rep, unsigned* __restrict__ Ps, float* __restrict__ ss,
+                                                                      unsigned* __restrict__ Px, float* __restrict__ sx, int64_t ldp) {
+    typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int row = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6);
+    if (row >= rows) return;
+    const int c4n = K >> 2, c = lane < c4n ? lane : c4n - 1;
+    sp_f32x4 x = reinterpret_cast<const sp_f32x4*>(X + (int64_t)row * ldx)[c];
+    sp_f32x4 v = reinterpret_cast<const sp_f32x4*>(add + ((int64_t)(row / (rep * rows_per_set)) * rows_per_set + row % rows_per_set) * ldadd)[c] + x;
+    if (lane >= c4n) { x = sp_f32x4{0.f, 0.f, 0.f, 0.f}; v = x; }
+    const float scs = f16_row_scale(wave_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
+    const float scx = f16_row_scale(wave_max(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])))));
+    if (lane == 0) { ss[row] = scs; sx[row] = scx; }
+    const int klim = (K + 31) & ~31;
+    const bool odd = lane & 1;
+    auto put = [&](const sp_f32x4& t, float sc, unsigned* prow) {
+        unsigned h0, l0, h1, l1;
+        psam_split2_f16(t[0], t[1], sc, h0, l0);
+        psam_split2_f16(t[2], t[3], sc, h1, l1);
+        const unsigned r0 = __shfl_xor(odd ? h0 : l0, 1, 64), r1 = __shfl_xor(odd ? h1 : l1, 1, 64);
+        if (lane * 4 < klim) *reinterpret_cast<pu32x4*>(prow + lane * 4) = odd ? pu32x4{r0, r1, l0, l1} : pu32x4{h0, h1, r0, r1};
+    };
+    put(v, scs, Ps + (int64_t)row * ldp);
+    put(x, scx, Px + (int64_t)row * ldp);
+}
+
+PSAM_API int32_t psam_scale_pack_rows_g8_add_dual(const float* X, int64_t ldx, const float* add, int64_t ldadd, int32_t rows_per_set, int32_t rep, int32_t rows, int32_t K,
+                                                  void* P_sum, float* scale_sum, void* P_x, float* scale_x, int64_t ldp, hipStream_t stream) {
+    PSAM_REQUIRE(X && add && P_sum && scale_sum && P_x && scale_x, PSAM_EINVAL, "psam_scale_pack_rows_g8_add_dual: null pointer");
+    const int Kp = (K + 31) / 32 * 32;
+    PSAM_REQUIRE(rows > 0 && K > 0 && K <= 256 && (K & 3) == 0 && ldx >= K && ldadd >= K && ldp >= Kp && rows_per_set > 0 && rep > 0, PSAM_EINVAL,
+                 "psam_scale_pack_rows_g8_add_dual: bad shape (K % 4 == 0, K <= 256, ldp >= K rounded up to 32)");
+    PSAM_REQUIRE(((ldx | ldadd) & 3) == 0 && (((uintptr_t)X | (uintptr_t)add) & 15) == 0 && (ldp & 7) == 0 && (((uintptr_t)P_sum | (uintptr_t)P_x) & 31) == 0, PSAM_EALIGN,
+                 "psam_scale_pack_rows_g8_add_dual: rows of X / add 16-byte, of the packed outputs 32-byte aligned");
+    hipLaunchKernelGGL(scale_pack_rows_g8_dual_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, K, add, ldadd, rows_per_set, rep,
+                       (unsigned*)P_sum, scale_sum, (unsigned*)P_x, scale_x, ldp);
+    return psam_launch_status("psam_scale_pack_rows_g8_add_dual: launch failed");
+}
+
 // ---------------------------------------------------------------------------------------------- host
 static int g_f16x3p_cfg = -1;
 PSAM_API void psam_gemm_f16x3p_force_config(int32_t cfg) { g_f16x3p_cfg = cfg; }
@@ -634,6 +676,9 @@ static bool f16x3p_splitk_fixup_enabled() {
     return on != 0;
 }
 PSAM_API void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode) { g_f16x3p_sk_fixup = mode; }
+static int* f16x3p_sk_counters(hipStream_t stream);
+int* psam_stream_arrival_counters(hipStream_t stream) { return f16x3p_sk_counters(stream); }
+PSAM_API int32_t psam_stream_has_arrival_counters(hipStream_t stream) { return f16x3p_sk_counters(stream) != nullptr; }
 static int* f16x3p_sk_counters(hipStream_t stream) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, int*> table;

@@ -753,6 +753,71 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     }
 }
 
+// Few queries against many keys (the decoder's 7-10 tokens x 8 heads against 512 patch tokens: 72 waves in attention_small_kernel, each walking all
+// 512 keys twice -- 19.6 us): one WORKGROUP per (batch, head, query), wave w takes the keys [w * per, (w + 1) * per); every wave runs the softmax and the
+// value sum of its keys relative to its own maximum (the code of attention_small_kernel), the four (max, sum, value) partials meet in LDS and wave 0
+// combines them in fixed order.  Head dims with hd % 4 == 0, hd <= 64, 64 % (hd / 4) == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void attention_small_split_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq, const float* __restrict__ k,
+                                                                    int64_t ldk, int64_t sk, const float* __restrict__ v, int64_t ldv, int64_t sv,
+                                                                    float* __restrict__ out, int64_t ldo, int64_t so, int H, int Lq, int Lk, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float s_p[];  // [Lk] probabilities, then [4][2 + 64] partials
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wv = blockIdx.x;
+    const int qi = (int)(wv % Lq);
+    const int hh = (int)((wv / Lq) % H);
+    const int64_t z = wv / ((int64_t)Lq * H);
+    const float* qp = q + z * sq + (int64_t)qi * ldq + hh * hd;
+    const float* kp = k + z * sk + hh * hd;
+    const float* vp = v + z * sv + hh * hd;
+    float* part = s_p + ((Lk + 3) & ~3) + wave * 68;
+    const int per = (Lk + 3) >> 2, j0 = wave * per, j1 = j0 + per < Lk ? j0 + per : Lk;
+    float m = -INFINITY;
+    for (int j = j0 + lane; j < j1; j += 64) {
+        const float* kr = kp + (int64_t)j * ldk;
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + d), b = *reinterpret_cast<const float4*>(kr + d);
+            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+        s *= scale;
+        s_p[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = j0 + lane; j < j1; j += 64) { const float e = __expf(s_p[j] - m); s_p[j] = e; l += e; }
+    l = wave_sum(l);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int hd4 = hd >> 2, ng = 64 / hd4, c4 = lane % hd4, grp = lane / hd4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = j0 + grp; j < j1; j += ng) {
+        const float pj = s_p[j];
+        const float4 vv = *reinterpret_cast<const float4*>(vp + (int64_t)j * ldv + c4 * 4);
+        acc.x = fmaf(pj, vv.x, acc.x); acc.y = fmaf(pj, vv.y, acc.y); acc.z = fmaf(pj, vv.z, acc.z); acc.w = fmaf(pj, vv.w, acc.w);
+    }
+    for (int o = 32; o >= hd4; o >>= 1) {      // add the key groups (lanes hd4 apart), fixed order
+        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (lane == 0) { part[0] = m; part[1] = l; }
+    if (grp == 0) *reinterpret_cast<float4*>(part + 4 + c4 * 4) = acc;
+    __syncthreads();
+    if (wave != 0 || lane >= hd4) return;
+    const float* p0 = s_p + ((Lk + 3) & ~3);
+    float mm = fmaxf(fmaxf(p0[0], p0[68]), fmaxf(p0[136], p0[204]));
+    float lt = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float f = __expf(p0[w * 68] - mm);      // a wave without keys: exp(-inf) = 0
+        const float4 a = *reinterpret_cast<const float4*>(p0 + w * 68 + 4 + lane * 4);
+        lt = fmaf(f, p0[w * 68 + 1], lt);
+        o.x = fmaf(f, a.x, o.x); o.y = fmaf(f, a.y, o.y); o.z = fmaf(f, a.z, o.z); o.w = fmaf(f, a.w, o.w);
+    }
+    const float invl = 1.0f / lt;
+    *reinterpret_cast<float4*>(out + z * so + (int64_t)qi * ldo + hh * hd + lane * 4) = make_float4(o.x * invl, o.y * invl, o.z * invl, o.w * invl);
+}
+
 template <int HD4>   // head dim / 4
 __global__ __launch_bounds__(256) void attention_fewkeys_kernel(const float* __restrict__ q, int64_t ldq, int64_t sq, const float* __restrict__ k,
                                                                 int64_t ldk, int64_t sk, const float* __restrict__ v, int64_t ldv, int64_t sv,
@@ -805,6 +870,8 @@ __global__ __launch_bounds__(256) void attention_fewkeys_kernel(const float* __r
     for (int d = 0; d < HD4; ++d) *reinterpret_cast<float4*>(op + 4 * d) = make_float4(acc[d].x * invl, acc[d].y * invl, acc[d].z * invl, acc[d].w * invl);
 }
 
+static int g_attn_small_split = 1;      // test / A-B hook: 0 = always one wave per query
+PSAM_API void psam_attention_small_force_split(int32_t on) { g_attn_small_split = on; }
 PSAM_API int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v,
                                       int64_t ldv, int64_t sv, float* out, int64_t ldo, int64_t so, int64_t Z, int32_t H, int32_t Lq, int32_t Lk,
                                       int32_t hd, float scale, hipStream_t stream) {
@@ -818,6 +885,11 @@ PSAM_API int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, c
         return psam_launch_status("psam_attention_small: launch failed");
     }
     const int64_t waves = Z * H * Lq;
+    if (g_attn_small_split && Lk >= 128 && waves <= 2048 && aligned && (hd & 3) == 0 && hd <= 64 && (64 % (hd >> 2)) == 0) {      // few queries, many keys: a workgroup per query
+        hipLaunchKernelGGL(attention_small_split_kernel, dim3((unsigned)waves), dim3(256), (size_t)(((Lk + 3) & ~3) + 4 * 68) * 4, stream, q, ldq, sq, k, ldk, sk, v, ldv,
+                           sv, out, ldo, so, H, Lq, Lk, hd, scale);
+        return psam_launch_status("psam_attention_small: launch failed");
+    }
     hipLaunchKernelGGL(attention_small_kernel, dim3((unsigned)psam_cdiv(waves, 4)), dim3(256), (size_t)Lk * 16, stream, q, ldq, sq, k, ldk, sk, v,
                        ldv, sv, out, ldo, so, Z, H, Lq, Lk, hd, scale);
     return psam_launch_status("psam_attention_small: launch failed");
@@ -832,40 +904,50 @@ PSAM_API int32_t psam_attention_small(const float* q, int64_t ldq, int64_t sq, c
 // wave-private LDS transpose (lane o sums row o: fixed order).  (A thread-per-output version over transposed weights was a chain of
 // dependent loads: 59 us per launch.)  MLP m of a stack reads x + z*ldx + m*sx and uses the m-th [out][in] matrix of each weight.
 // ------------------------------------------------------------------------------------------------
-constexpr int MLP3_MAXD = 1024, MLP3_OB = 32;
-__global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ x, int64_t ldx, int64_t sx, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                   const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ out, int64_t ldo,
-                                                   int64_t so, int din, int dh, int dout) {
+constexpr int MLP3_MAXD = 1024, MLP3_OB = 16, MLP3_NW = 16;      // 16 waves x 16 outputs: a 256-wide layer is ONE round of 16 loads per lane (round 5; before: four waves x 32 outputs, two rounds per layer, 256 registers + 54 spilled)
+__device__ __forceinline__ void mlp3_body(const float* __restrict__ x, int64_t ldx, int64_t sx, const float* __restrict__ w1,
+                                          const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                          const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ out, int64_t ldo,
+                                          int64_t so, int din, int dh, int dout, int z, int m) {
     __shared__ __attribute__((aligned(16))) float s_a[MLP3_MAXD], s_b[MLP3_MAXD];
-    __shared__ float s_red[4][MLP3_OB][65];
-    const int z = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_red[MLP3_NW][MLP3_OB][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xp = x + (int64_t)z * ldx + (int64_t)m * sx;
-    for (int i = tid; i < MLP3_MAXD; i += 256) s_a[i] = i < din ? xp[i] : 0.f;
+    for (int i = tid; i < MLP3_MAXD; i += 64 * MLP3_NW) s_a[i] = i < din ? xp[i] : 0.f;
     __syncthreads();
     auto layer = [&](const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ W, const float* __restrict__ b, int ni, int no,
                      bool relu) {
-        for (int ob = wave * MLP3_OB; ob < no; ob += 4 * MLP3_OB) {
+        for (int ob = wave * MLP3_OB; ob < no; ob += MLP3_NW * MLP3_OB) {
             float part[MLP3_OB];
 #pragma unroll
             for (int o = 0; o < MLP3_OB; ++o) part[o] = 0.f;
+            // buffer loads: the row offset is a scalar, the lane's k offset the one address register of all MLP3_OB loads; rows past `no` read as
+            // zero (bounds check of the resource), k past `ni` meets a zero of the input (LDS holds zeros beyond ni)
+            typedef unsigned m3_u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, no * ni * 4, 0x00020000);
+            const int obu = __builtin_amdgcn_readfirstlane(ob);
             for (int kc = 0; kc < ni; kc += 256) {
                 const int k = kc + 4 * lane;
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(src + (k < MLP3_MAXD ? k : 0));      // zero beyond ni (ni % 4 == 0)
-                const bool kin = k < ni;
+                // every input element in a register of its own: hipcc otherwise multiplies pairs with `v_pk_fma_f32 .. op_sel:[0,0,1]`, a form that
+                // returns wrong lanes 48-63 beside another stream's GEMM workgroups (point_sam_amd/isa_lint.py)
+                float x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3];
+                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 #pragma unroll
                 for (int o = 0; o < MLP3_OB; ++o) {
-                    const bool ok = kin && ob + o < no;
-                    const f32x4 wv = ok ? *reinterpret_cast<const f32x4*>(W + (int64_t)(ob + o) * ni + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    part[o] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+                    const f32x4 wv = __builtin_bit_cast(f32x4, (m3_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, k * 4, (obu + o) * ni * 4, 0));
+                    part[o] = fmaf(x3, wv[3], fmaf(x2, wv[2], fmaf(x1, wv[1], fmaf(x0, wv[0], part[o]))));      // one chain per output (16 independent chains): nothing to pair
                 }
             }
 #pragma unroll
-            for (int o = 0; o < MLP3_OB; ++o) s_red[wave][o][lane] = part[o];
+            for (int o = 0; o < MLP3_OB; ++o) {      // lane pairs first, then 32 values per output through LDS
+                const float pr = part[o] + dpp_f32<DPP_XOR1>(part[o]);
+                if (!(lane & 1)) s_red[wave][o][lane >> 1] = pr;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lane < MLP3_OB && ob + lane < no) {
                 float y = b[ob + lane];
-                for (int l = 0; l < 64; ++l) y += s_red[wave][lane][l];
+                for (int l = 0; l < 32; ++l) y += s_red[wave][lane][l];
                 if (relu) y = fmaxf(y, 0.f);
                 dst[ob + lane] = y;
             }
@@ -874,13 +956,26 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ x, 
     };
     layer(s_a, s_b, w1 + (int64_t)m * dh * din, b1 + (int64_t)m * dh, din, dh, true);
     __syncthreads();
-    for (int i = dh + tid; i < MLP3_MAXD; i += 256) s_b[i] = 0.f;      // (the next layer reads whole float4 chunks)
+    for (int i = dh + tid; i < MLP3_MAXD; i += 64 * MLP3_NW) s_b[i] = 0.f;      // (the next layer reads whole float4 chunks)
     __syncthreads();
     layer(s_b, s_a, w2 + (int64_t)m * dh * dh, b2 + (int64_t)m * dh, dh, dh, true);
     __syncthreads();
-    for (int i = dh + tid; i < MLP3_MAXD; i += 256) s_a[i] = 0.f;
+    for (int i = dh + tid; i < MLP3_MAXD; i += 64 * MLP3_NW) s_a[i] = 0.f;
     __syncthreads();
     layer(s_a, out + (int64_t)z * ldo + (int64_t)m * so, w3 + (int64_t)m * dout * dh, b3 + (int64_t)m * dout, dh, dout, false);
+}
+__global__ __launch_bounds__(64 * MLP3_NW) void mlp3_kernel(const float* __restrict__ x, int64_t ldx, int64_t sx, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                   const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ out, int64_t ldo,
+                                                   int64_t so, int din, int dh, int dout) {
+    mlp3_body(x, ldx, sx, w1, b1, w2, b2, w3, b3, out, ldo, so, din, dh, dout, blockIdx.x, blockIdx.y);
+}
+// Two MLP stacks over rows of the same matrix in one launch (grid.y = M_a + M_b): the decoder's hyper-networks (mask tokens) and its IoU head (token 0)
+// both read the transformer's token output (mask_decoder.py:167-182) -- two single-wave-of-workgroups launches of ~20 us, all latency, side by side.
+__global__ __launch_bounds__(64 * MLP3_NW) void mlp3_pair_kernel(const psam_mlp3_args_t a, const psam_mlp3_args_t b) {
+    const int m = blockIdx.y;
+    if (m < a.M) mlp3_body(a.x, a.ldx, a.sx, a.w1, a.b1, a.w2, a.b2, a.w3, a.b3, a.out, a.ldo, a.so, a.din, a.dh, a.dout, blockIdx.x, m);
+    else mlp3_body(b.x, b.ldx, b.sx, b.w1, b.b1, b.w2, b.b2, b.w3, b.b3, b.out, b.ldo, b.so, b.din, b.dh, b.dout, blockIdx.x, m - a.M);
 }
 
 // x rows [Z] (row stride ldx; MLP m reads at + m * sx), stacked weights in the reference's [out, in] layout w1 [M, dh, din], w2 [M, dh, dh],
@@ -892,8 +987,25 @@ PSAM_API int32_t psam_mlp3(const float* x, int64_t ldx, int64_t sx, const float*
     PSAM_REQUIRE(Z > 0 && M > 0 && M <= 65535 && din > 0 && dh > 0 && dout > 0 && din <= MLP3_MAXD && dh <= MLP3_MAXD && (din & 3) == 0 && (dh & 3) == 0,
                  PSAM_EINVAL, "psam_mlp3: bad shape (din, dh <= 1024 and multiples of 4)");
     PSAM_REQUIRE((((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3) & 15) == 0, PSAM_EALIGN, "psam_mlp3: weights must be 16-byte aligned");
-    hipLaunchKernelGGL(mlp3_kernel, dim3((unsigned)Z, (unsigned)M), dim3(256), 0, stream, x, ldx, sx, w1, b1, w2, b2, w3, b3, out, ldo, so, din, dh, dout);
+    hipLaunchKernelGGL(mlp3_kernel, dim3((unsigned)Z, (unsigned)M), dim3(64 * MLP3_NW), 0, stream, x, ldx, sx, w1, b1, w2, b2, w3, b3, out, ldo, so, din, dh, dout);
     return psam_launch_status("psam_mlp3: launch failed");
+}
+
+static int32_t mlp3_check(const psam_mlp3_args_t& a) {
+    PSAM_REQUIRE(a.x && a.w1 && a.b1 && a.w2 && a.b2 && a.w3 && a.b3 && a.out, PSAM_EINVAL, "psam_mlp3_pair: null pointer");
+    PSAM_REQUIRE(a.M > 0 && a.M <= 32767 && a.din > 0 && a.dh > 0 && a.dout > 0 && a.din <= MLP3_MAXD && a.dh <= MLP3_MAXD && (a.din & 3) == 0 && (a.dh & 3) == 0,
+                 PSAM_EINVAL, "psam_mlp3_pair: bad shape (din, dh <= 1024 and multiples of 4)");
+    PSAM_REQUIRE((((uintptr_t)a.w1 | (uintptr_t)a.w2 | (uintptr_t)a.w3) & 15) == 0, PSAM_EALIGN, "psam_mlp3_pair: weights must be 16-byte aligned");
+    return PSAM_OK;
+}
+// psam_mlp3 of stack a and of stack b over the same Z rows in one launch (the same arithmetic per output: the same bits as two psam_mlp3 calls).
+PSAM_API int32_t psam_mlp3_pair(const psam_mlp3_args_t* a, const psam_mlp3_args_t* b, int32_t Z, hipStream_t stream) {
+    PSAM_REQUIRE(a && b && Z > 0, PSAM_EINVAL, "psam_mlp3_pair: bad argument");
+    int32_t rc = mlp3_check(*a);
+    if (!rc) rc = mlp3_check(*b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp3_pair_kernel, dim3((unsigned)Z, (unsigned)(a->M + b->M)), dim3(64 * MLP3_NW), 0, stream, *a, *b);
+    return psam_launch_status("psam_mlp3_pair: launch failed");
 }
 
 // out[i] = ((p0[i] + p1[i]) + p2[i]) + ...: the partial planes of a GEMM's hyper-product epilogue (psam_gemm_fuse_t.hyper), fixed order.

@@ -411,6 +411,204 @@ __global__ void fps_coop_reset_kernel(unsigned long long* cand, int n) {
     if (i < n) cand[i] = ~0ull;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cooperative FPS with exact spatial pruning (round 5).  An iteration of fps_coop_kernel updates the running minimum of EVERY point against the new
+// centre, although late in the run a new centre only lowers the minimum of the points around it.  Here the cloud is first bucketed by a 32^3 grid in
+// Morton order (counting sort: histogram, scan, scatter; the order inside a cell is whatever the atomics give -- results do not depend on it), so that
+// the 256 PPT4 consecutive points a wave owns are a compact patch of the surface; every wave keeps the bounding box of its points and its current
+// candidate (maximum of the running minima, lowest ORIGINAL index among the points that hold it).  Per iteration a wave first evaluates the distance
+// from the new centre to its box WITH THE SCAN'S OWN ARITHMETIC -- per axis max(lo - c, c - hi, 0), then (ax ax + ay ay) + az az, every operation
+// rounded to fp32: rounding is monotone, so this is <= the distance the scan would compute for any point inside the box -- and, if that is >= the
+// wave's current maximum, no running minimum of the wave can change (min(m, d) with d >= box distance >= maximum >= m): the wave re-publishes its
+// cached candidate and skips the scan.  Same distances, same minima, same tie-break (lowest original index) as fps_kernel: bit-identical indices.
+// On a surface-like cloud the number of waves that scan falls like (1 + 16 / sqrt(j))^2 of 256 at iteration j; what remains per iteration is the
+// hand-over between the workgroups.
+// ------------------------------------------------------------------------------------------------
+constexpr int FPS_CELL_BITS = 5, FPS_NCELL = 1 << (3 * FPS_CELL_BITS);
+__device__ __forceinline__ int fps_ordered(float f) { const int i = __builtin_bit_cast(int, f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float fps_unordered(int i) { return __builtin_bit_cast(float, i >= 0 ? i : i ^ 0x7fffffff); }
+__device__ __forceinline__ unsigned fps_spread3(unsigned v) {      // 5 bits -> every third bit
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+__device__ __forceinline__ int fps_cell_code(float x, float y, float z, const int* __restrict__ bbox) {
+    const float lx = fps_unordered(bbox[0]), ly = fps_unordered(bbox[1]), lz = fps_unordered(bbox[2]);
+    const float hx = fps_unordered(bbox[3]), hy = fps_unordered(bbox[4]), hz = fps_unordered(bbox[5]);
+    const float n = (float)(1 << FPS_CELL_BITS);
+    auto cell = [&](float v, float lo, float hi) {
+        const float e = hi - lo;
+        const int c = e > 0.f ? (int)((v - lo) * (n / e)) : 0;
+        return (unsigned)(c < 0 ? 0 : (c > (1 << FPS_CELL_BITS) - 1 ? (1 << FPS_CELL_BITS) - 1 : c));
+    };
+    return (int)(fps_spread3(cell(x, lx, hx)) | (fps_spread3(cell(y, ly, hy)) << 1) | (fps_spread3(cell(z, lz, hz)) << 2));
+}
+// bbox [B][8] ints (ordered-int encoding of the floats: min x y z, max x y z), hist [B][FPS_NCELL]
+__global__ void fps_prune_reset_kernel(int* __restrict__ bbox, int* __restrict__ hist, int B) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)B * FPS_NCELL) hist[i] = 0;
+    if (i < B * 8) bbox[i] = (i & 7) < 3 ? 0x7fffffff : (int)0x80000000;
+}
+__global__ __launch_bounds__(256) void fps_bbox_kernel(const float* __restrict__ xyz, int N, int* __restrict__ bbox) {
+    const int b = blockIdx.y;
+    const float* P = xyz + (int64_t)b * N * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = P[n * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = -wave_max(-lo[a]), h = wave_max(hi[a]);
+        if ((threadIdx.x & 63) == 0) { atomicMin(bbox + b * 8 + a, fps_ordered(l)); atomicMax(bbox + b * 8 + 3 + a, fps_ordered(h)); }
+    }
+}
+__global__ __launch_bounds__(256) void fps_cell_hist_kernel(const float* __restrict__ xyz, int N, const int* __restrict__ bbox, int* __restrict__ hist) {
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* p = xyz + ((int64_t)b * N + n) * 3;
+    atomicAdd(hist + (int64_t)b * FPS_NCELL + fps_cell_code(p[0], p[1], p[2], bbox + b * 8), 1);
+}
+// exclusive scan of a cloud's FPS_NCELL cell counts, in place: one 1024-thread workgroup per cloud, 32 cells per thread
+__global__ __launch_bounds__(1024) void fps_cell_scan_kernel(int* __restrict__ hist) {
+    constexpr int PT = FPS_NCELL / 1024;
+    __shared__ int s_w[16];
+    int* h = hist + (int64_t)blockIdx.x * FPS_NCELL + threadIdx.x * PT;
+    int v[PT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { v[i] = h[i]; sum += v[i]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int off = inc - sum;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { h[i] = off; off += v[i]; }
+}
+// psoa [B][4][npad]: x, y, z planes of the bucketed cloud and the points' original indices (as int bits); positions >= N: zeros / -1
+__global__ __launch_bounds__(256) void fps_cell_scatter_kernel(const float* __restrict__ xyz, int N, int64_t npad, const int* __restrict__ bbox, int* __restrict__ offs,
+                                                               float* __restrict__ psoa) {
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= npad) return;
+    float* base = psoa + (int64_t)b * 4 * npad;
+    if (n >= N) { base[n] = 0.f; base[npad + n] = 0.f; base[2 * npad + n] = 0.f; base[3 * npad + n] = __builtin_bit_cast(float, -1); return; }
+    const float* p = xyz + ((int64_t)b * N + n) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    const int pos = atomicAdd(offs + (int64_t)b * FPS_NCELL + fps_cell_code(x, y, z, bbox + b * 8), 1);
+    base[pos] = x; base[npad + pos] = y; base[2 * npad + pos] = z; base[3 * npad + pos] = __builtin_bit_cast(float, (int)n);
+}
+
+template <int PPT4>
+__global__ __launch_bounds__(FPS_THREADS) void fps_coop_pruned_kernel(const float* __restrict__ xyz, const float* __restrict__ psoa, int N, int64_t npad,
+                                                                      int G, int W, int xcd_stride, unsigned long long* __restrict__ cand,
+                                                                      int64_t* __restrict__ idx_out, float* __restrict__ centers_out) {
+    const int b = blockIdx.y;
+    int w = blockIdx.x;
+    if (xcd_stride > 1) {      // one XCD per cloud, see fps_coop_kernel
+        if ((int)(blockIdx.x & 7) != (b & 7)) return;
+        w = blockIdx.x >> 3;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* P = xyz + (int64_t)b * N * 3;
+    const float* soa_b = psoa + (int64_t)b * 4 * npad;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)soa_b, 0, (int)(4 * npad * 4), 0x00020000);
+    const int plane_bytes = (int)(npad * 4);
+    __shared__ unsigned long long s_key[2][FPS_WAVES];
+    __shared__ int s_last[2];
+    unsigned long long* cand_b = cand + (int64_t)b * 2 * 64;
+
+    // this wave's points: positions ((w FPS_WAVES + wave) PPT4 + g) 256 + 4 lane .. + 3 of the bucketed order -- PPT4 * 256 consecutive positions
+    f32x4 md[PPT4], rx[PPT4], ry[PPT4], rz[PPT4];
+    u32x4 oi[PPT4];
+    float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < PPT4; ++g) {
+        const int base = (((w * FPS_WAVES + wave) * PPT4 + g) * 64 + lane) * 4;
+        rx[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base * 4, 0, 0));
+        ry[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base * 4, plane_bytes, 0));
+        rz[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base * 4, 2 * plane_bytes, 0));
+        oi[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base * 4, 3 * plane_bytes, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = base + e < N;
+            md[g][e] = ok ? INFINITY : -1.0f;
+            if (ok) {
+                blx = fminf(blx, rx[g][e]); bhx = fmaxf(bhx, rx[g][e]);
+                bly = fminf(bly, ry[g][e]); bhy = fmaxf(bhy, ry[g][e]);
+                blz = fminf(blz, rz[g][e]); bhz = fmaxf(bhz, rz[g][e]);
+            }
+        }
+    }
+    blx = -wave_max(-blx); bly = -wave_max(-bly); blz = -wave_max(-blz);      // an empty wave keeps lo = +inf, hi = -inf: its box distance is +inf, it never scans
+    bhx = wave_max(bhx); bhy = wave_max(bhy); bhz = wave_max(bhz);
+    float c_wmax = wave_max(md[0][0]) >= 0.f ? INFINITY : -1.0f;      // (position order: a wave with any valid point has a valid lane 0, slot 0)
+    unsigned c_idx = 0;
+    int last = 0;
+    if (w == 0) {
+        if (tid == 0) idx_out[(int64_t)b * G] = 0;
+        if (tid < 3) centers_out[(int64_t)b * G * 3 + tid] = P[tid];
+    }
+    for (int j = 1; j < G; ++j) {
+        const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[(int64_t)last * 3 + 0])));
+        const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[(int64_t)last * 3 + 1])));
+        const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[(int64_t)last * 3 + 2])));
+        asm volatile("s_nop 4");      // SGPRs possibly written by the VALU feed packed-fp32 VALU operands (inline asm) right below
+        // the centre's distance to the wave's box, in the scan's arithmetic (a - c and -(c - a) are the same bits; contraction is off in this file)
+        const float ax = fmaxf(fmaxf(blx - cx, cx - bhx), 0.f), ay = fmaxf(fmaxf(bly - cy, cy - bhy), 0.f), az = fmaxf(fmaxf(blz - cz, cz - bhz), 0.f);
+        const float dbox = (ax * ax + ay * ay) + az * az;
+        const unsigned tag = (unsigned)j & 0xFFFu;
+        if (!(dbox >= c_wmax)) {      // wave-uniform.  (c_wmax = -1: a wave of padding never scans; +inf in the first iteration: everybody does)
+            float best = -1.0f;
+            const fps_f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+            for (int g = 0; g < PPT4; ++g) {
+                const f32x4 dx = fps_sub_bcast(rx[g], c2x), dy = fps_sub_bcast(ry[g], c2y), dz = fps_sub_bcast(rz[g], c2z);
+                const f32x4 d = (dx * dx + dy * dy) + dz * dz;      // -ffp-contract=off: no FMA
+                md[g] = f32x4{fps_min(md[g].x, d.x), fps_min(md[g].y, d.y), fps_min(md[g].z, d.z), fps_min(md[g].w, d.w)};
+                best = fmaxf(fmaxf(best, md[g].x), md[g].y);
+                best = fmaxf(fmaxf(best, md[g].z), md[g].w);
+            }
+            c_wmax = wave_max(best);
+            unsigned cnd = 0x7fffffffu;      // the lowest ORIGINAL index among the points that hold the maximum
+            if (best == c_wmax) {
+#pragma unroll
+                for (int g = 0; g < PPT4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (md[g][e] == c_wmax && oi[g][e] < cnd) cnd = oi[g][e];
+            }
+            c_idx = (unsigned)wave_min_dpp((int)cnd);
+        }
+        // key: [63:32] min-distance bits, [31:20] iteration tag, [19:0] 0xFFFFF - original index (fps_coop_kernel); a wave of padding: distance 0, index field 0
+        unsigned long long key = (unsigned long long)tag << 20;
+        if (c_wmax >= 0.f) key = ((unsigned long long)__builtin_bit_cast(unsigned, c_wmax) << 32) | (tag << 20) | (0xFFFFFu - c_idx);
+        const int slot = j & 1;
+        if (lane == 0) s_key[slot][wave] = key;
+        __syncthreads();
+        if (wave == 0) {
+            static_assert(FPS_WAVES == 16, "one 16-lane row holds the waves' keys");
+            const unsigned long long wk = fps_row16_max_u64(s_key[slot][lane & 15]);
+            if (lane == 0) __hip_atomic_store(cand_b + slot * 64 + w, wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long k;
+            for (;;) {
+                k = lane < W ? __hip_atomic_load(cand_b + slot * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 20);
+                if (__all((((unsigned)k >> 20) & 0xFFFu) == tag)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            k = W <= 16 ? fps_row16_max_u64(k) : fps_wave_max_u64(k);
+            if (lane == 0) s_last[slot] = (int)(0xFFFFFu - ((unsigned)k & 0xFFFFFu));
+        }
+        __syncthreads();
+        last = __builtin_amdgcn_readfirstlane(s_last[slot]);
+        if (w == 0) {
+            if (tid == 0) idx_out[(int64_t)b * G + j] = last;
+            if (tid < 3) centers_out[((int64_t)b * G + j) * 3 + tid] = P[(int64_t)last * 3 + tid];
+        }
+    }
+}
+
 static int fps_num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -456,11 +654,20 @@ PSAM_API size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G) {
     (void)G;
     if (B <= 0 || N <= 0) return 0;
     // planar xyz (3) + streamed min-distance (1) + cooperative hand-over: 2 x 64 candidate keys and one barrier counter per cloud
-    return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float) + (size_t)B * (2 * 64 * sizeof(unsigned long long) + 16);
+    // + the pruned cooperative kernel's counting sort: per cloud a bounding box (8 ints) and FPS_NCELL cell counters
+    return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float) + (size_t)B * (2 * 64 * sizeof(unsigned long long) + 16) + (size_t)B * (FPS_NCELL + 8) * sizeof(int);
 }
 
 static int g_fps_coop = 1;  // test hook: 0 forces the single-workgroup kernels, 2 the cooperative kernel without the one-XCD placement
 PSAM_API void psam_fps_set_cooperative(int32_t on) { g_fps_coop = on; }
+static int g_fps_prune = -1;      // -1: environment PSAM_FPS_PRUNE (default 1); 0 = the cooperative kernel scans every point in every iteration (A/B, tests)
+PSAM_API void psam_fps_set_pruning(int32_t mode) { g_fps_prune = mode; }
+static bool fps_prune_enabled() {
+    if (g_fps_prune >= 0) return g_fps_prune != 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_FPS_PRUNE"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
 
 // xyz [B,N,3] f32 -> fps_idx [B,G] i64 (start index 0), centers [B,G,3] f32 (fused batch_index_select).
 PSAM_API int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int64_t* fps_idx, float* centers, void* ws,
@@ -473,14 +680,33 @@ PSAM_API int32_t psam_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int
     const int64_t npad = fps_npad(N);
     float* soa = (float*)ws;
     float* mdg = soa + (int64_t)B * 3 * npad;
-    hipLaunchKernelGGL(fps_soa_kernel, dim3((unsigned)psam_cdiv(npad, 256), B), dim3(256), 0, stream, xyz, N, npad, soa);
     int W = 0;
     const int coop = g_fps_coop ? fps_coop_ppt4(B, N, &W) : 0;
+    if (!(coop && fps_prune_enabled()))      // (the pruned cooperative kernel builds its own, bucketed planes)
+        hipLaunchKernelGGL(fps_soa_kernel, dim3((unsigned)psam_cdiv(npad, 256), B), dim3(256), 0, stream, xyz, N, npad, soa);
     if (coop) {
         unsigned long long* cand = (unsigned long long*)(mdg + (int64_t)B * npad);
         hipLaunchKernelGGL(fps_coop_reset_kernel, dim3((unsigned)psam_cdiv(B * 128, 256)), dim3(256), 0, stream, cand, B * 128);
         // one XCD (32 CUs) per cloud when its workgroups fit beside those of the other clouds dealt to the same XCD
         const int xs = ((int64_t)W * psam_cdiv(B, 8) <= fps_num_cus() / 8 && g_fps_coop != 2) ? 8 : 1;
+        if (fps_prune_enabled()) {
+            // counting sort of every cloud by grid cell (bounding box, histogram, scan, scatter) into the four planes of the workspace (x, y, z,
+            // original index: the cooperative kernels keep the running minima in registers, the fourth plane is free), then the pruned kernel
+            int* bbox = (int*)(cand + (int64_t)B * 128 + 2 * (int64_t)B);
+            int* hist = bbox + (int64_t)B * 8;
+            float* psoa = soa;
+            const unsigned nb = (unsigned)psam_cdiv(N, 256);
+            hipLaunchKernelGGL(fps_prune_reset_kernel, dim3((unsigned)psam_cdiv((int64_t)B * FPS_NCELL, 256)), dim3(256), 0, stream, bbox, hist, B);
+            hipLaunchKernelGGL(fps_bbox_kernel, dim3(nb < 256 ? nb : 256, B), dim3(256), 0, stream, xyz, N, bbox);
+            hipLaunchKernelGGL(fps_cell_hist_kernel, dim3(nb, B), dim3(256), 0, stream, xyz, N, bbox, hist);
+            hipLaunchKernelGGL(fps_cell_scan_kernel, dim3(B), dim3(1024), 0, stream, hist);
+            hipLaunchKernelGGL(fps_cell_scatter_kernel, dim3((unsigned)psam_cdiv(npad, 256), B), dim3(256), 0, stream, xyz, N, npad, bbox, hist, psoa);
+#define FPS_COOP_PRUNED(P) \
+    hipLaunchKernelGGL(fps_coop_pruned_kernel<P>, dim3(W * xs, B), dim3(FPS_THREADS), 0, stream, xyz, psoa, N, npad, G, W, xs, cand, fps_idx, centers)
+            if (coop == 1) FPS_COOP_PRUNED(1); else if (coop == 2) FPS_COOP_PRUNED(2); else FPS_COOP_PRUNED(4);
+#undef FPS_COOP_PRUNED
+            return psam_launch_status("psam_fps: launch failed");
+        }
 #define FPS_COOP(P) \
     hipLaunchKernelGGL(fps_coop_kernel<P>, dim3(W * xs, B), dim3(FPS_THREADS), 0, stream, xyz, soa, N, npad, G, W, xs, cand, fps_idx, centers)
         if (coop == 1) FPS_COOP(1); else if (coop == 2) FPS_COOP(2); else FPS_COOP(4);

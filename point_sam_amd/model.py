@@ -531,9 +531,10 @@ class PointCloudSAM:
         return self._patch_encoder("mask_encoder.patch_encoder", st.coords, pm.view(Z, N, 1), st.centers, st.knn_idx, radius=cfg.mask_encoder_radius,
                                    center_idx=st.fps_idx if cfg.mask_centralize_features else None)
 
-    def _masks_from_keys(self, st, keys, hs, Z, T, rep, multimask_output):
+    def _masks_from_keys(self, st, keys, hs, Z, T, rep, multimask_output, hyper=None):
         """Upscaling + hyper-network products (mask_decoder.py:146-176): keys [Z*G, E] after the transformer, hs [Z, T, E] -> (masks [Z, C, N],
-        the selected mask-token indices)."""
+        the selected mask-token indices).  hyper [Z, C, E]: the hyper-network outputs when the caller already has them (_decode: one launch with the
+        IoU head)."""
         cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
         N, G, nmt = st.coords.shape[1], st.centers.shape[1], cfg.num_mask_tokens
         # upscale: 3-NN interpolation G -> N, MLP, hyper-network dot product    (mask_decoder.py:146-176)
@@ -541,8 +542,9 @@ class PointCloudSAM:
             st.interp_index, st.interp_weight = ops.three_nn(st.coords, st.centers)
         sel = list(range(1, nmt)) if multimask_output else [0]
         C = len(sel)
-        hyper = torch.empty(Z, C, E, device=self.device)
-        ops.mlp3(hs[:, 1 + sel[0], :], T * E, E, self.hyper_mw[bool(multimask_output)], hyper, C * E, E, Z)      # mask token i -> MLP i
+        if hyper is None:
+            hyper = torch.empty(Z, C, E, device=self.device)
+            ops.mlp3(hs[:, 1 + sel[0], :], T * E, E, self.hyper_mw[bool(multimask_output)], hyper, C * E, E, Z)      # mask token i -> MLP i
         masks = torch.empty(Z, C, N, device=self.device)
         up = torch.empty(Z * N, E, device=self.device)
         U0, U3 = "mask_decoder.output_upscaling.0", "mask_decoder.output_upscaling.3"
@@ -630,9 +632,12 @@ class PointCloudSAM:
         hs, keys = self._two_way(src.view(Z * G, E), st.pc_pe, tokens.view(Z * T, E), Z, G, T, rep)
         hs = hs.view(Z, T, E)
         assert hs.is_contiguous()
-        masks, sel = self._masks_from_keys(st, keys, hs, Z, T, rep, multimask_output)
-        iou = torch.empty(Z, nmt, device=self.device)
-        ops.mlp3(hs, T * E, 0, self.iou_mw, iou, nmt, 0, Z)      # token 0 = IoU token
+        # the hyper-networks (mask tokens) and the IoU head (token 0) read the same rows: one launch (mask_decoder.py:167-182)
+        sel0, C = (1, nmt - 1) if multimask_output else (0, 1)
+        hmw = self.hyper_mw[bool(multimask_output)]      # output width E (E // 2 in the hierarchical decoder)
+        hyper, iou = torch.empty(Z, C, hmw.dout, device=self.device), torch.empty(Z, nmt, device=self.device)
+        ops.mlp3_pair(hs[:, 1 + sel0, :], T * E, E, hmw, hyper, C * hmw.dout, hmw.dout, hs, T * E, 0, self.iou_mw, iou, nmt, 0, Z)
+        masks, sel = self._masks_from_keys(st, keys, hs, Z, T, rep, multimask_output, hyper=hyper)
         return masks, iou[:, sel[0]:sel[-1] + 1]
 
     # ------------------------------------------------------------------------------------------ reference API

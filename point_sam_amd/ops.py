@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the HIP stream; every comput
 libpointsam_hip.so launched on ``torch.cuda.current_stream()``.  Inputs must be CUDA(HIP) fp32 / int64
 tensors; there is no CPU path.
 """
+import ctypes
 import torch
 
 from . import _lib
@@ -893,6 +894,84 @@ def mlp3(x, ldx, sx, mw: Mlp3Weights, out, ldo, so, Z):
             raise _lib.PointSamHipError("mlp3: operands must be fp32 tensors on the GPU (there is no CPU fallback)")
     check(_lib.load().psam_mlp3(x.data_ptr(), ldx, sx, mw.w1.data_ptr(), mw.b1.data_ptr(), mw.w2.data_ptr(), mw.b2.data_ptr(), mw.w3.data_ptr(),
                                 mw.b3.data_ptr(), out.data_ptr(), ldo, so, Z, mw.M, mw.din, mw.dh, mw.dout, _stream()), "psam_mlp3")
+    return out
+
+
+def mlp3_pair(xa, ldxa, sxa, mwa: Mlp3Weights, outa, ldoa, soa, xb, ldxb, sxb, mwb: Mlp3Weights, outb, ldob, sob, Z):
+    """mlp3 of stack a and of stack b over the same Z rows in ONE launch (the hyper-networks and the IoU head, mask_decoder.py:167-182): the same
+    bits as two mlp3 calls."""
+    for t in (xa, outa, xb, outb):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise _lib.PointSamHipError("mlp3_pair: operands must be fp32 tensors on the GPU (there is no CPU fallback)")
+    def args(x, ldx, sx, mw, out, ldo, so):
+        return _lib.Mlp3Args(x.data_ptr(), mw.w1.data_ptr(), mw.b1.data_ptr(), mw.w2.data_ptr(), mw.b2.data_ptr(), mw.w3.data_ptr(), mw.b3.data_ptr(), out.data_ptr(),
+                             ldx, sx, ldo, so, mw.M, mw.din, mw.dh, mw.dout)
+    a, b = args(xa, ldxa, sxa, mwa, outa, ldoa, soa), args(xb, ldxb, sxb, mwb, outb, ldob, sob)
+    check(_lib.load().psam_mlp3_pair(ctypes.byref(a), ctypes.byref(b), Z, _stream()), "psam_mlp3_pair")
+    return outa, outb
+
+
+def skinny_ln_supported(M, N, K) -> bool:
+    """linear_skinny_ln's shapes; False also while the current stream is being captured without ever having run an eager launch (no arrival counters)."""
+    return 0 < M <= SKINNY_MAX_M and N == 256 and K % 16 == 0 and bool(_lib.load().psam_stream_has_arrival_counters(_stream()))
+
+
+def linear_skinny_ln(x, W, bias, ln_w, ln_b, eps, residual=None, out=None):
+    """out [M, 256] = LayerNorm(x W^T + bias + residual) * ln_w + ln_b for M <= 64 rows in ONE launch (csrc/gemm.hip linear_skinny_ln_kernel: the last
+    workgroup to finish its columns normalises the rows) -- the `queries = norm(queries + out_proj(attn))` steps of the decoder (transformer.py:153-176)."""
+    for t, n in ((ln_w, "ln_w"), (ln_b, "ln_b")):
+        _chk(t, name=n)
+    M, K = x.shape
+    N = W.shape[0]
+    xp, ldx = _row_view(x, "x"); wp, ldw = _row_view(W, "W")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    op, ldo = _row_view(out, "out")
+    rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
+    L = _lib.load()
+    tmp = torch.empty(L.psam_linear_skinny_ln_tmp_floats(M, K), dtype=torch.float32, device=x.device)
+    check(L.psam_linear_skinny_ln(xp, ldx, wp, ldw, _p(bias), rp, ldr, ln_w.data_ptr(), ln_b.data_ptr(), eps, tmp.data_ptr(), op, ldo, M, N, K, _stream()),
+          "psam_linear_skinny_ln")
+    return out
+
+
+def linear_rows_multi(x, jobs, xadd_rows_per_set=1, xadd_rep=1):
+    """[y_i] = [act_i((x + xadd_i) W_i^T + bias_i)] for jobs = [(W, bias | None, xadd | None, act), ..] over the same rows of x in ONE launch, exact fp32
+    products (csrc/gemm.hip linear_rows_multi_kernel: 32 x 64 tiles; a few hundred to a few thousand rows).  xadd_i: sets of xadd_rows_per_set rows, set
+    (row // (xadd_rep * xadd_rows_per_set)) is added to row `row` (the decoder's key_pe)."""
+    xp, ldx = _row_view(x, "x")
+    M, K = x.shape
+    js = _lib.SkinnyJobs()
+    js.n = len(jobs)
+    outs, ldw, ldxa = [], None, ldx
+    for i, (W, bias, xadd, act) in enumerate(jobs):
+        wp, lw = _row_view(W, "W")
+        if ldw not in (None, lw):
+            raise ValueError("linear_rows_multi: the weights must share their row stride")
+        ldw = lw
+        y = torch.empty(M, W.shape[0], dtype=torch.float32, device=x.device)
+        outs.append(y)
+        ap = 0
+        if xadd is not None:
+            ap, ldxa = _row_view(xadd, "xadd")
+        js.job[i] = _lib.SkinnyJob(xp, ap, wp, _p(bias), y.data_ptr(), y.stride(0), W.shape[0], act)
+    check(_lib.load().psam_linear_rows_multi(ctypes.byref(js), ldx, ldxa, xadd_rows_per_set, xadd_rep, ldw, M, K, _stream()), "psam_linear_rows_multi")
+    return outs
+
+
+def linear_ln256(x, W, bias, ln_w, ln_b, eps, residual=None, out=None):
+    """out [M, 256] = LayerNorm(x W^T + bias + residual) * ln_w + ln_b for any M and a short K (K % 16 == 0, K <= 512) in one launch (csrc/gemm.hip
+    linear_ln256_kernel: a workgroup per 16 whole rows, exact fp32 products) -- `keys = norm4(keys + out_proj(attn))`, transformer.py:170-175."""
+    for t, n in ((ln_w, "ln_w"), (ln_b, "ln_b")):
+        _chk(t, name=n)
+    M, K = x.shape
+    N = W.shape[0]
+    xp, ldx = _row_view(x, "x"); wp, ldw = _row_view(W, "W")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    op, ldo = _row_view(out, "out")
+    rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
+    check(_lib.load().psam_linear_ln256(xp, ldx, wp, ldw, _p(bias), rp, ldr, ln_w.data_ptr(), ln_b.data_ptr(), eps, op, ldo, M, N, K, _stream()), "psam_linear_ln256")
     return out
 
 

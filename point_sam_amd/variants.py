@@ -193,7 +193,7 @@ class PointCloudSAMHier(_VariantBase):
         f2 = ops.group_gather(ex["centers1"], x1.view(Z, G1, -1), st.centers, st.knn_idx, radius=r2, width=_r4(3 + x1.shape[1]))
         return _GenericPatchEncoder.run(self, "mask_encoder.patch_encoder2", f2.view(Z * G2 * K2, -1), K2)                  # [Z*G2, E]
 
-    def _masks_from_keys(self, st, keys, hs, Z, T, rep, multimask_output):
+    def _masks_from_keys(self, st, keys, hs, Z, T, rep, multimask_output, hyper=None):
         """MaskDecoderHier's upscaling (mask_decoder.py:312-332): G2 -> G1 interpolation, level-1 embeddings concatenated, output_upscaling2;
         G1 -> N interpolation, output_upscaling1; hyper-network products over E // 2 channels."""
         cfg, w, E = self.cfg, self.w, self.cfg.embed_dim
@@ -219,8 +219,9 @@ class PointCloudSAMHier(_VariantBase):
         u = self._lin(U1 + ".3", u, act=ACT_GELU)
         sel = list(range(1, nmt)) if multimask_output else [0]
         C = len(sel)
-        hyper = torch.empty(Z, C, Eh, device=self.device)
-        ops.mlp3(hs[:, 1 + sel[0], :], T * E, E, self.hyper_mw[bool(multimask_output)], hyper, C * Eh, Eh, Z)
+        if hyper is None:
+            hyper = torch.empty(Z, C, Eh, device=self.device)
+            ops.mlp3(hs[:, 1 + sel[0], :], T * E, E, self.hyper_mw[bool(multimask_output)], hyper, C * Eh, Eh, Z)
         masks = torch.empty(Z, C, N, device=self.device)
         ops.gemm_batched(hyper, u, masks, C, N, Eh, Eh, Eh, N, C * Eh, N * Eh, C * N, Z)
         return masks, sel

@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
+mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$PWD
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "skinny or mlp3 or attention_small or scale_pack or g8_packing" > gpurun_out/pytest_new.log 2>&1; echo "pytest kernels exit $?"; tail -12 gpurun_out/pytest_new.log
+timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -s --tb=short -p no:cacheprovider -k "twoway or against_oracle or c_eva_block or graph_pipeline or free_running" > gpurun_out/pytest_e2e.log 2>&1; echo "pytest e2e exit $?"; grep -E "^\[|passed|failed|Error" gpurun_out/pytest_e2e.log | tail -30
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/click -o t -- python $R/scripts/exp/r05_click_trace.py run > $R/gpurun_out/click.log 2>&1; echo "trace exit $?"
+cd $R
+python scripts/exp/r05_click_trace.py report "gpurun_out/click/**/t_kernel_trace.csv" > gpurun_out/r05_click_kernels.txt; cat gpurun_out/r05_click_kernels.txt
+find gpurun_out/click -name "*.csv" -size +20M -delete

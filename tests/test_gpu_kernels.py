@@ -77,6 +77,58 @@ def test_fps_cooperative_bit_exact(ops, B, N, G, dup):
         assert torch.equal(idx1, idx), mode
 
 
+def _clustered_cloud(B, N, seed):
+    """Points in a few tight clusters plus a thin uniform background, quantised to a coarse lattice: many exactly equal distances (ties decided by the
+    index), cells of very unequal population."""
+    g = torch.Generator().manual_seed(seed)
+    k = 7
+    centres = torch.rand(B, k, 3, generator=g) * 1.6 - 0.8
+    which = torch.randint(0, k, (B, N), generator=g)
+    xyz = torch.gather(centres, 1, which[..., None].expand(-1, -1, 3)) + 0.02 * torch.randn(B, N, 3, generator=g)
+    bg = torch.rand(B, N, generator=g) < 0.05
+    xyz[bg] = torch.rand(int(bg.sum()), 3, generator=g) * 2 - 1
+    return (xyz * 64).round() / 64
+
+
+@pytest.mark.parametrize("B,N,G,kind", [(1, 131072, 2048, "surface"), (2, 70000, 500, "dup"), (1, 131072, 700, "clustered"), (2, 32768, 512, "surface"),
+                                        (3, 50000, 64, "clustered"), (1, 40000, 300, "identical"), (1, 100000, 256, "line"), (1, 29000, 128, "surface")])
+def test_fps_pruned_bit_exact(ops, B, N, G, kind):
+    """The cooperative FPS with exact spatial pruning (csrc/tokenizer.hip fps_coop_pruned_kernel: the cloud bucketed by grid cell, a wave skips its scan
+    when the new centre's distance to the wave's bounding box -- in the scan's own arithmetic -- cannot lower any of its running minima) gives the
+    oracle's indices bit for bit and the un-pruned kernel's: surface-like clouds, clouds with duplicates and with many exactly tied distances (lattice
+    coordinates in clusters), a cloud of identical points (zero-extent box), a cloud on a line (two zero extents), several clouds per call, and the two
+    smallest cooperative sizes."""
+    if kind == "surface":
+        xyz, _ = _cloud(B, N, seed=N + G)
+    elif kind == "dup":
+        xyz, _ = _cloud(B, N, seed=N + G, dup=N // 3)
+    elif kind == "clustered":
+        xyz = _clustered_cloud(B, N, seed=N + G)
+    elif kind == "identical":
+        xyz = torch.full((B, N, 3), 0.375)
+    else:
+        t = torch.rand(B, N, 1, generator=torch.Generator().manual_seed(N))
+        xyz = torch.cat([t * 1.5 - 0.75, torch.full((B, N, 1), 0.25), torch.full((B, N, 1), -0.5)], -1)
+    want = O.fps(xyz, G)
+    L = ops._lib.load()
+    out = {}
+    try:
+        for mode in (1, 0, 1):
+            L.psam_fps_set_pruning(mode)
+            idx, centers = ops.fps(cu(xyz), G)
+            if mode in out:
+                assert torch.equal(idx, out[mode][0]), "pruned FPS: not repeatable"
+            out[mode] = (idx, centers)
+    finally:
+        L.psam_fps_set_pruning(-1)
+    got = out[1][0].cpu()
+    if not torch.equal(got, want):
+        first = (got != want).nonzero()[0].tolist()
+        raise AssertionError(f"pruned FPS differs from the oracle: {(got != want).sum().item()} of {got.numel()} indices, first at {first}: got {got[tuple(first)]} want {want[tuple(first)]}")
+    assert torch.equal(out[0][0].cpu(), want), "un-pruned cooperative FPS differs from the oracle"
+    assert torch.equal(out[1][1].cpu(), O.batch_index_select(xyz, want))
+
+
 def test_fps_cooperative_under_memory_load(ops):
     """The cooperative FPS exchanges keys between workgroups through device memory; run it several times while another stream
     saturates HBM / the fabric with large copies and GEMMs (uneven load is what exposes an unordered key store vs barrier arrival)
@@ -1203,6 +1255,154 @@ def test_attention_small(ops, hd, H, Lq, Lk):
     out = torch.empty(Z * Lq, D, device="cuda")
     ops.attention_small(cu(q).view(-1, D), cu(k).view(-1, D), cu(v).view(-1, D), out, Z, H, Lq, Lk, hd, hd ** -0.5)
     _close(out.view(Z, Lq, D), _sdpa(q, k, v, H, hd ** -0.5), 2e-5, what="attention_small")
+
+
+@pytest.mark.parametrize("hd,H,Lq,Lk,Z", [(16, 8, 9, 512, 1), (16, 8, 7, 2048, 2), (32, 8, 10, 130, 1), (16, 8, 6, 128, 3), (64, 2, 5, 515, 1)])
+def test_attention_small_split_keys(ops, hd, H, Lq, Lk, Z):
+    """Few queries against many keys (the decoder's tokens -> patches attention, transformer.py:160-166): one workgroup per query with the keys split
+    over its four waves (attention_small_split_kernel) against the one-wave-per-query kernel and against fp64 -- also key counts that leave the last wave
+    short (130, 515) and a spike that puts the maximum into one wave's range."""
+    L = ops._lib.load()
+    g = torch.Generator().manual_seed(hd + Lk)
+    D = H * hd
+    q, k, v = torch.randn(Z, Lq, D, generator=g), torch.randn(Z, Lk, D, generator=g), torch.randn(Z, Lk, D, generator=g)
+    k[0, Lk - 3] = q[0, 1] * 3.0
+    out = {}
+    try:
+        for mode in (0, 1):
+            L.psam_attention_small_force_split(mode)
+            out[mode] = ops.attention_small(cu(q).view(-1, D), cu(k).view(-1, D), cu(v).view(-1, D), torch.empty(Z * Lq, D, device="cuda"), Z, H, Lq, Lk, hd, hd ** -0.5)
+        torch.cuda.synchronize()
+    finally:
+        L.psam_attention_small_force_split(1)
+    want = _sdpa(q, k, v, H, hd ** -0.5)
+    _close(out[1].view(Z, Lq, D), want, 2e-5, what="attention_small split")
+    _close(out[0].view(Z, Lq, D), want, 2e-5, what="attention_small one wave")
+    assert not torch.equal(out[0], out[1]) or Lk < 128      # (another summation order: the split kernel really ran)
+
+
+@pytest.mark.parametrize("M,K,res", [(7, 256, True), (10, 128, True), (10, 2048, True), (64, 256, False), (1, 2048, True), (9, 256, False), (33, 1024, True)])
+def test_linear_skinny_ln(ops, M, K, res):
+    """psam_linear_skinny_ln -- `queries = norm(queries + Linear(x))` of the decoder's token side in one launch, the last workgroup normalising the rows
+    (transformer.py:153-176) -- against psam_linear_skinny + psam_layernorm and fp64: last-bit agreement for K <= 256 (one K range: same products, same
+    order), fp32 round-off for the split K = 2048 of the MLP's lin2; in place on the residual; the same bits launch after launch while another stream
+    keeps the chip busy (who arrives last must not matter)."""
+    g = torch.Generator().manual_seed(M * 13 + K)
+    N = 256
+    x, W, b = cu(torch.randn(M, K, generator=g)), cu(torch.randn(N, K, generator=g) / K ** 0.5), cu(torch.randn(N, generator=g))
+    r = cu(torch.randn(M, N, generator=g)) if res else None
+    lw, lb = cu(1.0 + 0.1 * torch.randn(N, generator=g)), cu(0.1 * torch.randn(N, generator=g))
+    assert ops.skinny_ln_supported(M, N, K)
+    want2 = ops.layernorm(ops.linear(x, W, b), lw, lb, 1e-6, residual=r)
+    got = ops.linear_skinny_ln(x, W, b, lw, lb, 1e-6, residual=r)
+    y = F.linear(x.cpu().double(), W.cpu().double(), b.cpu().double()) + (r.cpu().double() if res else 0)
+    want = F.layer_norm(y, (N,), lw.cpu().double(), lb.cpu().double(), 1e-6)
+    _close(got, want, 2e-5, what="linear_skinny_ln vs fp64")
+    _close(got, want2.cpu().double(), 2e-6 if K <= 256 else 1e-5, what="linear_skinny_ln vs two launches")      # (K <= 256: the same products in the same order; the
+    # LayerNorm arithmetic is compiled in another translation unit -- contraction may differ in the last bit)
+    if res:      # in place: queries = norm(queries + ..)
+        q = r.clone()
+        ops.linear_skinny_ln(x, W, b, lw, lb, 1e-6, residual=q, out=q)
+        assert torch.equal(q, got)
+    s2 = torch.cuda.Stream()
+    a, bb = torch.randn(2048, 2048, device="cuda"), torch.randn(2048, 2048, device="cuda")
+    for rep in range(10):
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s2):
+            for _ in range(3):
+                a @ bb
+        again = ops.linear_skinny_ln(x, W, b, lw, lb, 1e-6, residual=r)
+        assert torch.equal(again, got), rep
+    torch.cuda.synchronize()
+    with pytest.raises(ops._lib.PointSamHipError):
+        ops.linear_skinny_ln(x, cu(torch.randn(128, K, generator=g)), None, lw, lb, 1e-6)      # N != 256
+
+
+@pytest.mark.parametrize("M,K,res", [(512, 128, True), (1000, 128, True), (7, 256, False), (2048, 64, True), (33, 512, True), (16, 16, False)])
+def test_linear_ln256(ops, M, K, res):
+    """psam_linear_ln256 -- `keys = norm4(keys + out_proj(attn))` of the decoder's patch side in one launch, a workgroup per 16 whole rows
+    (transformer.py:170-175) -- against fp64 and against Linear + LayerNorm as two launches; ragged row counts; in place on the residual."""
+    g = torch.Generator().manual_seed(M + K)
+    N = 256
+    x, W, b = cu(torch.randn(M, K, generator=g)), cu(torch.randn(N, K, generator=g) / K ** 0.5), cu(torch.randn(N, generator=g))
+    r = cu(torch.randn(M, N, generator=g) * 3.0) if res else None
+    lw, lb = cu(1.0 + 0.1 * torch.randn(N, generator=g)), cu(0.1 * torch.randn(N, generator=g))
+    got = ops.linear_ln256(x, W, b, lw, lb, 1e-6, residual=r)
+    y = F.linear(x.cpu().double(), W.cpu().double(), b.cpu().double()) + (r.cpu().double() if res else 0)
+    _close(got, F.layer_norm(y, (N,), lw.cpu().double(), lb.cpu().double(), 1e-6), 2e-5, what="linear_ln256 vs fp64")
+    with ops.gemm_mode("f32"):
+        two = ops.layernorm(ops.linear(x, W, b), lw, lb, 1e-6, residual=r)
+    _close(got, two.cpu().double(), 2e-5, what="linear_ln256 vs two launches")
+    if res:
+        q = r.clone()
+        ops.linear_ln256(x, W, b, lw, lb, 1e-6, residual=q, out=q)
+        assert torch.equal(q, got)
+    assert torch.equal(got, ops.linear_ln256(x, W, b, lw, lb, 1e-6, residual=r))
+    with pytest.raises(ops._lib.PointSamHipError):
+        ops.linear_ln256(x, cu(torch.randn(128, K, generator=g)), None, lw, lb, 1e-6)      # N != 256
+
+
+@pytest.mark.parametrize("Z,G,rep,K,Ns", [(1, 512, 1, 256, (128, 128, 128)), (4, 256, 2, 256, (128, 256)), (1, 1000, 1, 128, (512,)), (3, 77, 3, 48, (40, 16, 100)), (1, 2048, 1, 256, (256,))])
+def test_linear_rows_multi(ops, Z, G, rep, K, Ns):
+    """psam_linear_rows_multi -- the patch side's projections of a decoder layer in one launch (k / q from keys + key_pe, v from keys:
+    transformer.py:160-175), exact fp32 products on 32 x 64 tiles -- against fp64: broadcast positional addend over `rep` prompt sets, ragged row and
+    column counts, activations, and the single-job form the upscaling's first Linear and the mask encoder use."""
+    g = torch.Generator().manual_seed(G + K)
+    M = Z * G
+    x, pos = torch.randn(M, K, generator=g), torch.randn(Z // rep, G, K, generator=g)
+    jobs, want = [], []
+    for i, N in enumerate(Ns):
+        W, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+        add, act = (i % 2 == 0), (0, 2, 1)[i % 3]
+        xin = (x.view(Z // rep, rep, G, K) + pos[:, None]).reshape(M, K) if add else x
+        y = F.linear(xin.double(), W.double(), b.double())
+        want.append(F.gelu(y) if act == 1 else (F.relu(y) if act == 2 else y))
+        jobs.append((cu(W), cu(b) if i != 1 else None, cu(pos.view(-1, K)) if add else None, act))
+        if i == 1:
+            want[-1] = F.linear(xin.double(), W.double())
+            want[-1] = F.gelu(want[-1]) if act == 1 else (F.relu(want[-1]) if act == 2 else want[-1])
+    got = ops.linear_rows_multi(cu(x), jobs, xadd_rows_per_set=G, xadd_rep=rep)
+    for i, (a, w) in enumerate(zip(got, want)):
+        _close(a, w, 1e-5, rtol=1e-5, what=f"linear_rows_multi job {i}")
+
+
+def test_mlp3_pair_equals_two_launches(ops):
+    """psam_mlp3_pair (hyper-networks + IoU head in one launch, mask_decoder.py:167-182): the bits of the two psam_mlp3 launches."""
+    g = torch.Generator().manual_seed(5)
+    Z, T, E, nmt = 3, 9, 256, 4
+    hs = cu(torch.randn(Z, T, E, generator=g))
+    mk = lambda M, dout: ops.Mlp3Weights([[(cu(torch.randn(o, i, generator=g) / i ** 0.5), cu(torch.randn(o, generator=g) * 0.1)) for i, o in ((E, E), (E, E), (E, dout))]
+                                          for _ in range(M)])
+    for C, dout in ((3, E), (1, E), (3, E // 2)):
+        hw, iw = mk(C, dout), mk(1, nmt)
+        h1, i1 = torch.empty(Z, C, dout, device="cuda"), torch.empty(Z, nmt, device="cuda")
+        ops.mlp3(hs[:, 1, :], T * E, E, hw, h1, C * dout, dout, Z)
+        ops.mlp3(hs, T * E, 0, iw, i1, nmt, 0, Z)
+        h2, i2 = torch.full_like(h1, float("nan")), torch.full_like(i1, float("nan"))
+        ops.mlp3_pair(hs[:, 1, :], T * E, E, hw, h2, C * dout, dout, hs, T * E, 0, iw, i2, nmt, 0, Z)
+        assert torch.equal(h1, h2) and torch.equal(i1, i2)
+
+
+@pytest.mark.parametrize("Z,G,rep,K", [(2, 512, 1, 256), (4, 128, 2, 256), (1, 300, 1, 128)])
+def test_scale_pack_rows_dual(ops, Z, G, rep, K):
+    """psam_scale_pack_rows_g8_add_dual: keys + key_pe and keys packed in one pass (transformer.py:160-170) = the bits of psam_scale_pack_rows_g8_add and
+    psam_scale_pack_rows_g8."""
+    L = ops._lib.load()
+    g = torch.Generator().manual_seed(Z * G)
+    X = cu(torch.randn(Z * G, K, generator=g) * torch.exp(torch.randn(Z * G, 1, generator=g)))
+    pos = cu(torch.randn(Z // rep, G, K, generator=g))
+    Kp = ops.packed_cols(K)
+    e = lambda: torch.empty(Z * G, Kp, device="cuda")
+    s = lambda: torch.empty(Z * G, device="cuda")
+    Ps, ss, Px, sx, Pa, sa = e(), s(), e(), s(), e(), s()
+    check = ops._lib.check
+    check(L.psam_scale_pack_rows_g8_add_dual(X.data_ptr(), K, pos.data_ptr(), K, G, rep, Z * G, K, Ps.data_ptr(), ss.data_ptr(), Px.data_ptr(), sx.data_ptr(), Kp, None), "dual")
+    check(L.psam_scale_pack_rows_g8_add(X.data_ptr(), K, pos.data_ptr(), K, G, rep, Z * G, K, Pa.data_ptr(), Kp, sa.data_ptr(), None), "add")
+    Pw, sw = ops.scale_pack_rows_g8(X)
+    torch.cuda.synchronize()
+    i32 = lambda t: t.view(torch.int32)
+    assert torch.equal(i32(Ps), i32(Pa)) and torch.equal(ss, sa)
+    assert torch.equal(i32(Px), i32(Pw)) and torch.equal(sx, sw)
 
 
 def test_invalid_arguments_raise(ops):

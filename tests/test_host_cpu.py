@@ -163,11 +163,11 @@ def test_ctypes_structs_match_the_header(tmp_path):
     pairs = [("psam_gemm_fuse_t", _lib.GemmFuse, "out_bound"), ("psam_twoway_tokens_t", _lib.TwoWayTokens, "ws_floats"),
              ("psam_eva_block_weights_t", _lib.EvaBlockWeights, "eps"), ("psam_eva_block_plan_t", _lib.EvaBlockPlan, "o_lnd"),
              ("psam_eva_gelu_block_weights_t", _lib.EvaGeluBlockWeights, "eps"), ("psam_eva_gelu_block_plan_t", _lib.EvaGeluBlockPlan, "o_s2"),
-             ("psam_skinny_job_t", _lib.SkinnyJob, "act"), ("psam_skinny_jobs_t", _lib.SkinnyJobs, "n"),
+             ("psam_skinny_job_t", _lib.SkinnyJob, "act"), ("psam_skinny_jobs_t", _lib.SkinnyJobs, "n"), ("psam_mlp3_args_t", _lib.Mlp3Args, "dout"),
              ("psam_patch_encoder_weights_t", _lib.PatchEncoderWeights, "eps"), ("psam_patch_encoder_plan_t", _lib.PatchEncoderPlan, "o_s23"),
              ("psam_upscale_weights_t", _lib.UpscaleWeights, "eps"), ("psam_upscale_plan_t", _lib.UpscalePlan, "o_s3"),
              ("psam_attn_weights_t", _lib.AttnWeights, "o_b"), ("psam_twoway_layer_weights_t", _lib.TwoWayLayerW, "m2_b"),
-             ("psam_twoway_weights_t", _lib.TwoWayWeights, "nf_b"), ("psam_twoway_plan_t", _lib.TwoWayPlan, "o_scales")]
+             ("psam_twoway_weights_t", _lib.TwoWayWeights, "nf_b"), ("psam_twoway_plan_t", _lib.TwoWayPlan, "o_cat_bias")]
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "pointsam_hip.h"', 'int main(void) {']
     for name, _, field in pairs:
         src.append(f'    printf("{name} %zu %zu\\n", sizeof({name}), offsetof({name}, {field}));')
