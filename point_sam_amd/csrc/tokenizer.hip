@@ -500,6 +500,9 @@ __global__ __launch_bounds__(256) void fps_cell_scatter_kernel(const float* __re
     base[pos] = x; base[npad + pos] = y; base[2 * npad + pos] = z; base[3 * npad + pos] = __builtin_bit_cast(float, (int)n);
 }
 
+// (Tried and dropped, round 5: publishing the candidate's COORDINATES with the key -- four self-validating 64-bit words per slot -- so that nobody fetches
+// the winner's point after the exchange: exact, but four polled loads and four stores per hand-over cost more than the three scalar loads they replace,
+// cfg #3 FPS 4.18 -> 4.91 ms, one cloud of 32768 points 0.97 -> 1.12 ms; profiles/r05_fps_pruned.txt.)
 template <int PPT4>
 __global__ __launch_bounds__(FPS_THREADS) void fps_coop_pruned_kernel(const float* __restrict__ xyz, const float* __restrict__ psoa, int N, int64_t npad,
                                                                       int G, int W, int xcd_stride, unsigned long long* __restrict__ cand,
@@ -653,7 +656,7 @@ static int fps_coop_ppt4(int B, int N, int* W) {
 PSAM_API size_t psam_fps_workspace_bytes(int32_t B, int32_t N, int32_t G) {
     (void)G;
     if (B <= 0 || N <= 0) return 0;
-    // planar xyz (3) + streamed min-distance (1) + cooperative hand-over: 2 x 64 candidate keys and one barrier counter per cloud
+    // planar xyz (3) + streamed min-distance (1) + cooperative hand-over: 2 x 64 candidate slots and one barrier counter per cloud
     // + the pruned cooperative kernel's counting sort: per cloud a bounding box (8 ints) and FPS_NCELL cell counters
     return (size_t)B * 4 * (size_t)fps_npad(N) * sizeof(float) + (size_t)B * (2 * 64 * sizeof(unsigned long long) + 16) + (size_t)B * (FPS_NCELL + 8) * sizeof(int);
 }

@@ -48,7 +48,7 @@ def test_invalid_arguments_return_status_not_crash():
     assert lib.psam_fps(None, 1, 16, 4, None, None, None, 0, None) == -1
     assert b"null" in lib.psam_last_error_string()
     assert lib.psam_knn(None, None, 1, 1, 1, 1, None, None) == -1
-    assert lib.psam_fps_workspace_bytes(2, 1000, 10) == 2 * 4 * 4096 * 4 + 2 * (2 * 64 * 8 + 16)   # planar xyz + min-dist + cooperative keys/counter
+    assert lib.psam_fps_workspace_bytes(2, 1000, 10) == 2 * 4 * 4096 * 4 + 2 * (2 * 64 * 8 + 16) + 2 * (32768 + 8) * 4   # planar xyz + min-dist + cooperative keys / counter + the pruned kernel's box and cell counters
 
 
 def test_attention_keysplit_is_per_context():
