@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, dense peaks at 256 CUs x 2.4 GHz
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16
-TRAFFIC_FILES = {"f16x3": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), "bf16x6": ("r01_v6_traffic.json",), "f32": ("r01_v6_traffic.json",)}
+TRAFFIC_FILES = {"f16x3": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), "bf16x6": ("r01_v6_traffic.json",), "f32": ("r01_v6_traffic.json",)}
 
 
 # BASELINE.json `configs` that fit one GPU (config #4 is cfg2 across 8 GPUs: --gpus 8; config #1 is the CPU plumbing case of the tests)
