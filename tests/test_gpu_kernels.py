@@ -129,6 +129,33 @@ def test_fps_pruned_bit_exact(ops, B, N, G, kind):
     assert torch.equal(out[1][1].cpu(), O.batch_index_select(xyz, want))
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_fps_pruned_random_shapes(ops, seed):
+    """Pruned cooperative FPS on randomly drawn shapes and coordinate ranges: clouds scaled by 1e-3 .. 1e3, shifted far from the origin (coordinates that
+    cancel in x - c), flattened onto an axis-aligned plane (one zero box extent), mixed with duplicates -- the bounding-box argument must hold for any finite
+    fp32 coordinates, so the indices equal the oracle's bit for bit."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    B = 1 + seed % 2
+    N = int(torch.randint(28673, 90000, (1,), generator=g))
+    G = int(torch.randint(24, 160, (1,), generator=g))
+    xyz, _ = _cloud(B, N, seed=seed, dup=(N // 5 if seed % 3 == 0 else 0))
+    xyz = xyz * (10.0 ** float(torch.randint(-3, 4, (1,), generator=g)))
+    if seed % 4 == 1:
+        xyz = xyz + torch.tensor([1000.0, -250.0, 31.0])
+    if seed % 4 == 2:
+        xyz[..., int(torch.randint(0, 3, (1,), generator=g))] = 0.125
+    want = O.fps(xyz, G)
+    L = ops._lib.load()
+    try:
+        L.psam_fps_set_pruning(1)
+        idx, centers = ops.fps(cu(xyz), G)
+    finally:
+        L.psam_fps_set_pruning(-1)
+    got = idx.cpu()
+    assert torch.equal(got, want), f"B={B} N={N} G={G}: {(got != want).sum().item()} of {got.numel()} indices differ, first at {(got != want).nonzero()[0].tolist()}"
+    assert torch.equal(centers.cpu(), O.batch_index_select(xyz, want))
+
+
 def test_fps_cooperative_under_memory_load(ops):
     """The cooperative FPS exchanges keys between workgroups through device memory; run it several times while another stream
     saturates HBM / the fabric with large copies and GEMMs (uneven load is what exposes an unordered key store vs barrier arrival)
