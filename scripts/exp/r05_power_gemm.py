@@ -30,6 +30,13 @@ def operands(kind):
     if kind == "lo planes zeroed":
         for P in (xp, wp):
             P.view(torch.int32).view(P.shape[0], -1, 8)[:, :, 4:] = 0
+    if kind.startswith("lo low "):      # "lo low <n> bits zeroed": the n least significant mantissa bits of every lo value cleared (how much of the power is operand entropy)
+        nb = int(kind.split()[2])
+        mask = (0xFFFF << nb) & 0xFFFF
+        m32 = ((mask << 16) | mask) - (1 << 32)      # (the mask's top bit is set: as a signed 32-bit value)
+        for P in (xp, wp):
+            lo = P.view(torch.int32).view(P.shape[0], -1, 8)[:, :, 4:]
+            lo &= m32
     return xp, sa, wp, sw
 
 
@@ -37,7 +44,10 @@ def main():
     th = threading.Thread(target=sampler, daemon=True); th.start()
     y = torch.empty(M, N, device="cuda")
     print(f"qkv GEMM {M}x{N}x{K}; package power cap: " + (re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True).stdout) or [0, "?"])[1] + " W", flush=True)
-    for cfg, kind in ((21, "random"), (95, "random"), (21, "lo planes zeroed"), (21, "zeros"), (21, "random")):
+    conds = ((21, "random"), (95, "random"), (21, "lo planes zeroed"), (21, "zeros"), (21, "random"))
+    if os.environ.get("POWER_SWEEP") == "entropy":
+        conds = ((21, "random"), (21, "lo low 4 bits zeroed"), (21, "lo low 7 bits zeroed"), (21, "lo low 10 bits zeroed"), (21, "lo planes zeroed"), (21, "random"))
+    for cfg, kind in conds:
         xp, sa, wp, sw = operands(kind)
         torch.cuda.synchronize()
         t0 = time.time(); n = 0
@@ -49,7 +59,7 @@ def main():
         sel = [(p, c) for t, p, c in samples if t0 + 1.5 < t < t1 - 0.3]
         us = (t1 - t0) / n * 1e6
         pw = sum(p for p, _ in sel) / max(1, len(sel)); ck = sum(c for _, c in sel) / max(1, len(sel))
-        print(f"cfg {cfg:2d}, {kind:16s}: {us:6.1f} us per launch = {2.0 * M * N * K / us / 1e6:4.0f} TFLOP/s fp32-equivalent ({3 * 2.0 * M * N * K / us / 1e6 / 2500:.3f} of the fp16 peak executed); "
+        print(f"cfg {cfg:2d}, {kind:22s}: {us:6.1f} us per launch = {2.0 * M * N * K / us / 1e6:4.0f} TFLOP/s fp32-equivalent ({3 * 2.0 * M * N * K / us / 1e6 / 2500:.3f} of the fp16 peak executed); "
               f"package {pw:6.0f} W, sclk {ck:5.0f} MHz ({len(sel)} samples)", flush=True)
         time.sleep(2.0)
     stop.set()
