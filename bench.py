@@ -65,6 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graphs", dest="graphs", action="store_false", help="issue every kernel launch from Python (BatchPipeline)")
     ap.add_argument("--slots", type=int, default=3, help="batches in flight with --graphs (static buffer sets)")
     ap.add_argument("--no-stage-times", action="store_true", help="skip the per-stage timing pass after the timed region")
+    ap.add_argument("--no-mfma-probe", action="store_true", help="skip the ~2 s register-only MFMA probe behind roofline.measured_mfma_ceiling_tflops")
     ap.add_argument("--sustained-steps", type=int, default=400, help="steps of the second, long timed region (0 = skip); reported under `sustained`")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo run of this file's control flow with a stand-in pipeline (tests)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
@@ -284,7 +285,14 @@ class HipHarness:
             st["ms_per_additional_click"] = round(sorted(per_g)[2], 3)
             st["ms_per_additional_click_note"] = ("clicks 2..T on the cached encoder state replayed as one HIP graph (median of 5 replays); "
                                                   "`ms_per_additional_click_eager` = the same clicks issued launch by launch from Python (median of 3)")
-        return st, tokenizer_metrics(st, a.batch, a.points, a.groups, a.group_size)
+        traffic = None
+        for cand in TRAFFIC_FILES["f16x3"]:
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                break
+            except (OSError, ValueError):
+                continue
+        return st, tokenizer_metrics(st, a.batch, a.points, a.groups, a.group_size, traffic)
 
     def cpu_baseline(self, out, iters=3):
         """The oracle (CPU restatement of the reference, PyTorch fp32 + C tokenizer) on a bounded sample: cloud 0 of this very batch, one
@@ -507,15 +515,20 @@ def worker(args):
     # second, long timed region: the same passes, enough of them that clock / power state is the sustained one
     sustained = None
     if args.sustained_steps > 0:
-        clocks = []
+        clocks, power, sampler = [], None, None
+        if not args.stub and rank == 0:
+            from point_sam_amd.profiling import PowerSampler
+            sampler = PowerSampler(local).start()
         _, el2, _ = timed(args.sustained_steps)
         if not args.stub:
             from point_sam_amd.profiling import read_sclk_mhz
-            clocks = read_sclk_mhz()
+            clocks = read_sclk_mhz(local)
+            power = sampler.stop() if sampler is not None else None
         sustained = {"steps": args.sustained_steps, "seconds": round(el2, 3), "value": round(total * args.sustained_steps / el2, 3), "unit": "point-clouds/s",
                      "ms_per_step": round(el2 / args.sustained_steps * 1e3, 3), "vs_timed_region": round((total * args.sustained_steps / el2) / (total * args.steps / elapsed), 4),
-                     "sclk_mhz_after": clocks or None,
-                     "note": "same passes, run right after the contract's timed region with the same fences; `value` above stays the contract's K-step figure"}
+                     "sclk_mhz_after": clocks or None, "power": power,
+                     "note": "same passes, run right after the contract's timed region with the same fences; `value` above stays the contract's K-step figure; "
+                             "`power` = package power and shader clock of this GPU sampled during these steps (first 0.5 s dropped)"}
 
     # the collective on its own: ranks seen + time of the per-step gather of the logits
     rccl = None
@@ -556,6 +569,8 @@ def worker(args):
         if not args.no_stage_times:
             stage_ms, tok = H.stage_times()
     roofline = build_roofline(args, prof, total, world, elapsed) if prof else None
+    if roofline is not None and not args.stub:
+        add_power_ceiling(roofline, args, (sustained or {}).get("power"), local)
 
     if rank == 0:
         a = args
@@ -570,7 +585,8 @@ def worker(args):
                                    + (f"{a.clicks}-click session (encoder cached)" if a.clicks > 1 else "1 point prompt multimask") + f", {a.data} clouds",
                        "global_batch": total, "parallelism": f"dp{world}", "tokenizer_pipeline": not a.no_pipeline,
                        "batches_in_flight": H.depth, "dense_streams": a.streams, "hip_graphs": bool(H.use_graphs),
-                       "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "gemm_precision": a.precision, "weights": "seeded random init (no checkpoint offline)"},
+                       "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "gemm_precision": a.precision, "weights": "seeded random init (no checkpoint offline)",
+                       "streams": streams_report(args)},
             "roofline": roofline, "step_ms": step_stats, "stage_ms": stage_ms, "tokenizer": tok, "sustained": sustained, "rccl": rccl,
             "per_rank": {"ranks": [{"rank": r, "value": round(B * a.steps / t, 3), "ms_per_step": round(t / a.steps * 1e3, 3)} for r, t in enumerate(rank_times)],
                          "min_value": round(B * a.steps / max(rank_times), 3), "max_value": round(B * a.steps / min(rank_times), 3),
@@ -588,40 +604,116 @@ def worker(args):
         elif world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = H.cpu_baseline(keep, iters=a.cpu_baseline_iters)
         if not args.stub and world == 1 and a.workload == "cfg2" and a.other_workloads:
-            # BASELINE configs #3 / #5 as short legs of the SAME run, so that whoever runs the default command sees them (each is also a full
-            # contract line of its own under --workload)
-            del H
-            res["other_workloads"] = {w: other_leg(w, a, local) for w in a.other_workloads.split(",") if w in WORKLOADS and w != a.workload}
+            # BASELINE configs #3 / #5 as short legs of the SAME run AND PROCESS, so that whoever runs the default command sees them (each is also a
+            # full contract line of its own under --workload)
+            import gc
+            H.pipe = H.gpipe = H.model = None      # the main workload's graphs and weights are not needed any more
+            gc.collect()
+            torch.cuda.empty_cache()
+            res["other_workloads"] = {w: other_leg(w, a, local, (roofline or {}).get("measured_mfma_ceiling_tflops")) for w in a.other_workloads.split(",")
+                                      if w in WORKLOADS and w != a.workload}
         print(json.dumps(res), flush=True)
 
 
-def other_leg(name, base, local):
-    """One BASELINE configuration as a short leg: `python bench.py --workload <name>` in a FRESH process (its own HIP context: a leg run inside this
-    process, after the main workload's streams and graphs, measured 1.3 - 2 x slower than the same command on its own -- profiles/r05_bench_legs.txt),
-    `--other-steps` timed passes after 3 warm-ups, one oracle run as the CPU baseline; its contract line is cut down to the leg's fields."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(base.other_steps), "--warmup", "3", "--precision", base.precision,
-           "--streams", str(base.streams), "--slots", str(base.slots), "--sustained-steps", "0", "--no-other-workloads", "--cpu-baseline-iters", "1", "--no-stage-times"]
-    for flag, on in (("--no-graphs", not base.graphs), ("--no-gemm-profile", base.no_gemm_profile), ("--no-cpu-baseline", base.no_cpu_baseline)):
+def streams_report(args):
+    if args.stub:
+        return None
+    from point_sam_amd.streams import pipeline_streams_report
+    return pipeline_streams_report()
+
+
+def other_leg(name, base, local, ceiling=None):
+    """One BASELINE configuration as a short leg of THIS process: a second model and a second set of graphs on the process's pipeline streams
+    (point_sam_amd/streams.py -- until round 5 a leg had to be a fresh subprocess: its pipeline got other streams and ran 1.3 - 2 x slower,
+    profiles/r06_inproc.txt).  `--other-steps` timed passes after 3 warm-ups, ~2 s more of the same passes with package power sampled, the GEMM launch
+    sampling, one oracle run as the CPU baseline and the checker."""
+    import gc
+    import math
+    argv = ["--workload", name, "--steps", str(base.other_steps), "--warmup", "3", "--precision", base.precision, "--streams", str(base.streams), "--slots", str(base.slots),
+            "--cpu-baseline-iters", "1"]
+    for flag, on in (("--no-graphs", not base.graphs), ("--no-gemm-profile", base.no_gemm_profile), ("--no-cpu-baseline", base.no_cpu_baseline), ("--no-mfma-probe", True)):
         if on:
-            cmd.append(flag)
-    env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(local))
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
-    d = json.loads(lines[-1])
-    leg = {"workload": d["config"]["workload"], "value": d["value"], "unit": "sessions/s" if d["config"].get("clicks", 1) > 1 else d["unit"], "ms_per_step": d["ms_per_step"],
-           "steps": d["steps"], "warmup": d["warmup"], "batches_in_flight": d["config"]["batches_in_flight"], "startup_s": d["startup_s"]["per_rank"][0]}
-    if d.get("roofline"):
-        leg["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "sampled_launches", "avg_launch_ms", "avg_launch_gflop")}
-    for k in ("cpu_baseline", "parity"):
-        if k in d:
-            leg[k] = d[k]
-    return leg
+            argv.append(flag)
+    a = parse_args(argv)
+    try:
+        H = HipHarness(a, 0, local)
+
+        def loop(n):
+            out = None
+            if H.inline:
+                for _ in range(n):
+                    out = H.next()
+                return out
+            for _ in range(min(H.depth, n)):
+                H.submit()
+            for k in range(n):
+                out = H.next()
+                if k + H.depth < n:
+                    H.submit()
+            return out
+
+        loop(a.warmup)
+        H.sync()
+        t0 = time.perf_counter()
+        out = loop(a.steps)
+        H.sync()
+        el = time.perf_counter() - t0
+        H.finalize()
+        assert torch.isfinite(out[0]).all()
+        keep = (out[0].clone(), out[1].clone())
+        leg = {"workload": f"{name}: ViT-{a.config} N={a.points} g={a.groups}x{a.group_size} batch={a.batch}/GPU "
+                           + (f"{a.clicks}-click session (encoder cached)" if a.clicks > 1 else "1 point prompt multimask") + f", {a.data} clouds",
+               "value": round(a.batch * a.steps / el, 3), "unit": "sessions/s" if a.clicks > 1 else "point-clouds/s", "ms_per_step": round(el / a.steps * 1e3, 3),
+               "steps": a.steps, "warmup": a.warmup, "batches_in_flight": H.depth, "startup_s": H.startup, "in_process": True}
+        from point_sam_amd.profiling import PowerSampler
+        n2 = max(a.steps, int(math.ceil(2.0 / (el / a.steps))))
+        ps = PowerSampler(local).start()
+        H.sync()
+        t0 = time.perf_counter()
+        loop(n2)
+        H.sync()
+        el2 = time.perf_counter() - t0
+        power = ps.stop()
+        leg["sustained"] = {"steps": n2, "seconds": round(el2, 3), "value": round(a.batch * n2 / el2, 3), "ms_per_step": round(el2 / n2 * 1e3, 3), "power": power}
+        if not a.no_gemm_profile:
+            r = build_roofline(a, H.gemm_profile(), a.batch, 1, el)
+            if r:
+                leg["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "sampled_launches", "avg_launch_ms", "avg_launch_gflop")}
+                leg["roofline"]["power"] = power
+                products = {"f16x3": 3.0, "bf16x6": 6.0}.get(a.precision)
+                if ceiling and products:      # the probe ran once, after the main workload: the same box, the same minute
+                    leg["roofline"]["measured_mfma_ceiling_tflops"] = ceiling
+                    leg["roofline"]["frac_of_measured_ceiling"] = round(r["achieved"] * products / ceiling, 4)
+        if not a.no_cpu_baseline:
+            leg["cpu_baseline"], leg["parity"] = H.cpu_baseline(keep, iters=1)
+        return leg
+    except Exception as e:      # a leg must not take the main line down
+        import traceback
+        return {"error": repr(e), "traceback_tail": traceback.format_exc()[-800:]}
+    finally:
+        H = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def add_power_ceiling(roofline, args, power, local):
+    """What the hardware delivers to this arithmetic on THIS box: package power / clock while the workload ran, and the matrix pipe's
+    own sustained rate (register-only MFMA probe, ~2 s) as a second yardstick beside the nominal peak.  `peak` / `frac` stay nominal."""
+    from point_sam_amd.profiling import mfma_ceiling
+    roofline["power"] = power
+    products = {"f16x3": 3.0, "bf16x6": 6.0}.get(args.precision)
+    if products is None or args.no_mfma_probe:
+        return
+    c = mfma_ceiling(2.0, local)
+    if c is None:
+        return
+    roofline["measured_mfma_ceiling_tflops"] = c["tflops"]
+    roofline["measured_mfma_ceiling"] = c
+    roofline["executed_tflops"] = round(roofline["achieved"] * products, 1)
+    roofline["frac_of_measured_ceiling"] = round(roofline["achieved"] * products / c["tflops"], 4)
+    roofline["ceiling_note"] = ("measured_mfma_ceiling_tflops = fp16 MFMA products per second of a register-only loop on this box right after the run (no memory traffic; operands "
+                                "with the GEMM's hi/lo value distribution), i.e. what clock and power management leave of the nominal 2500; frac_of_measured_ceiling = "
+                                "executed products of the dominant kernel (achieved x products per fp32-grade product) / that ceiling")
 
 
 def build_roofline(args, prof, total, world, elapsed):

@@ -34,6 +34,9 @@ SOURCES = [
 if EXPERIMENTS:
     COMMON = COMMON + ["-DPSAM_BUILD_EXPERIMENTS"]
 FLAGS_STAMP = os.path.join(CSRC, ".build_flags")
+# measurement aid of bench.py (matrix-pipe ceiling probe): its own small library, not part of the product ABI
+PROBE_SRC = os.path.join(CSRC, "probe", "mfma_probe.hip")
+PROBE_LIB = os.path.join(CSRC, "probe", "libpsam_probe.so")
 
 
 def _stale(out, deps):
@@ -83,6 +86,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         os.replace(tmp, LIB)
         with open(FLAGS_STAMP, "w") as f:
             f.write(flags)
+    if force or _stale(PROBE_LIB, [PROBE_SRC]):
+        run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-o", PROBE_LIB, PROBE_SRC])
     return LIB
 
 

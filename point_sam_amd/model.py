@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .config import ModelConfig
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU
+from .streams import pipeline_streams
 from .weights import check_state_dict
 
 
@@ -766,8 +767,7 @@ class BatchPipeline:
     def __init__(self, model: PointCloudSAM, dense_streams: int = 1):
         from collections import deque
         self.model = model
-        self.tok_stream = torch.cuda.Stream(device=model.device, priority=-1)
-        self.dense = [torch.cuda.Stream(device=model.device) for _ in range(dense_streams)] if dense_streams > 1 else []
+        self.tok_stream, self.dense = pipeline_streams(model.device, dense_streams if dense_streams > 1 else 0)
         self.count = 0
         self.queue = deque()
 
@@ -840,7 +840,7 @@ class GraphPipeline:
     copy them before `slots` further submits.  Coordinates outside [-1, 1] are still recorded in the model's device flag."""
 
     def __init__(self, model: PointCloudSAM, coords, features, prompt_coords, prompt_labels, prompt_masks=None, multimask_output=True, slots: int = 3,
-                 dense_streams: int = 2, session: bool = False):
+                 dense_streams: int = 2, session: bool = False, streams=None):
         """session=True: prompt_coords [B, T, 3] / prompt_labels [B, T] are the T clicks of an interactive session; the dense graph is encode +
         PointCloudSAM.click_session (T decodes on the cached state) and next() returns the LAST click's (masks, iou)."""
         from collections import deque
@@ -858,8 +858,7 @@ class GraphPipeline:
                      (lambda st_, tok_: model.decode(model.encode(st_.coords, st_.features, tok_), st_.pc, st_.pl, st_.pm, multimask_output))
         self.queue = deque()
         dev = model.device
-        self.tok_stream = torch.cuda.Stream(device=dev, priority=-1)
-        self.dense = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        self.tok_stream, self.dense = pipeline_streams(dev, nstreams) if streams is None else (streams[0], list(streams[1])[:nstreams])      # streams=(tok, [dense..]): the caller's own
         self.multimask = multimask_output
         conv = lambda t, dt: None if t is None else t.to(dev, dt).contiguous().clone()
         self.slots = []
