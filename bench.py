@@ -259,7 +259,8 @@ class HipHarness:
             # by the GPU front end instead of Python, so the figure is the kernels' own time
             m, i = self.model.decode(enc, prompt[:, :1].contiguous(), labels[:, :1].contiguous(), None, True)
             best0 = torch.gather(m, 1, i.argmax(1).view(-1, 1, 1).expand(-1, 1, xyz.shape[1]))[:, 0].contiguous()
-            side = torch.cuda.Stream()
+            from point_sam_amd.streams import pipeline_streams
+            side = pipeline_streams(self.dev, 2)[1][0]      # a stream of the process's probed set (point_sam_amd/streams.py)
             side.wait_stream(torch.cuda.current_stream())
 
             def later_clicks():
@@ -269,11 +270,12 @@ class HipHarness:
                     best = mm[:, 0]
                 return best
 
-            with torch.cuda.stream(side):
+            counters = self.ops.new_counters(self.dev)      # the graph's own arrival-counter block: it may replay on any stream, beside anything
+            with torch.cuda.stream(side), self.ops.use_counters(counters):
                 later_clicks()      # eager once on the capture stream: one-time set-up must not happen inside the capture
             side.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side), self.ops.use_counters(counters):
                 last = later_clicks()
             torch.cuda.synchronize()
             per_g = []

@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
     const int64_t* labels;
     int64_t *fps_idx, *knn_idx, *idx3;
     float *centers, *emb, *x, *p1, *h, *pc_emb, *pc_pe, *tokens, *src, *hs, *hyper, *masks, *iou, *w3, *out_tokens, *hw[6], *iw[6];
-    int32_t* flag;
+    int32_t *flag, *counters;
     void* ws;
     size_t wsb, pb;
     int i, j;
@@ -174,7 +174,9 @@ int main(int argc, char** argv) {
         pb = psam_twoway_decoder_prepared_bytes(DEC_DEPTH, E, DEC_MLP, DEC_DOWN); prep = dmalloc(pb);
         CK(psam_twoway_decoder_prepare(&tw, &plan, prep, pb, NULL));
         wsb = psam_twoway_decoder_ws_bytes(Z, T, G, E, DEC_MLP); ws = dmalloc(wsb);
-        CK(psam_twoway_decoder(&plan, prep, tokens, src, pc_pe, Z / B, Z, T, G, hs, ws, wsb, NULL));
+        /* the caller owns the arrival-counter block of the fused Linear + LayerNorm launches: zeroed once, left zero by every launch */
+        counters = (int32_t*)dmalloc(PSAM_COUNTER_BYTES); HCK(hipMemset(counters, 0, PSAM_COUNTER_BYTES));
+        CK(psam_twoway_decoder(&plan, prep, tokens, src, pc_pe, Z / B, Z, T, G, hs, ws, wsb, counters, NULL));
     }
 
     /* ---- hyper-networks of mask tokens 1..3 (multimask output), upscaling + mask products, IoU head (mask_decoder.py:146-182) */

@@ -149,7 +149,7 @@ void psam_gemm_f16x3p_force_config(int32_t cfg); /* tuning hook: tile / ring con
  * Both give the same bits; the hook exists for A/B measurements and the bitwise test. */
 void psam_gemm_f16x3p_force_epilogue(int32_t mode);
 /* split-K launches of psam_gemm_f16x3p_ex: 1 = in-kernel fix-up (the last workgroup of a tile adds the partial accumulators in split order and runs the
- * epilogue; no reduction launch), 0 = partial planes + reduction launch, -1 = the default (fix-up wherever the workspace and the stream's counters allow;
+ * epilogue; no reduction launch), 0 = partial planes + reduction launch, -1 = the default (fix-up wherever psam_gemm_fuse_t.counters is given and the workspace allows;
  * environment PSAM_GEMM_SPLITK_FIXUP=0 switches it off).  Tuning / test hook: both forms give the same bits for power-of-two scales. */
 void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
 #ifdef PSAM_BUILD_EXPERIMENTS
@@ -158,11 +158,14 @@ void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
  * time: profiles/r05_continuous_sweep.txt) -- -1 = default (environment PSAM_GEMM_CONTINUOUS, else off), 0 = never, 1 = wherever it applies. */
 void psam_gemm_f16x3p_force_continuous(int32_t mode);
 #endif
-/* The in-kernel fix-ups (split-K GEMM, key-split attention) keep arrival counters per (device, stream) that every launch leaves at zero.  After a
- * FAILED launch on a stream (device fault, aborted process) call these before reusing the stream: they re-zero its counters, stream-ordered.  A HIP
- * graph that captured such launches must replay on its capture stream (the counters' address is part of the captured launch). */
-int32_t psam_gemm_f16x3p_reset_splitk_state(psam_stream_t stream);
-int32_t psam_attention_f16x3_reset_keysplit_state(psam_stream_t stream);
+/* ARRIVAL-COUNTER BLOCK (round 6: the library allocates nothing and keeps no per-stream state).  Kernels with an in-kernel fix-up -- the split-K GEMM
+ * (the last workgroup of a tile adds the partial accumulators), the key-split attention (the last arrival combines the partial softmax states), the
+ * skinny Linear + LayerNorm of the decoder's token side (the last workgroup normalises the rows) -- count their workgroups in through device memory the
+ * CALLER owns: PSAM_COUNTER_BYTES bytes, zero before the first use (one hipMemsetAsync), left zero by every launch that completes.  Launches that
+ * share a block must be ordered with respect to each other (one stream, or one graph); streams or graphs that run CONCURRENTLY need a block each.
+ * A captured launch carries the block's address like any other buffer: a graph replays on any stream.  After a FAILED launch re-zero the block.
+ * NULL where an entry takes `counters`: the entry runs without the in-kernel fix-up (reduction pass, unsplit attention, two launches). */
+#define PSAM_COUNTER_BYTES 65536
 /* psam_attention_f16x3(_ex) with few workgroups (one cloud, head dim in (64, 128]): up to four workgroups per (query block, head) share the key tiles and
  * the last arrival combines their partial softmax states in split order.  0 = never split, 1 / -1 = the default (environment PSAM_ATTN_KEYSPLIT=0: off). */
 void psam_attention_f16x3_force_keysplit(int32_t mode);
@@ -205,6 +208,8 @@ typedef struct {
     /* pack_out with a bound PER ROW: out_scale[row] = f16_row_scale(out_bound[row]) instead of the k1 / k2 form (out_bound[row] >= max |output
      * row|; psam_layernorm_ex2 writes it from the L2 norm of the A row).  Tighter than k1 / scaleA + k2 by sqrt(K) max|a| / ||a||_2. */
     const float* out_bound;
+    /* split-K with the in-kernel fix-up: the caller's arrival-counter block (PSAM_COUNTER_BYTES, see above); NULL = partial planes + reduction launch */
+    int32_t* counters;
 } psam_gemm_fuse_t;
 int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_t act);
 /* hyper without row_ln_*: any N % 128 == 0, M % 256 == 0; every 64-column wave tile contributes the partial products of its columns:
@@ -264,11 +269,16 @@ int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const floa
 int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                                 int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
                                 const float* a_scale, float k1, float k2, float* o_scale, psam_stream_t stream);
-/* the same with the key split capped: max_keysplit = 1 never splits (a caller that keeps the chip busy from several streams -- throughput --
- * is better off without the split's extra work), 4 = what psam_attention_f16x3_ex does (latency of a single cloud). */
+/* the same with the KEY SPLIT: few workgroups (one cloud, head dim in (64, 128]: 16 heads x 4 query blocks = 64 on 256 CUs) -- up to max_keysplit <= 4
+ * workgroups per (query block, head) share the key tiles and the last arrival combines their partial softmax states in split order, inside the kernel.
+ * Needs ks_ws (psam_attention_f16x3_keysplit_ws_bytes(...) bytes of scratch for the partial states) and the caller's arrival-counter block `counters`
+ * (PSAM_COUNTER_BYTES, see above); with either NULL, or max_keysplit = 1, the launch is unsplit (what psam_attention_f16x3_ex does; a caller that keeps
+ * the chip busy from several streams -- throughput -- is better off without the split's extra work). */
+size_t psam_attention_f16x3_keysplit_ws_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t max_keysplit);
 int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                                 int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, float scale,
-                                const float* a_scale, float k1, float k2, float* o_scale, int32_t max_keysplit, psam_stream_t stream);
+                                const float* a_scale, float k1, float k2, float* o_scale, int32_t max_keysplit, void* ks_ws, size_t ks_ws_bytes,
+                                int32_t* counters, psam_stream_t stream);
 
 /* Self-attention on PRE-PACKED operands (head dim 64): qkv [B*L, ld] holds every row's q | k | v (column blocks of D = H*64 containers) in
  * the g8-packed hi|lo fp16 form of psam_gemm_f16x3p, all rows with ONE power-of-two scale (sc[b*L] is read) -- what the qkv GEMM writes with
@@ -305,14 +315,12 @@ int32_t psam_linear_rows_multi(const psam_skinny_jobs_t* jobs, int64_t ldx, int6
                                psam_stream_t stream);
 /* Skinny Linear + residual + LayerNorm in one launch: y [M, 256] = LayerNorm(x W^T + bias + residual) * ln_w + ln_b, M <= 64 rows, N == 256 -- the
  * `queries = norm(queries + out_proj(attn))` / `norm3(queries + mlp(queries))` steps of the decoder's token side (transformer.py:153-176).  The last
- * workgroup to finish its columns normalises the rows (arrival counter of the stream; psam_stream_has_arrival_counters(stream) == 0 while a stream
- * that never ran an eager launch is being captured: the call is then refused and the caller issues the two launches).  K is split over up to 8
- * workgroup rows (lin2 of the token MLP: K = 2048).  tmp: psam_linear_skinny_ln_tmp_floats(M, K) floats. */
+ * workgroup to finish its columns normalises the rows (`counters`: the caller's arrival-counter block, PSAM_COUNTER_BYTES, see above; required).  K is
+ * split over up to 8 workgroup rows (lin2 of the token MLP: K = 2048).  tmp: psam_linear_skinny_ln_tmp_floats(M, K) floats. */
 size_t psam_linear_skinny_ln_tmp_floats(int32_t M, int32_t K);
 int32_t psam_linear_skinny_ln(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                               const float* ln_w, const float* ln_b, float eps, float* tmp, float* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
-                              psam_stream_t stream);
-int32_t psam_stream_has_arrival_counters(psam_stream_t stream);
+                              int32_t* counters, psam_stream_t stream);
 /* The same for ANY number of rows and a short K (K % 16 == 0, K <= 512): y [M, 256] = LayerNorm(x W^T + bias + residual) * ln_w + ln_b, a workgroup per
  * 16 whole rows, exact fp32 products -- `keys = norm4(keys + out_proj(attn))` of the decoder's patch side (transformer.py:170-175; K = 128). */
 int32_t psam_linear_ln256(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr, const float* ln_w,
@@ -376,10 +384,11 @@ typedef struct {
 size_t psam_eva_gelu_block_prepared_bytes(int32_t dim, int32_t hidden);
 int32_t psam_eva_gelu_block_prepare(const psam_eva_gelu_block_weights_t* weights, psam_eva_gelu_block_plan_t* plan, void* prepared, size_t prepared_bytes,
                                     psam_stream_t stream);
-size_t psam_eva_gelu_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden);
-/* x [B*L, dim] fp32, updated in place */
+size_t psam_eva_gelu_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden);      /* includes the split-K planes and the key-split partial states */
+/* x [B*L, dim] fp32, updated in place.  counters: the caller's arrival-counter block (PSAM_COUNTER_BYTES, see above) for the split-K fix-up and the
+ * key-split attention of single-cloud shapes; NULL = reduction passes / unsplit attention (same bits for the GEMMs, round-off for the attention). */
 int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes,
-                            psam_stream_t stream);
+                            int32_t* counters, psam_stream_t stream);
 
 /* PatchEncoder.forward on kNN groups in one call (csrc/blocks.hip): the mini-PointNet of the patch embedding (features = rgb) and of the mask
  * encoder (features = mask logits) -- pc_sam/model/common.py:477-506 after the gather of :99-120 / :126-187 -- "f16x3", fused as the Python host
@@ -444,9 +453,11 @@ typedef struct {
 size_t psam_twoway_decoder_prepared_bytes(int32_t depth, int32_t dim, int32_t mlp, int32_t downsample);
 int32_t psam_twoway_decoder_prepare(const psam_twoway_weights_t* weights, psam_twoway_plan_t* plan, void* prepared, size_t prepared_bytes, psam_stream_t stream);
 size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, int32_t dim, int32_t mlp);
-/* tokens [Z*T, dim] (= query_pe), keys [Z*G, dim] in / out (src -> the transformer's second output), pos [Z / rep, G, dim] -> queries [Z*T, dim] */
+/* tokens [Z*T, dim] (= query_pe), keys [Z*G, dim] in / out (src -> the transformer's second output), pos [Z / rep, G, dim] -> queries [Z*T, dim].
+ * counters: the caller's arrival-counter block (PSAM_COUNTER_BYTES, see above) for the fused Linear + LayerNorm launches of the regrouped sequence;
+ * NULL = the operator-by-operator sequence (the same operators, other launch boundaries: results equal to fp32 round-off). */
 int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void* prepared, const float* tokens, float* keys, const float* pos, int32_t rep, int64_t Z,
-                            int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, psam_stream_t stream);
+                            int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, int32_t* counters, psam_stream_t stream);
 /* A/B and test hook: 0 = the operator-by-operator launch sequence (what the Python host issues), 1 = the regrouped sequence (fused Linear + LayerNorm
  * launches of the token side, merged projections; csrc/blocks.hip), -1 = default (environment PSAM_TWOWAY_FAST, else 1). */
 void psam_twoway_decoder_force_fast(int32_t mode);

@@ -48,8 +48,6 @@ SIGNATURES = {
     "psam_gemm_f16x3p_force_epilogue": (None, [i32]),
     "psam_gemm_f16x3p_force_splitk_fixup": (None, [i32]),
     "psam_gemm_f16x3p_force_continuous": (None, [i32]),
-    "psam_gemm_f16x3p_reset_splitk_state": (i32, [ptr]),
-    "psam_attention_f16x3_reset_keysplit_state": (i32, [ptr]),
     "psam_attention_f16x3_force_keysplit": (None, [i32]),
     "psam_twoway_decoder_force_fork": (None, [i32]),
     "psam_attention_packed_force_variant": (None, [i32]),
@@ -63,8 +61,7 @@ SIGNATURES = {
     "psam_eva_block_ws_bytes": (size_t, [i64, i32, i32]),
     "psam_eva_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
     "psam_linear_skinny_multi": (i32, [ptr, i64, i64, i64, i32, i32, ptr]),
-    "psam_linear_skinny_ln": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr, f32, ptr, ptr, i64, i32, i32, i32, ptr]),
-    "psam_stream_has_arrival_counters": (i32, [ptr]),
+    "psam_linear_skinny_ln": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr, f32, ptr, ptr, i64, i32, i32, i32, ptr, ptr]),
     "psam_linear_rows_multi": (i32, [ptr, i64, i64, i32, i32, i64, i64, i32, ptr]),
     "psam_linear_ln256": (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, i64, i32, i32, ptr]),
     "psam_twoway_decoder_force_fast": (None, [i32]),
@@ -76,7 +73,7 @@ SIGNATURES = {
     "psam_eva_gelu_block_prepared_bytes": (size_t, [i32, i32]),
     "psam_eva_gelu_block_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_eva_gelu_block_ws_bytes": (size_t, [i64, i32, i32]),
-    "psam_eva_gelu_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr]),
+    "psam_eva_gelu_block": (i32, [ptr, ptr, ptr, i32, i32, ptr, size_t, ptr, ptr]),
     "psam_patch_encoder_prepared_bytes": (size_t, [i32, i32, i32]),
     "psam_patch_encoder_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_patch_encoder_ws_bytes": (size_t, [i64, i64, i32, i32]),
@@ -88,7 +85,7 @@ SIGNATURES = {
     "psam_twoway_decoder_prepared_bytes": (size_t, [i32, i32, i32, i32]),
     "psam_twoway_decoder_prepare": (i32, [ptr, ptr, ptr, size_t, ptr]),
     "psam_twoway_decoder_ws_bytes": (size_t, [i64, i32, i32, i32, i32]),
-    "psam_twoway_decoder": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i64, i32, i32, ptr, ptr, size_t, ptr]),
+    "psam_twoway_decoder": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i64, i32, i32, ptr, ptr, size_t, ptr, ptr]),
     "psam_twoway_tokens_ws_floats": (i64, [i32]),
     "psam_twoway_tokens": (i32, [ptr, ptr]),
     "psam_gemm_f16x3p_ex": (i32, [ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i64, ptr, i64, i32, i32, i32, i32, f32, i32, ptr, ptr]),
@@ -102,7 +99,8 @@ SIGNATURES = {
     "psam_attention_f32": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr]),
     "psam_attention_f16x3_ex": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, ptr]),
-    "psam_attention_f16x3_ex2": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, i32, ptr]),
+    "psam_attention_f16x3_ex2": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr, f32, f32, ptr, i32, ptr, size_t, ptr, ptr]),
+    "psam_attention_f16x3_keysplit_ws_bytes": (size_t, [i32, i32, i32, i32, i32, i32]),
     "psam_attention_packed": (i32, [ptr, i64, ptr, ptr, i64, ptr, i32, i32, i32, i32, f32, f32, ptr]),
     "psam_attention_small": (i32, [ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, i64, i64, i32, i32, i32, i32, f32, ptr]),
     "psam_gemm_f16x3p_hyper_planes": (i32, [i32, i32]),
@@ -123,7 +121,7 @@ class GemmFuse(ctypes.Structure):
     _fields_ = [("out_scale", ptr), ("out_k1", f32), ("out_k2", f32), ("pack_out", i32), ("stats", ptr), ("stat_cols", i32),
                 ("ln_mean", ptr), ("ln_rstd", ptr), ("ln_c", ptr), ("gmax_out", ptr), ("gmax_ld", i64), ("gmax_k", i32), ("no_store", i32),
                 ("row_ln_g", ptr), ("row_ln_b", ptr), ("row_ln_eps", f32), ("hyper", ptr), ("masks", ptr), ("hyper_c", i32), ("hyper_rows", i32), ("hyper_pstride", i64),
-                ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32), ("out_bound", ptr)]
+                ("splitk_ws", ptr), ("splitk_plane", i64), ("splitk", i32), ("out_bound", ptr), ("counters", ptr)]
 
 
 class EvaBlockWeights(ctypes.Structure):

@@ -13,8 +13,6 @@
 // buffered with a register prefetch; Q stays in registers, pre-scaled by scale*log2(e) so softmax uses v_exp_f32.
 #include "common.h"
 #include <math.h>
-#include <map>
-#include <mutex>
 #include <utility>
 #include <cstdlib>
 
@@ -620,11 +618,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     }
 }
 
-// Key-split state of a stream (see FlashArgs.ksplit): a partial-state workspace and one arrival counter per (query block, head), allocated on the
-// stream's first use -- outside a graph capture; a captured launch on a stream without them runs unsplit -- and shared by the stream's (ordered)
-// launches.  PSAM_ATTN_KEYSPLIT=0 / psam_attention_f16x3_force_keysplit(0) switch the split off.
-constexpr int64_t FA_SK_WS_BYTES = (int64_t)32 << 20, FA_SK_MAX_UNITS = 4096;
-struct FaStreamBlock { float* part; int* count; };
+// Key split (see FlashArgs.ksplit): the partial softmax states go to the caller's scratch (psam_attention_f16x3_keysplit_ws_bytes) and the workgroups of a
+// (query block, head) count in through the caller's arrival-counter block (PSAM_COUNTER_BYTES, include/pointsam_hip.h: words PSAM_CNT_ATTN ..); the
+// library allocates nothing and keeps no per-stream state.  PSAM_ATTN_KEYSPLIT=0 / psam_attention_f16x3_force_keysplit(0) switch the split off.
+constexpr int64_t FA_SK_MAX_UNITS = PSAM_CNT_ATTN_N;
 static int g_fa_keysplit = -1;
 static bool fa_keysplit_enabled() {
     if (g_fa_keysplit >= 0) return g_fa_keysplit != 0;
@@ -633,40 +630,31 @@ static bool fa_keysplit_enabled() {
     return on != 0;
 }
 PSAM_API void psam_attention_f16x3_force_keysplit(int32_t mode) { g_fa_keysplit = mode; }
-static FaStreamBlock fa_stream_block(hipStream_t stream) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, FaStreamBlock> table;
-    int dev = 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipGetDevice(&dev) != hipSuccess || hipStreamIsCapturing(stream, &cs) != hipSuccess) return {nullptr, nullptr};
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = table.find({dev, stream});
-    if (it != table.end()) return it->second;
-    if (cs != hipStreamCaptureStatusNone) return {nullptr, nullptr};
-    void* part = nullptr; void* count = nullptr;
-    if (hipMalloc(&part, FA_SK_WS_BYTES) != hipSuccess) return {nullptr, nullptr};
-    if (hipMalloc(&count, FA_SK_MAX_UNITS * sizeof(int)) != hipSuccess || hipMemsetAsync(count, 0, FA_SK_MAX_UNITS * sizeof(int), stream) != hipSuccess) {
-        (void)hipFree(part); if (count) (void)hipFree(count);
-        return {nullptr, nullptr};
-    }
-    const FaStreamBlock b = {static_cast<float*>(part), static_cast<int*>(count)};
-    table[{dev, stream}] = b;
-    return b;
+// the split factor the launch would use, given unlimited scratch (0 / 1: unsplit)
+static int fa_keysplit_factor(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t max_keysplit) {
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || hd <= 64) return 1;      // (head dim 64 at this size runs on the packed-operand kernel)
+    const int64_t units = (int64_t)psam_cdiv(Lq, FA_BQ) * H * B;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    const int ntiles = (int)psam_cdiv(Lk, FA_BKV);
+    int ks = fa_keysplit_enabled() ? (int)(ncu / units) : 1;
+    if (ks > 4) ks = 4;
+    if (ks > max_keysplit) ks = max_keysplit;
+    if (ks > ntiles / 2) ks = ntiles / 2;
+    return (ks > 1 && units <= FA_SK_MAX_UNITS) ? ks : 1;
 }
-
-// The key-split counterpart of psam_gemm_f16x3p_reset_splitk_state: re-zeroes the stream's arrival counters after a failed launch (stream-ordered).
-PSAM_API int32_t psam_attention_f16x3_reset_keysplit_state(hipStream_t stream) {
-    const FaStreamBlock b = fa_stream_block(stream);
-    if (!b.count) return PSAM_OK;
-    PSAM_REQUIRE(hipMemsetAsync(b.count, 0, FA_SK_MAX_UNITS * sizeof(int), stream) == hipSuccess, PSAM_EINVAL, "psam_attention_f16x3_reset_keysplit_state: memset failed");
-    return PSAM_OK;
+static int64_t fa_split_bytes(int32_t hd) { return ((int64_t)((hd == 64 ? 64 : 128) / 32) * 4 * 256 + 128) * 16; }      // one workgroup's partial state
+PSAM_API size_t psam_attention_f16x3_keysplit_ws_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t max_keysplit) {
+    const int ks = fa_keysplit_factor(B, H, Lq, Lk, hd, max_keysplit);
+    return ks > 1 ? (size_t)((int64_t)psam_cdiv(Lq, FA_BQ) * H * B * ks * fa_split_bytes(hd)) : 0;
 }
 
 // Same contract as psam_attention_f32; head_dim 64, or a multiple of 8 in (64, 128] (computed zero-padded to 128: the giant encoder's 88).  a_scale != NULL: packed output (FlashArgs), o_scale [B*Lq] receives the row
 // scales; o must then be 32-byte aligned with ldo % 8 == 0 and H*hd % 8 == 0.
 PSAM_API int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                                           int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
-                                          float scale, const float* a_scale, float k1, float k2, float* o_scale, int32_t max_keysplit, hipStream_t stream) {
+                                          float scale, const float* a_scale, float k1, float k2, float* o_scale, int32_t max_keysplit, void* ks_ws,
+                                          size_t ks_ws_bytes, int32_t* counters, hipStream_t stream) {
     PSAM_REQUIRE(q && k && v && o, PSAM_EINVAL, "psam_attention_f16x3: null pointer");
     PSAM_REQUIRE((a_scale == nullptr) == (o_scale == nullptr), PSAM_EINVAL, "psam_attention_f16x3: packed output needs both a_scale and o_scale");
     PSAM_REQUIRE(!o_scale || ((ldo & 7) == 0 && ((uintptr_t)o & 31) == 0 && (so & 7) == 0 && Lq == Lk), PSAM_EINVAL,
@@ -690,19 +678,12 @@ PSAM_API int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t s
     // workgroups per (query block, head); the last arrival combines the partial softmax states in the kernel (no second launch)
     p.ksplit = 1; p.sk_part = nullptr; p.sk_count = nullptr;
     const int64_t units = (int64_t)psam_cdiv(Lq, FA_BQ) * H * B;
-    {
-        int dev = 0, ncu = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        const int ntiles = (int)psam_cdiv(Lk, FA_BKV), HDk = hd == 64 ? 64 : 128;
-        const int64_t split_bytes = ((int64_t)(HDk / 32) * 4 * 256 + 128) * 16;
-        int ks = fa_keysplit_enabled() ? (int)(ncu / units) : 1;
-        if (ks > 4) ks = 4;
-        if (ks > max_keysplit) ks = max_keysplit;
-        if (ks > ntiles / 2) ks = ntiles / 2;
-        while (ks > 1 && units * ks * split_bytes > FA_SK_WS_BYTES) --ks;
-        if (ks > 1 && units <= FA_SK_MAX_UNITS && hd > 64) {      // (head dim 64 at this size runs on the packed-operand kernel)
-            FaStreamBlock blk = fa_stream_block(stream);
-            if (blk.part) { p.ksplit = ks; p.sk_part = blk.part; p.sk_count = blk.count; }
+    if (ks_ws && counters) {
+        int ks = fa_keysplit_factor(B, H, Lq, Lk, hd, max_keysplit);
+        while (ks > 1 && (size_t)(units * ks * fa_split_bytes(hd)) > ks_ws_bytes) --ks;
+        if (ks > 1) {
+            PSAM_REQUIRE(((uintptr_t)ks_ws & 15) == 0, PSAM_EALIGN, "psam_attention_f16x3: ks_ws must be 16-byte aligned");
+            p.ksplit = ks; p.sk_part = static_cast<float*>(ks_ws); p.sk_count = counters + PSAM_CNT_ATTN;
         }
     }
     const dim3 grid((unsigned)(units * p.ksplit)), block(256);      // 1-D over (key split, query block, head, batch), see the kernel
@@ -718,7 +699,7 @@ PSAM_API int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t s
 PSAM_API int32_t psam_attention_f16x3_ex(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
                                          int64_t sv, float* o, int64_t ldo, int64_t so, int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd,
                                          float scale, const float* a_scale, float k1, float k2, float* o_scale, hipStream_t stream) {
-    return psam_attention_f16x3_ex2(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, B, H, Lq, Lk, hd, scale, a_scale, k1, k2, o_scale, 4, stream);
+    return psam_attention_f16x3_ex2(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, B, H, Lq, Lk, hd, scale, a_scale, k1, k2, o_scale, 1, nullptr, 0, nullptr, stream);
 }
 
 PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,

@@ -11,8 +11,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#ifdef PSAM_BUILD_EXPERIMENTS
 #include <map>
 #include <mutex>
+#endif
 #include <utility>
 #include <vector>
 #include "common.h"      // brings in include/pointsam_hip.h
@@ -35,7 +37,9 @@ static bool rows_multi_enabled() {
     if (on < 0) { const char* e = getenv("PSAM_ROWS_MULTI"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
 }
-static bool rows_multi_fits(int64_t M, int K) { return rows_multi_enabled() && M > 64 && M <= 2048 && (K & 15) == 0; }
+// The choice is made from the rows of ONE cloud (its G patch tokens), never from the batch: a cloud's results must not depend on how many clouds share
+// the launch (bit-exact batch independence, tests/test_gpu_e2e.py::test_batch_independence_across_the_row_kernel_threshold).
+static bool rows_multi_fits(int64_t rows_per_cloud, int K) { return rows_multi_enabled() && rows_per_cloud <= 2048 && (K & 15) == 0; }
 static int32_t rows_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream) {
     psam_skinny_jobs_t jobs;
     std::memset(&jobs, 0, sizeof(jobs));
@@ -309,6 +313,9 @@ PSAM_API int32_t psam_eva_gelu_block_prepare(const psam_eva_gelu_block_weights_t
     return rc;
 }
 
+// scratch of the key-split attention inside psam_eva_gelu_block: the largest single-cloud case (4 splits x 64 units x 66 KiB = 16.5 MiB) with room to spare;
+// a shape that would need more runs with a smaller split factor (psam_attention_f16x3_ex2 caps it to the scratch it is given)
+constexpr int64_t GELU_KS_WS_BYTES = (int64_t)32 << 20;
 PSAM_API size_t psam_eva_gelu_block_ws_bytes(int64_t M, int32_t dim, int32_t hidden) {
     if (M <= 0 || dim <= 0 || hidden <= 0) return 0;
     const int64_t D = dim, Dp = kpad(dim), Hp = kpad(hidden), widest = 3 * D > Hp ? 3 * D : Hp;
@@ -318,11 +325,12 @@ PSAM_API size_t psam_eva_gelu_block_ws_bytes(int64_t M, int32_t dim, int32_t hid
     b += align256(M * Dp * 4);                            // attention output, packed
     b += 2 * align256(M * Hp * 4);                        // GELU(fc1) rows (fp32 or packed) and their packed copy
     b += align256(4 * M * widest * 4);                    // split-K partial planes (<= 4 per launch)
+    b += GELU_KS_WS_BYTES;                                // key-split attention: partial softmax states (used by single-cloud shapes only)
     return (size_t)b;
 }
 
 PSAM_API int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, const void* prepared, float* x, int32_t B, int32_t L, void* ws, size_t ws_bytes,
-                                     hipStream_t stream) {
+                                     int32_t* counters, hipStream_t stream) {
     PSAM_REQUIRE(plan && prepared && x && ws, PSAM_EINVAL, "psam_eva_gelu_block: null pointer");
     const int D = plan->dim, H = plan->hidden, heads = plan->heads, Dp = kpad(D), Hp = kpad(H), hd = D / heads;
     const int64_t M = (int64_t)B * L;
@@ -338,12 +346,13 @@ PSAM_API int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, con
     float* o = cv.take<float>(M * Dp);
     float* g = cv.take<float>(M * Hp); float* gp = cv.take<float>(M * Hp);
     float* planes = cv.take<float>(4 * M * widest);
+    char* ks_ws = cv.take<char>(GELU_KS_WS_BYTES);
     // a plain GEMM as the host's ops.linear issues it: the library's split-K factor, partial planes in the workspace
     auto gemm = [&](const float* A, int64_t lda, const float* sA, int64_t ow, int64_t os, int N, int K, float* C, int64_t ldc, const float* bias, const float* res, int act) -> int32_t {
         psam_gemm_fuse_t f;
         std::memset(&f, 0, sizeof(f));
         const int ks = ((N & 3) == 0 && (ldc & 3) == 0) ? psam_gemm_f16x3p_splitk((int32_t)M, N, K, act) : 1;
-        if (ks > 1) { f.splitk = ks; f.splitk_ws = planes; f.splitk_plane = M * (int64_t)N; }
+        if (ks > 1) { f.splitk = ks; f.splitk_ws = planes; f.splitk_plane = M * (int64_t)N; f.counters = counters; }
         return psam_gemm_f16x3p_ex(A, lda, sA, P(ow), K, P(os), C, ldc, bias, res, res ? ldc : 0, nullptr, 0, 0, (int32_t)M, N, K, 1.f, act, ks > 1 ? &f : nullptr, stream);
     };
     int32_t rc;
@@ -353,7 +362,7 @@ PSAM_API int32_t psam_eva_gelu_block(const psam_eva_gelu_block_plan_t* plan, con
     rc = gemm(h, Dp, rs, plan->o_wqkv, plan->o_sqkv, 3 * D, Dp, qkv, 3 * D, P(plan->o_bqkv), nullptr, 0);
     if (rc) return rc;
     rc = psam_attention_f16x3_ex2(qkv, 3 * D, (int64_t)L * 3 * D, qkv + D, 3 * D, (int64_t)L * 3 * D, qkv + 2 * D, 3 * D, (int64_t)L * 3 * D, o, Dp, (int64_t)L * Dp, B, heads, L, L,
-                                  hd, (float)std::pow((double)hd, -0.5), rs, plan->vk1, plan->vk2, so, plan->attn_keysplit > 0 ? plan->attn_keysplit : 1, stream);      // float(hd ** -0.5), as the host computes it
+                                  hd, (float)std::pow((double)hd, -0.5), rs, plan->vk1, plan->vk2, so, plan->attn_keysplit > 0 ? plan->attn_keysplit : 1, ks_ws, (size_t)GELU_KS_WS_BYTES, counters, stream);      // float(hd ** -0.5), as the host computes it
     if (rc) return rc;
     rc = gemm(o, Dp, so, plan->o_wproj, plan->o_sproj, D, Dp, x, D, plan->proj_b, x, 0);
     if (rc) return rc;
@@ -480,7 +489,7 @@ PSAM_API int32_t psam_patch_encoder(const psam_patch_encoder_plan_t* plan, const
     rc = psam_gemm_f16x3p_ex(x1, a, s1, P(plan->o_w13), a, P(plan->o_s13), x2, a, plan->c13_b, nullptr, 0, nullptr, 0, 0, (int32_t)rows, h0, a, 1.f, 0, &f, stream);
     if (rc) return rc;
     if (parts > 1) { rc = psam_group_max(part1, h0, y1, h0, groups, parts, h0, stream); if (rc) return rc; }
-    if (rows_multi_fits(groups, h0)) {      // the pooled half of conv2.0, one row per group: a cloud or two
+    if (rows_multi_fits(G, h0)) {      // the pooled half of conv2.0, one row per group
         rc = rows_linear(y1, h0, plan->c20_w, 2 * h0, plan->c20_b, g1, h1, groups, h1, h0, stream);
     } else if (groups >= 256) {
         rc = psam_scale_pack_rows_g8(y1, h0, (int32_t)groups, h0, y1p, a, sy, stream);
@@ -566,7 +575,7 @@ PSAM_API int32_t psam_upscale_masks(const psam_upscale_plan_t* plan, const void*
     float* up = cv.take<float>(Z * N * a); float* s1 = cv.take<float>(Z * N);
     float* parts = cv.take<float>(planes * count);
     int32_t rc;
-    if (rows_multi_fits(Z * G, E)) {
+    if (rows_multi_fits(G, E)) {
         rc = rows_linear(keys, E, plan->u0_w, E, plan->u0_b, k1, E, Z * G, E, E, stream);
     } else if (Z * G >= 256) {
         rc = psam_scale_pack_rows_g8(keys, E, (int32_t)(Z * G), E, kp, a, sk, stream);
@@ -633,6 +642,10 @@ static bool tw_fork_enabled() {
     return on != 0;
 }
 static const TwSide* tw_side(hipStream_t stream) {
+#ifndef PSAM_BUILD_EXPERIMENTS
+    (void)stream;
+    return nullptr;      // the default build creates no streams or events and keeps no per-stream state
+#else
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, TwSide> table;
     if (!tw_fork_enabled()) return nullptr;
@@ -648,6 +661,7 @@ static const TwSide* tw_side(hipStream_t stream) {
     if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.join1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&t.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
     return &(table[{dev, stream}] = t);
+#endif
 }
 }  // namespace
 
@@ -734,7 +748,7 @@ PSAM_API size_t psam_twoway_decoder_ws_bytes(int64_t Z, int32_t T, int32_t G, in
 // prompt; UPDATED IN PLACE to the transformer's second output), pos [Z / rep, G, dim] (image positional encoding, shared by the rep prompt sets of
 // a cloud) -> queries [Z*T, dim] (the transformer's first output)
 PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void* prepared, const float* tokens, float* keys, const float* pos, int32_t rep,
-                                     int64_t Z, int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                     int64_t Z, int32_t T, int32_t G, float* queries, void* ws, size_t ws_bytes, int32_t* counters, hipStream_t stream) {
     PSAM_REQUIRE(plan && prepared && tokens && keys && pos && queries && ws, PSAM_EINVAL, "psam_twoway_decoder: null pointer");
     const psam_twoway_weights_t& W = plan->weights;
     const int E = W.dim, IX = W.dim / W.downsample, H = W.heads, mlp = W.mlp;
@@ -800,9 +814,9 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
     //    the final attention's q) -- are one psam_linear_skinny_multi launch (the patch -> token attention in between only changes `keys`);
     //  * patch side: keys + key_pe and keys are packed in one pass (psam_scale_pack_rows_g8_add_dual), the k projection of tokens -> patches and the
     //    q projection of patches -> tokens are one GEMM on the concatenated weight (both read keys + key_pe).
-    // Needs the stream's arrival counters (not while a stream that never ran eagerly is being captured) and embedding_dim 256.
+    // Needs the caller's arrival-counter block (`counters`) and embedding_dim 256.
     const bool fast = tok_fast && !sd && tw_fast_enabled() && E == 256 && IX >= 128 && 2 * IX <= E && IX <= 512 && I >= 256 && (mlp & 15) == 0 && (IX & 15) == 0 && plan->o_cat_packed[0] != 0 &&
-                      psam_stream_arrival_counters(stream) != nullptr;
+                      counters != nullptr;
     if (fast) {
         auto LS = [&](int sl, const float* w, const float* b, int n, int k) {
             TwLin l{w, b, nullptr, nullptr, n, k};
@@ -817,13 +831,13 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
             return psam_linear_skinny_multi(&jobs, E, E, E, (int32_t)R, E, stream);
         };
         auto lin_ln = [&](const TwLin& l, const float* x, const float* res, const float* nw, const float* nb) -> int32_t {
-            return psam_linear_skinny_ln(x, l.K, l.w, l.K, l.b, res, E, nw, nb, W.eps, lntmp, queries, E, (int32_t)R, E, l.K, stream);
+            return psam_linear_skinny_ln(x, l.K, l.w, l.K, l.b, res, E, nw, nb, W.eps, lntmp, queries, E, (int32_t)R, E, l.K, counters, stream);
         };
         auto sattn = [&](int inner, const float* oq, int64_t ldq, const float* ok, int64_t ldk, const float* ov, int64_t ldv, float* out, int Lq, int Lk) -> int32_t {
             return psam_attention_small(oq, ldq, Lq * ldq, ok, ldk, Lk * ldk, ov, ldv, Lk * ldv, out, inner, (int64_t)Lq * inner, Z, H, Lq, Lk, inner / H,
                                         1.0f / std::sqrt((float)(inner / H)), stream);
         };
-        const bool small_rows = tw_fast_mode() >= 2 && rows_multi_fits(I, E);
+        const bool small_rows = tw_fast_mode() >= 2 && rows_multi_fits(G, E);
         auto rows_multi = [&](int n, const TwLin* ls, const float* const* xadds, float* const* ys, const int64_t* ldys) -> int32_t {
             psam_skinny_jobs_t jobs;
             std::memset(&jobs, 0, sizeof(jobs));

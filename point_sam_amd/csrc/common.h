@@ -128,8 +128,10 @@ __device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float
     return s;
 }
 
-// Arrival counters for in-kernel "last workgroup finishes the job" fix-ups (split-K GEMM, skinny Linear + LayerNorm): a block of zeroed ints per
-// (device, stream), every launch leaves it zero; launches on one stream are ordered, so they may share words.  nullptr: the stream has no block yet
-// and is being captured (csrc/gemm_f16x3p.hip).
-int* psam_stream_arrival_counters(hipStream_t stream);
+// Layout of the caller's arrival-counter block (PSAM_COUNTER_BYTES = 16384 ints, include/pointsam_hip.h), in ints.  Launches that use one block are ordered,
+// so the users could share words; they have ranges of their own anyway (a fault in one must not poison the others).
+constexpr int PSAM_CNT_GEMM = 0, PSAM_CNT_GEMM_N = 4096;          // split-K GEMM: one word per output tile
+constexpr int PSAM_CNT_ATTN = 4096, PSAM_CNT_ATTN_N = 4096;       // key-split attention: one word per (query block, head, batch)
+constexpr int PSAM_CNT_ROW = 8192;                                // skinny Linear + LayerNorm: one word
+static_assert((PSAM_CNT_ROW + 1) * 4 <= PSAM_COUNTER_BYTES, "counter block layout");
 #endif

@@ -533,19 +533,17 @@ static int skinny_ln_ksplit(int K) { const int s = (K + 255) / 256; return s < 1
 PSAM_API size_t psam_linear_skinny_ln_tmp_floats(int32_t M, int32_t K) { return M > 0 && K > 0 ? (size_t)skinny_ln_ksplit(K) * (size_t)M * 256 : 0; }
 
 // y [M, 256] = LayerNorm_256(x [M, K] W [256, K]^T + bias + residual) * ln_w + ln_b for M <= 64 rows (residual optional, may alias y), one launch.
-// tmp: psam_linear_skinny_ln_tmp_floats(M, K) floats of scratch.  The arrival counter is the stream's (psam_stream_arrival_counters): refused
-// (PSAM_EINVAL) when the stream has none yet and is being captured (psam_stream_has_arrival_counters tells) -- the caller then issues
-// psam_linear_skinny + psam_layernorm.
+// tmp: psam_linear_skinny_ln_tmp_floats(M, K) floats of scratch.  counters: the caller's arrival-counter block (PSAM_COUNTER_BYTES,
+// include/pointsam_hip.h; word PSAM_CNT_ROW is used).
 PSAM_API int32_t psam_linear_skinny_ln(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual, int64_t ldr,
                                        const float* ln_w, const float* ln_b, float eps, float* tmp, float* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
-                                       hipStream_t stream) {
-    PSAM_REQUIRE(x && W && y && ln_w && ln_b && tmp, PSAM_EINVAL, "psam_linear_skinny_ln: null pointer");
+                                       int32_t* counters, hipStream_t stream) {
+    PSAM_REQUIRE(x && W && y && ln_w && ln_b && tmp && counters, PSAM_EINVAL, "psam_linear_skinny_ln: null pointer (the arrival-counter block is required)");
     PSAM_REQUIRE(M > 0 && M <= 64 && N == 256 && K > 0 && (K & 15) == 0, PSAM_EINVAL, "psam_linear_skinny_ln: need 0 < M <= 64, N == 256, K % 16 == 0");
     PSAM_REQUIRE(((ldx | ldw | ldy | (residual ? ldr : 0)) & 3) == 0 &&
                      (((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)tmp | (uintptr_t)bias) & 15) == 0,
                  PSAM_EALIGN, "psam_linear_skinny_ln: rows must be 16-byte aligned");
-    int* counter = psam_stream_arrival_counters(stream);
-    PSAM_REQUIRE(counter, PSAM_EINVAL, "psam_linear_skinny_ln: the stream has no arrival counters yet and is being captured");
+    int* counter = counters + PSAM_CNT_ROW;
     const int ksplit = skinny_ln_ksplit(K);
     const int kper = ((K + ksplit - 1) / ksplit + 15) & ~15;
     hipLaunchKernelGGL(linear_skinny_ln_kernel, dim3(N / 16, ksplit), dim3(256), 0, stream, x, ldx, W, ldw, bias, residual, ldr, ln_w, ln_b, eps, tmp, y, ldy, M, K, kper,

@@ -24,8 +24,6 @@
 #include <type_traits>
 #include <cstdlib>
 #include "common.h"
-#include <map>
-#include <mutex>
 #include <utility>
 #include "gemm_f16x3p_args.h"
 #include "gemm_epilogue.h"
@@ -663,11 +661,11 @@ static void f16x3p_cfg_tile(int cfg, int& bm, int& bn, int& per_cu) {
     }
 }
 
-// Arrival counters of the split-K fix-up: SK_MAX_TILES ints per (device, stream), zeroed once and left zero by every launch (the last workgroup of a
-// tile resets its counter).  Launches on one stream are ordered, so they share the block; another stream gets its own.  Allocated on first use --
-// not possible while the stream is being captured into a graph: such a launch falls back to the reduction pass (GraphPipeline runs one eager pass
-// on each of its streams before capturing, which is when the block appears).  PSAM_GEMM_SPLITK_FIXUP=0 switches the fix-up off.
-constexpr int64_t SK_MAX_TILES = 4096;
+// Arrival counters of the split-K fix-up: the first SK_MAX_TILES ints of the CALLER's counter block (psam_gemm_fuse_t.counters, PSAM_COUNTER_BYTES,
+// include/pointsam_hip.h): zero before the first launch, left zero by every launch (the last workgroup of a tile resets its word).  The library keeps no
+// state and allocates nothing; without a block the launch writes partial planes and a reduction pass adds them.  PSAM_GEMM_SPLITK_FIXUP=0 switches
+// the fix-up off.
+constexpr int64_t SK_MAX_TILES = PSAM_CNT_GEMM_N;
 static int g_f16x3p_sk_fixup = -1;      // -1: PSAM_GEMM_SPLITK_FIXUP (default on); 0 / 1 forced (psam_gemm_f16x3p_force_splitk_fixup)
 static bool f16x3p_splitk_fixup_enabled() {
     if (g_f16x3p_sk_fixup >= 0) return g_f16x3p_sk_fixup != 0;
@@ -676,40 +674,6 @@ static bool f16x3p_splitk_fixup_enabled() {
     return on != 0;
 }
 PSAM_API void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode) { g_f16x3p_sk_fixup = mode; }
-static int* f16x3p_sk_counters(hipStream_t stream);
-int* psam_stream_arrival_counters(hipStream_t stream) { return f16x3p_sk_counters(stream); }
-PSAM_API int32_t psam_stream_has_arrival_counters(hipStream_t stream) { return f16x3p_sk_counters(stream) != nullptr; }
-static int* f16x3p_sk_counters(hipStream_t stream) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, int*> table;
-    int dev = 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipGetDevice(&dev) != hipSuccess || hipStreamIsCapturing(stream, &cs) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = table.find({dev, stream});
-    if (it != table.end()) return it->second;
-    if (cs != hipStreamCaptureStatusNone) return nullptr;
-    int* c = nullptr;
-    if (hipMalloc(&c, SK_MAX_TILES * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(c, 0, SK_MAX_TILES * sizeof(int), stream) != hipSuccess) { (void)hipFree(c); return nullptr; }
-    table[{dev, stream}] = c;
-    return c;
-}
-
-// After a FAILED or aborted launch on `stream` (a device fault, a killed process group) the arrival counters of the split-K fix-up may be left non-zero, and every
-// later split launch on that stream would then combine the wrong number of partials.  This re-zeroes the stream's block (stream-ordered).  Also the
-// documented constraint of graphs: the counters' address is baked into a captured launch, so a graph must replay on the stream it was captured on
-// (GraphPipeline does) -- replaying it elsewhere would race with eager split launches on the capture stream.
-PSAM_API int32_t psam_gemm_f16x3p_reset_splitk_state(hipStream_t stream) {
-#ifdef PSAM_BUILD_EXPERIMENTS
-    f16x3c_reset_state(stream);
-    f16x3s_reset_state(stream);
-#endif
-    int* c = f16x3p_sk_counters(stream);
-    if (!c) return PSAM_OK;      // no block yet (or the stream is capturing: nothing to reset)
-    PSAM_REQUIRE(hipMemsetAsync(c, 0, SK_MAX_TILES * sizeof(int), stream) == hipSuccess, PSAM_EINVAL, "psam_gemm_f16x3p_reset_splitk_state: memset failed");
-    return PSAM_OK;
-}
 
 // Split-K factor for a shape (1: none).  A launch whose tiles cover less than half of the CUs (M = 512 rows of one cloud: 44 tiles of
 // 128x128 for the N = 1408 GEMMs of the giant encoder) leaves the rest of the chip idle for a K loop of up to 192 slabs; `ks` workgroups
@@ -799,7 +763,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         int bm = 0, bn = 0, per_cu = 0;
         f16x3p_cfg_tile(cfg, bm, bn, per_cu);
         const int64_t sk_tiles = psam_cdiv(M, bm) * psam_cdiv(N, bn);
-        int* counters = (f16x3p_splitk_fixup_enabled() && sk_tiles <= SK_MAX_TILES && sk_tiles * bm * bn <= fuse->splitk_plane) ? f16x3p_sk_counters(stream) : nullptr;
+        int* counters = (f16x3p_splitk_fixup_enabled() && sk_tiles <= SK_MAX_TILES && sk_tiles * bm * bn <= fuse->splitk_plane) ? (fuse->counters ? fuse->counters + PSAM_CNT_GEMM : nullptr) : nullptr;
         p.ksplit = ks; p.plane = fuse->splitk_plane;
         if (counters) { p.sk_part = fuse->splitk_ws; p.sk_count = counters; }
         else { p.C = fuse->splitk_ws; p.ldc = N; p.bias = nullptr; p.residual = nullptr; p.act = 0; p.alpha = 1.f; }

@@ -921,13 +921,14 @@ __device__ __forceinline__ void mlp3_body(const float* __restrict__ x, int64_t l
             float part[MLP3_OB];
 #pragma unroll
             for (int o = 0; o < MLP3_OB; ++o) part[o] = 0.f;
-            // buffer loads: the row offset is a scalar, the lane's k offset the one address register of all MLP3_OB loads; rows past `no` read as
-            // zero (bounds check of the resource), k past `ni` meets a zero of the input (LDS holds zeros beyond ni)
+            // buffer loads: the row offset is a scalar (soffset), the lane's k offset the one address register of all MLP3_OB loads.  The scalar offset
+            // is NOT covered by the resource's bounds check, so rows past `no` are clamped to the last row (their sums are never stored) and k past `ni`
+            // to the row's last chunk (it meets a zero of the input: LDS holds zeros beyond ni) -- no load leaves the matrix.
             typedef unsigned m3_u32x4 __attribute__((ext_vector_type(4)));
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, no * ni * 4, 0x00020000);
             const int obu = __builtin_amdgcn_readfirstlane(ob);
             for (int kc = 0; kc < ni; kc += 256) {
-                const int k = kc + 4 * lane;
+                const int k = kc + 4 * lane, kw = k < ni ? k : ni - 4;
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(src + (k < MLP3_MAXD ? k : 0));      // zero beyond ni (ni % 4 == 0)
                 // every input element in a register of its own: hipcc otherwise multiplies pairs with `v_pk_fma_f32 .. op_sel:[0,0,1]`, a form that
                 // returns wrong lanes 48-63 beside another stream's GEMM workgroups (point_sam_amd/isa_lint.py)
@@ -935,7 +936,8 @@ __device__ __forceinline__ void mlp3_body(const float* __restrict__ x, int64_t l
                 asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 #pragma unroll
                 for (int o = 0; o < MLP3_OB; ++o) {
-                    const f32x4 wv = __builtin_bit_cast(f32x4, (m3_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, k * 4, (obu + o) * ni * 4, 0));
+                    const int row = obu + o < no ? obu + o : no - 1;
+                    const f32x4 wv = __builtin_bit_cast(f32x4, (m3_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, kw * 4, row * ni * 4, 0));
                     part[o] = fmaf(x3, wv[3], fmaf(x2, wv[2], fmaf(x1, wv[1], fmaf(x0, wv[0], part[o]))));      // one chain per output (16 independent chains): nothing to pair
                 }
             }

@@ -493,7 +493,10 @@ class PointCloudSAM:
         cfg, E, eps = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps
         P = "mask_decoder.transformer"
         if self.c_blocks and getattr(self, "c_twoway", None) is not None and ops.current_gemm_mode() == "f16x3" and not self.fuse_tokens:
-            return self.c_twoway.run(tokens, src, pos, rep, Z, T, G)      # psam_twoway_decoder: the same launches, sequenced by the library
+            # psam_twoway_decoder: the library's REGROUPED launch sequence (fused Linear + LayerNorm launches, merged projections, exact-fp32 row kernels on the
+            # patch side; csrc/blocks.hip) -- the same operators as the Python sequence below with other launch boundaries: equal to fp32 round-off (<= 1.5e-5,
+            # test_twoway_decoder_regrouped_sequence_matches_operator_sequence), not bit for bit
+            return self.c_twoway.run(tokens, src, pos, rep, Z, T, G)
         if self.fuse_tokens and ops.TwoWayLayerWeights.supported(E, self.w[P + ".layers.0.cross_attn_token_to_image.q_proj.weight"].shape[0], cfg.dec_heads, Z, T, G):
             return self._two_way_fused(src, pos, tokens, Z, G, T, rep)
         queries, keys = tokens, src
@@ -844,11 +847,12 @@ class GraphPipeline:
         """session=True: prompt_coords [B, T, 3] / prompt_labels [B, T] are the T clicks of an interactive session; the dense graph is encode +
         PointCloudSAM.click_session (T decodes on the cached state) and next() returns the LAST click's (masks, iou)."""
         from collections import deque
-        # A slot's dense graph is captured on ONE dense stream and must replay there: kernels with in-kernel fix-ups (split-K / stream-K GEMMs, key-split
-        # attention) use arrival counters that belong to the (device, stream) they were captured on, and two graphs sharing a counter block must never run
-        # concurrently.  Slot s is therefore bound to stream s % streams, and the number of slots is a multiple of the number of streams, so that
-        # consecutive batches always alternate streams.  (Until round 5 the replay stream was `count % streams`: with 3 slots on 2 streams every third
-        # batch replayed beside a graph holding the same counters -- garbage partial sums whenever two split launches overlapped.)
+        # Every slot owns an arrival-counter block (ops.new_counters) and captures its graphs with it (ops.use_counters): kernels with in-kernel fix-ups
+        # (split-K GEMMs, key-split attention, the decoder's fused Linear + LayerNorm) count in through the SLOT's block, so any two slots' graphs may be in
+        # flight together, on whatever streams.  (Until round 5 the counters belonged to the (device, stream) inside the library: with 3 slots on 2 streams
+        # every third batch replayed beside a graph holding the same counters -- garbage partial sums; round 5 bound slots to their capture streams, round 6
+        # moved the state to the caller.)  Slot s still runs on stream s % streams and the number of slots is a multiple of the number of streams, so
+        # that consecutive batches alternate streams.
         nstreams = max(1, min(dense_streams, max(1, slots)))
         self.model, self.depth, self.count = model, (max(1, slots) + nstreams - 1) // nstreams * nstreams, 0
         self.session = bool(session)
@@ -868,21 +872,22 @@ class GraphPipeline:
                                  pl=conv(prompt_labels, torch.int64), pm=conv(prompt_masks, torch.float32))
             ds = st.ds = self.dense[s % len(self.dense)]
             st.busy = False
+            st.counters = ops.new_counters(dev)
             # one eager pass first: every kernel's one-time set-up (LDS attributes, library loading) must not happen inside a capture
             self.tok_stream.wait_stream(main); ds.wait_stream(main)
-            with torch.cuda.stream(self.tok_stream):
+            with torch.cuda.stream(self.tok_stream), ops.use_counters(st.counters):
                 tok = model.tokenize(st.coords, with_interp=True)
             ds.wait_stream(self.tok_stream)
             # the key split of the single-cloud attention serves the latency of ONE stream; with several dense streams the graphs are captured without it
             keysplit = ops.attention_keysplit(1 if len(self.dense) > 1 else 4)
-            with torch.cuda.stream(ds), keysplit:
+            with torch.cuda.stream(ds), keysplit, ops.use_counters(st.counters):
                 dense_body(st, tok)
             torch.cuda.synchronize(dev)
             st.g_tok = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.g_tok, stream=self.tok_stream):
+            with torch.cuda.graph(st.g_tok, stream=self.tok_stream), ops.use_counters(st.counters):
                 st.tok = model.tokenize(st.coords, with_interp=True)
             st.g_dense = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.g_dense, stream=ds), keysplit:
+            with torch.cuda.graph(st.g_dense, stream=ds), keysplit, ops.use_counters(st.counters):
                 st.out = dense_body(st, st.tok)
             st.tok_done, st.done = torch.cuda.Event(), torch.cuda.Event()
             self.slots.append(st)

@@ -98,6 +98,54 @@ class attention_keysplit:
         _ATTN_KEYSPLIT_VAR.reset(self.token)
 
 
+# Arrival-counter blocks (include/pointsam_hip.h, PSAM_COUNTER_BYTES): kernels with an in-kernel fix-up (split-K GEMM, key-split attention, skinny Linear +
+# LayerNorm) count their workgroups in through device memory the CALLER owns -- the library allocates nothing and keeps no per-stream state (round 6).
+# This host keeps one zeroed block per (device, stream) for eager launches (launches on one stream are ordered, so they may share it) and lets a scope
+# bring its own: every GraphPipeline slot captures its graphs on a block of its own (`use_counters`), so any two graphs may be in flight together and a
+# graph may replay on any stream.  A capture outside such a scope on a stream that never launched eagerly gets a fresh block inside the capture
+# (zeroed by a node of that graph on every replay).
+COUNTER_BYTES = 65536
+_COUNTERS = {}
+_COUNTERS_VAR = contextvars.ContextVar("point_sam_amd_counters", default=None)
+
+
+def new_counters(device) -> torch.Tensor:
+    return torch.zeros(COUNTER_BYTES // 4, dtype=torch.int32, device=device)
+
+
+def arrival_counters(device) -> torch.Tensor:
+    """The arrival-counter block of the enclosing `use_counters` scope, else the current stream's."""
+    t = _COUNTERS_VAR.get()
+    if t is not None:
+        if t.device != torch.device(device) and not (t.device.type == "cuda" and torch.device(device).index is None):
+            raise _lib.PointSamHipError(f"use_counters: the block lives on {t.device}, the launch is on {device}")
+        return t
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    t = _COUNTERS.get(key)
+    if t is None:
+        t = new_counters(dev)
+        if not torch.cuda.is_current_stream_capturing():
+            _COUNTERS[key] = t
+    return t
+
+
+class use_counters:
+    """Context manager: the enclosed launches count in through `block` (a new_counters() tensor) instead of the current stream's block."""
+
+    def __init__(self, block: torch.Tensor):
+        if block.dtype != torch.int32 or block.numel() * 4 < COUNTER_BYTES or not block.is_cuda or not block.is_contiguous():
+            raise ValueError("use_counters: need a contiguous int32 device tensor of COUNTER_BYTES bytes (ops.new_counters)")
+        self.block = block
+
+    def __enter__(self):
+        self.token = _COUNTERS_VAR.set(self.block)
+        return self.block
+
+    def __exit__(self, *exc):
+        _COUNTERS_VAR.reset(self.token)
+
+
 SPLIT_MIN_M, SPLIT_MIN_N, SPLIT_MIN_K = 256, 128, 128
 SKINNY_MAX_M = 64      # up to this many rows nn.Linear runs on the skinny kernel (exact fp32 products, like "f32")
 GEMM_MODES = ("f32", "bf16x6", "f16x3")
@@ -457,6 +505,7 @@ def linear(x, W, bias=None, act=ACT_NONE, residual=None, out=None, rowbias=None,
                 ws = torch.empty(ks, M * N, dtype=torch.float32, device=x.device)
                 fuse = _lib.GemmFuse()
                 fuse.splitk_ws, fuse.splitk_plane, fuse.splitk = ws.data_ptr(), M * N, ks
+                fuse.counters = arrival_counters(x.device).data_ptr()      # in-kernel fix-up instead of a reduction launch
         if fused:
             fuse = _lib.GemmFuse()
             fuse.no_store = int(bool(no_store))
@@ -563,14 +612,17 @@ def attention(q, k, v, out, B, H, Lq, Lk, hd, scale, pack=None):
     qp, ldq = _row_view(q, "q"); kp, ldk = _row_view(k, "k"); vp, ldv = _row_view(v, "v"); op, ldo = _row_view(out, "out")
     L = _lib.load()
     args = (qp, ldq, Lq * ldq, kp, ldk, Lk * ldk, vp, ldv, Lk * ldv, op, ldo, Lq * ldo, B, H, Lq, Lk, hd, scale)
-    if pack is not None:
-        if not attention_can_pack(hd):
-            raise ValueError("packed attention output needs the f16x3 kernel (head dim 64, or a multiple of 8 in (64, 128])")
-        a_scale, k1, k2, o_scale = pack
-        check(L.psam_attention_f16x3_ex2(*args, a_scale.data_ptr(), float(k1), float(k2), o_scale.data_ptr(), current_attention_keysplit(), _stream()), "psam_attention")
+    if pack is not None and not attention_can_pack(hd):
+        raise ValueError("packed attention output needs the f16x3 kernel (head dim 64, or a multiple of 8 in (64, 128])")
+    if pack is not None or (current_gemm_mode() == "f16x3" and _f16x3_head_dim(hd)):
+        a_scale, k1, k2, o_scale = pack if pack is not None else (None, 0.0, 0.0, None)
+        ks = current_attention_keysplit()
+        nb = int(L.psam_attention_f16x3_keysplit_ws_bytes(B, H, Lq, Lk, hd, ks)) if ks > 1 else 0
+        ks_ws = torch.empty(nb, dtype=torch.uint8, device=out.device) if nb else None      # single-cloud shape: key split with in-kernel combine (scratch and
+        check(L.psam_attention_f16x3_ex2(*args, _p(a_scale), float(k1), float(k2), _p(o_scale), ks if nb else 1, _p(ks_ws), nb,      # counter block are the caller's)
+                                         arrival_counters(out.device).data_ptr() if nb else None, _stream()), "psam_attention")
         return out
-    fn = L.psam_attention_f16x3 if (current_gemm_mode() == "f16x3" and _f16x3_head_dim(hd)) else L.psam_attention_f32
-    check(fn(*args, _stream()), "psam_attention")
+    check(L.psam_attention_f32(*args, _stream()), "psam_attention")
     return out
 
 
@@ -679,7 +731,8 @@ class EvaGeluBlock:
         # POD the library reads during the call only) carries it; the shared plan is never written after _prepare
         plan = _lib.EvaGeluBlockPlan.from_buffer_copy(self.plan)
         plan.attn_keysplit = current_attention_keysplit()
-        check(lib.psam_eva_gelu_block(ctypes.byref(plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), _stream()), "psam_eva_gelu_block")
+        check(lib.psam_eva_gelu_block(ctypes.byref(plan), self.blob.data_ptr(), x.data_ptr(), B, L, ws.data_ptr(), ws.numel(), arrival_counters(x.device).data_ptr(), _stream()),
+              "psam_eva_gelu_block")
         return x
 
 
@@ -801,7 +854,7 @@ class CTwoWay:
         queries = torch.empty(Z * T, self.dim, dtype=torch.float32, device=tokens.device)
         ws = torch.empty(int(lib.psam_twoway_decoder_ws_bytes(Z, T, G, self.dim, self.mlp)), dtype=torch.uint8, device=tokens.device)
         check(lib.psam_twoway_decoder(ctypes.byref(self.plan), self.blob.data_ptr(), tokens.data_ptr(), keys.data_ptr(), pos.data_ptr(), rep, Z, T, G, queries.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), _stream()), "psam_twoway_decoder")
+                                      ws.data_ptr(), ws.numel(), arrival_counters(tokens.device).data_ptr(), _stream()), "psam_twoway_decoder")
         return queries, keys
 
 
@@ -912,8 +965,8 @@ def mlp3_pair(xa, ldxa, sxa, mwa: Mlp3Weights, outa, ldoa, soa, xb, ldxb, sxb, m
 
 
 def skinny_ln_supported(M, N, K) -> bool:
-    """linear_skinny_ln's shapes; False also while the current stream is being captured without ever having run an eager launch (no arrival counters)."""
-    return 0 < M <= SKINNY_MAX_M and N == 256 and K % 16 == 0 and bool(_lib.load().psam_stream_has_arrival_counters(_stream()))
+    """linear_skinny_ln's shapes."""
+    return 0 < M <= SKINNY_MAX_M and N == 256 and K % 16 == 0
 
 
 def linear_skinny_ln(x, W, bias, ln_w, ln_b, eps, residual=None, out=None):
@@ -930,8 +983,8 @@ def linear_skinny_ln(x, W, bias, ln_w, ln_b, eps, residual=None, out=None):
     rp, ldr = (0, 0) if residual is None else _row_view(residual, "residual")
     L = _lib.load()
     tmp = torch.empty(L.psam_linear_skinny_ln_tmp_floats(M, K), dtype=torch.float32, device=x.device)
-    check(L.psam_linear_skinny_ln(xp, ldx, wp, ldw, _p(bias), rp, ldr, ln_w.data_ptr(), ln_b.data_ptr(), eps, tmp.data_ptr(), op, ldo, M, N, K, _stream()),
-          "psam_linear_skinny_ln")
+    check(L.psam_linear_skinny_ln(xp, ldx, wp, ldw, _p(bias), rp, ldr, ln_w.data_ptr(), ln_b.data_ptr(), eps, tmp.data_ptr(), op, ldo, M, N, K,
+                                  arrival_counters(x.device).data_ptr(), _stream()), "psam_linear_skinny_ln")
     return out
 
 

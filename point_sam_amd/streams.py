@@ -179,13 +179,14 @@ def pipeline_streams(device, dense: int):
     tokenizer candidate (`stream_starved_by`) and must not conflict with the dense streams already admitted (`launch_chains_conflict`); the tokenizer
     candidate must not starve the default stream either; finally the set must run the miniature pipeline (`mini_pipeline_ms`) with its dense graphs
     overlapping (ms per step < 0.8 x one dense graph).  Up to 6 tokenizer candidates x 10 dense candidates; if no set passes (GPU_MAX_HW_QUEUES=2, say)
-    the one with the best miniature-pipeline ratio is kept and the pool is marked `compromised` (`pipeline_streams_report`).
+    the one with the best miniature-pipeline ratio is kept and the pool is marked `compromised` (`pipeline_streams_report`).  More than two dense
+    streams: a third is admitted by the same probes if the hardware queues allow it, otherwise taken unprobed (counted, not `compromised`).
     PSAM_PRIVATE_STREAMS=1: every call returns fresh, unprobed streams (the behaviour until round 5, kept for the A/B)."""
     if os.environ.get("PSAM_PRIVATE_STREAMS", "0") == "1":
         return torch.cuda.Stream(device=device, priority=-1), [torch.cuda.Stream(device=device) for _ in range(dense)]
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    ent = _POOL.setdefault((dev.type, idx), {"tok": None, "dense": [], "cands": [], "passed_over": 0, "compromised": False, "probe_s": 0.0, "mini_ratio": None})
+    ent = _POOL.setdefault((dev.type, idx), {"tok": None, "dense": [], "cands": [], "passed_over": 0, "compromised": False, "unadmitted": 0, "probe_s": 0.0, "mini_ratio": None})
     want = max(2, dense)
     if ent["tok"] is not None and len(ent["dense"]) >= want:
         return ent["tok"], list(ent["dense"][:dense])
@@ -238,8 +239,10 @@ def pipeline_streams(device, dense: int):
             else:
                 ent["compromised"] = True
             ent["tok"], ent["dense"], ent["mini_ratio"] = best
-        while len(ent["dense"]) < want:      # nothing admissible left: take what there is
-            ent["compromised"] = True
+        while len(ent["dense"]) < want:      # nothing admissible left (four hardware queues: the default stream's and three more): take what there is
+            if len(ent["dense"]) < 2:
+                ent["compromised"] = True
+            ent["unadmitted"] += 1
             ent["dense"].append(torch.cuda.Stream(device=device))
     ent["probe_s"] += time.perf_counter() - t0
     return ent["tok"], list(ent["dense"][:dense])
@@ -248,6 +251,6 @@ def pipeline_streams(device, dense: int):
 def pipeline_streams_report():
     """What the pool holds and what admission cost, per device (bench line: `config.streams`)."""
     return {f"{k[0]}:{k[1]}": {"tokenizer_stream_id": v["tok"].stream_id if v["tok"] is not None else None, "dense_stream_ids": [d.stream_id for d in v["dense"]],
-                               "tokenizer_candidates_passed_over": v["passed_over"], "dense_candidates_seen": len(v["cands"]), "compromised": v["compromised"],
+                               "tokenizer_candidates_passed_over": v["passed_over"], "dense_candidates_seen": len(v["cands"]), "compromised": v["compromised"], "dense_streams_beyond_the_probed_set": v["unadmitted"],
                                "mini_pipeline_ratio": None if v["mini_ratio"] is None else round(v["mini_ratio"], 3), "probe_seconds": round(v["probe_s"], 3)}
             for k, v in _POOL.items()}

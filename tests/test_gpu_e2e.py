@@ -262,7 +262,7 @@ def test_twoway_decoder_regrouped_sequence_matches_operator_sequence(gpu, B, G, 
     sd = random_state_dict(cfg, seed=28)
     xyz, rgb, prompt, labels = O.synthetic_batch(B, 8192, seed=29, num_prompts=num_prompts)
     model = gpu(cfg, sd, precision="f16x3")
-    assert model.c_twoway is not None and L.psam_stream_has_arrival_counters(None) == 1
+    assert model.c_twoway is not None
     st = model.encode(xyz.cuda(), rgb.cuda())
     Z = prompt.shape[0]
     extra = xyz[torch.arange(Z) // (Z // B), :2]
@@ -319,7 +319,7 @@ def test_c_eva_gelu_block_matches_python_sequence(gpu):
     import ctypes
     lib = ops._lib.load()
     small = torch.empty(1024, dtype=torch.uint8, device="cuda")
-    assert lib.psam_eva_gelu_block(ctypes.byref(blk.plan), blk.blob.data_ptr(), x.data_ptr(), 2, 256, small.data_ptr(), small.numel(), None) == -3      # PSAM_EWORKSPACE
+    assert lib.psam_eva_gelu_block(ctypes.byref(blk.plan), blk.blob.data_ptr(), x.data_ptr(), 2, 256, small.data_ptr(), small.numel(), None, None) == -3      # PSAM_EWORKSPACE
 
 
 def test_attention_packed_output_is_transparent(gpu):
@@ -452,6 +452,24 @@ def test_properties_full_size(gpu):
     assert (st.knn_idx[:, :, 0].cpu() == idx).all(), "each center is its own nearest neighbour"
     model.decode(st, prompt, labels)
     assert torch.allclose(st.interp_weight.sum(-1), torch.ones(3, 32768, device="cuda"), atol=1e-6)
+
+
+def test_batch_independence_across_the_row_kernel_threshold(gpu):
+    """the small-row Linears (pooled conv2.0 of the patch / mask encoder, the first upscaling Linear, the decoder's patch-side projections)
+    used to pick their arithmetic from the TOTAL row count B * G -- exact-fp32 row kernel up to 2048 rows, packed f16x3 GEMM above -- so a cloud's logits
+    differed in the low bits between a batch of 1 and a batch of 8 at G = 512.  The choice is now made from one cloud's rows: bitwise equal, both clicks."""
+    cfg = get_config("tiny", 512, 64)
+    model = gpu(cfg, random_state_dict(cfg, 1))
+    xyz, rgb, prompt, labels = (t.cuda() for t in O.synthetic_batch(8, 8192, seed=9, num_prompts=2))
+    m8, i8 = model.predict_masks(xyz, rgb, prompt[:, :1].contiguous(), labels[:, :1].contiguous())
+    best = torch.gather(m8, 1, i8.argmax(1).view(-1, 1, 1).expand(-1, 1, m8.shape[2]))[:, 0].contiguous()
+    n8, j8 = model.predict_masks(xyz, rgb, prompt, labels, best, False)
+    for b in (0, 5):
+        one = lambda t: t[b:b + 1].contiguous()
+        m1, i1 = model.predict_masks(one(xyz), one(rgb), one(prompt[:, :1]), one(labels[:, :1]))
+        assert torch.equal(m1[0], m8[b]) and torch.equal(i1[0], i8[b]), "click 1: a cloud's logits depend on the batch size"
+        n1, j1 = model.predict_masks(one(xyz), one(rgb), one(prompt), one(labels), one(best), False)
+        assert torch.equal(n1[0], n8[b]) and torch.equal(j1[0], j8[b]), "click 2 (mask prompt): a cloud's logits depend on the batch size"
 
 
 def test_predictor_click_loop(gpu):
@@ -847,6 +865,39 @@ def test_graph_pipeline_with_in_kernel_fixups_matches_eager(gpu):
     torch.cuda.synchronize()
     for k, ((m1, i1), (m2, i2)) in enumerate(zip(want, got)):
         assert torch.equal(m1, m2) and torch.equal(i1, i2), (k, _maxerr(m1, m2))
+
+
+def test_captured_graph_replays_on_another_stream_beside_eager_launches(gpu):
+    """the in-kernel fix-ups (split-K GEMMs, key-split attention, fused Linear + LayerNorm of the decoder) count in through an
+    arrival-counter block the CALLER owns (ops.new_counters / use_counters); the library keeps no (device, stream) state.  So a graph captured with a block
+    of its own replays bit-identically on ANOTHER stream, while the capture stream runs eager launches of the same kernels (which use that stream's
+    block).  Giant width, one cloud: every fix-up kernel is on the path."""
+    from point_sam_amd import ops
+    cfg = _giant_slim()
+    model = gpu(cfg, random_state_dict(cfg, 14), precision="f16x3")
+    xyz, rgb, prompt, labels = (t.cuda() for t in O.synthetic_batch(1, 4096, seed=71))
+    xyz2, rgb2, prompt2, labels2 = (t.cuda() for t in O.synthetic_batch(1, 4096, seed=72))
+    want = model.predict_masks(xyz, rgb, prompt, labels)
+    want2 = model.predict_masks(xyz2, rgb2, prompt2, labels2)
+    cap, other = torch.cuda.Stream(), torch.cuda.Stream()
+    block = ops.new_counters(xyz.device)
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap), ops.use_counters(block):
+        model.predict_masks(xyz, rgb, prompt, labels)
+    cap.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap), ops.use_counters(block):
+        out = model.predict_masks(xyz, rgb, prompt, labels, validate=False)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(other):
+            g.replay()
+        with torch.cuda.stream(cap):      # eager launches of the same kernels on the capture stream, concurrently
+            got2 = model.predict_masks(xyz2, rgb2, prompt2, labels2)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]), "graph replayed on another stream: other bits"
+        assert torch.equal(got2[0], want2[0]) and torch.equal(got2[1], want2[1]), "eager launches beside the replay: other bits"
+        assert int(block.abs().max()) == 0, "a launch left its arrival counters non-zero"
 
 
 def test_graph_pipeline_matches_eager(gpu):
