@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TR && WM * WN == 4) ? 2 : 1) void ge
         if (sum == 123.456f) p.C[0] = sum;
         return;
     }
-    if constexpr (!TR) if (p.sk_part) {      // (split-K launches use the LDS-epilogue instances only: the register-epilogue kernels have no registers to spare)
+    if constexpr (!TR || NW == 8) if (p.sk_part) {      // (the four-wave register-epilogue kernels have no registers to spare for the fix-up; the eight-wave ones hold 32 accumulator registers)
         // ---- split-K fix-up.  Every split of a tile parks its accumulators (raw MFMA layout: [register quad][wave][lane] float4, 1 KiB per store
         // instruction) with device-coherent stores (sc1: written through the XCD's L2), counts itself in, and all but the last arrival are done.  The
         // last one reads the ksplit partials back (its own too: same bits, and the sum order s = 0 .. ksplit-1 then never depends on who came last),
@@ -596,12 +596,14 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     }
     static int reserve = -1;
-    static double share2 = 0.0;
+    static double share2 = 0.0, pen9 = 0.0;
     if (reserve < 0) {      // tuning hooks (environment, read once): CUs assumed busy elsewhere; slowdown of two co-resident tiles
         const char* e = getenv("PSAM_GEMM_RESERVE_CUS");
         reserve = e ? atoi(e) : 8;
         const char* f = getenv("PSAM_GEMM_SHARE");
         share2 = f ? atof(f) : 1.6;
+        const char* g = getenv("PSAM_GEMM_PEN9");
+        pen9 = g ? atof(g) : 1.15;
     }
     const int ncu_eff = ncu > 2 * reserve ? ncu - reserve : ncu;
     struct Cand { int cfg, bm, bn, per_cu; bool swiglu, two_wide; double pen; };
@@ -615,7 +617,7 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
         const int64_t tiles = psam_cdiv(M, c.bm) * psam_cdiv(N, c.bn);
         const double rounds = (double)psam_cdiv(tiles, (int64_t)ncu_eff * c.per_cu);
         const double share = (c.per_cu == 2 && tiles * 2 > (int64_t)ncu_eff * 3) ? share2 : 1.0;
-        const double cost = rounds * c.bm * c.bn * (K + 300.0) * c.pen * share;
+        const double cost = rounds * c.bm * c.bn * (K + 300.0) * (c.cfg == 9 ? pen9 : c.pen) * share;
         if (cost < best_cost) { best_cost = cost; best = c.cfg; }
     }
     return best;
@@ -656,7 +658,7 @@ static void f16x3p_cfg_tile(int cfg, int& bm, int& bn, int& per_cu) {
         case 4: bm = 256; bn = 128; per_cu = 1; break;
         case 14: bm = 256; bn = 256; per_cu = 1; break;
         case 12: case 23: bm = 256; bn = 192; per_cu = 1; break;
-        case 9: bm = 128; bn = 128; per_cu = 1; break;
+        case 9: case 29: bm = 128; bn = 128; per_cu = 1; break;
         default: bm = 128; bn = 128; per_cu = 2; break;      // 0, 21, 28
     }
 }
@@ -693,7 +695,12 @@ PSAM_API int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     const int64_t tiles = psam_cdiv(M, bm) * psam_cdiv(N, bn), slots = (int64_t)(ncu - 8) * per_cu;
-    if (tiles * 20 > slots * 11) return 1;        // measured (profiles/r03_splitk.log): a gain up to ~0.55 of the slots, best factor 3-4
+    // Measured per shape, alone on the chip (profiles/r06_small_m.txt): splitting pays for 44 tiles on 248 slots (giant proj 24.7 -> 18.6 us, fc2 82.6 -> 38.7)
+    // and LOSES for 132 and 192 tiles (giant qkv 27.9 -> 41.2 us with two splits, fc1 30.1 -> 44.1 with three: 8.6 - 12.6 MB of partial planes per split
+    // through the fabric and a serial fix-up for a K loop that was only 44 slabs long).  Until round 5 the limit was 0.55 of the slots.
+    static int frac_pct = -1;
+    if (frac_pct < 0) { const char* e = getenv("PSAM_GEMM_SPLITK_MAX_FILL_PCT"); frac_pct = e ? atoi(e) : 30; }
+    if (tiles * 100 > slots * frac_pct) return 1;
     int ks = (int)((slots + tiles / 2) / tiles);
     if (ks > 4) ks = 4;
     if (ks > nslabs / 8) ks = nslabs / 8;
@@ -777,6 +784,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
             case 21: rc = launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream); break;
             case 23: rc = launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream); break;
             case 28: rc = launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream); break;
+            case 29: rc = launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 0, 1>(p, stream); break;
             default: psam_set_error("psam_gemm_f16x3p_ex: split-K has no such tile configuration"); return PSAM_EINVAL;
         }
         if (rc != PSAM_OK || counters) return rc;
@@ -932,6 +940,8 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
                                                         : launch_f16x3p<2, 2, 2, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 4 waves, mid-slab stage release
         case 23: return launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream);     // 256x192, mid-slab stage release
         case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 8 waves of 32x64, 2 stages, mid-slab release (70 KiB): 2 per CU
+        case 29: return f16x3p_use_register_epilogue(p) ? launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 0, 1>(p, stream)      // cfg 9 with the register epilogue (round 6)
+                                                        : launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);
         // 30 / 31: three workgroups per CU.  Alone they win on the short launches (proj 38.4 -> 32.3 us, up.3 233 -> 205 us), in the pipelined
         // bench (two batches' kernels co-scheduled) they lose 1.5 % (profiles/r02_gemm_tri_tile.txt): reachable through force_config only
         case 30: return launch_f16x3p<2, 2, 2, 1, 2, 0, 0, 2>(p, stream);     // 128x64, 4 waves of 64x32, 48 KiB (no SwiGLU / fused extras)
