@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, dense peaks at 256 CUs x 2.4 GHz
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16
-TRAFFIC_FILES = {"f16x3": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), "bf16x6": ("r01_v6_traffic.json",), "f32": ("r01_v6_traffic.json",)}
+TRAFFIC_FILES = {"f16x3": ("r06/r06_traffic.json", "r05/r05_traffic.json", "r04/r04_traffic.json", "r03/r03_traffic.json", "r02/r02_traffic.json"), "bf16x6": ("r01/r01_v6_traffic.json",),
+                 "f32": ("r01/r01_v6_traffic.json",)}
 
 
 # BASELINE.json `configs` that fit one GPU (config #4 is cfg2 across 8 GPUs: --gpus 8; config #1 is the CPU plumbing case of the tests)
@@ -627,7 +628,7 @@ def streams_report(args):
 def other_leg(name, base, local, ceiling=None):
     """One BASELINE configuration as a short leg of THIS process: a second model and a second set of graphs on the process's pipeline streams
     (point_sam_amd/streams.py -- until round 5 a leg had to be a fresh subprocess: its pipeline got other streams and ran 1.3 - 2 x slower,
-    profiles/r06_inproc.txt).  `--other-steps` timed passes after 3 warm-ups, ~2 s more of the same passes with package power sampled, the GEMM launch
+    profiles/r06/r06_inproc.txt).  `--other-steps` timed passes after 3 warm-ups, ~2 s more of the same passes with package power sampled, the GEMM launch
     sampling, one oracle run as the CPU baseline and the checker."""
     import gc
     import math

@@ -155,7 +155,7 @@ void psam_gemm_f16x3p_force_splitk_fixup(int32_t mode);
 #ifdef PSAM_BUILD_EXPERIMENTS
 /* Batch-sized launches (>= 2048 rows) of the packed-operand GEMM on the 128x128 register-epilogue configuration: the persistent kernel (csrc/gemm_f16x3c.hip: resident
  * workgroups draw whole tiles from per-XCD queues and keep one continuous stream of K slabs going across tile boundaries; the same bits, measured the same
- * time: profiles/r05_continuous_sweep.txt) -- -1 = default (environment PSAM_GEMM_CONTINUOUS, else off), 0 = never, 1 = wherever it applies. */
+ * time: profiles/r05/r05_continuous_sweep.txt) -- -1 = default (environment PSAM_GEMM_CONTINUOUS, else off), 0 = never, 1 = wherever it applies. */
 void psam_gemm_f16x3p_force_continuous(int32_t mode);
 #endif
 /* ARRIVAL-COUNTER BLOCK (round 6: the library allocates nothing and keeps no per-stream state).  Kernels with an in-kernel fix-up -- the split-K GEMM

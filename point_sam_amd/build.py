@@ -16,7 +16,7 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # (source, extra flags).  The tokenizer must not contract a*b+c into fma: FPS / kNN indices are bit-exact
 # against the oracle's fp32 arithmetic (oracle/tokenizer_oracle.c is built with -ffp-contract=off too).
-# PSAM_BUILD_EXPERIMENTS=1: also build the measured-and-rejected paths (the unit-ring GEMM gemm_f16x3q.hip, the persistent GEMMs gemm_f16x3s.hip (stream-K) and gemm_f16x3c.hip (continuous), the one-launch token side twoway.hip, the
+# PSAM_BUILD_EXPERIMENTS=1: also build the measured-and-rejected paths under csrc/experiments/ (the unit-ring GEMM gemm_f16x3q.hip, the persistent GEMMs gemm_f16x3s.hip (stream-K) and gemm_f16x3c.hip (continuous), the one-launch token side twoway.hip, the
 # forked two-way decoder, the 128x512 row-LayerNorm GEMM tile) -- off by default: they are not on the product path, and their objects, exports, ISA
 # lint and tests cost every build and every test run (tests that need them skip unless the library was built with them).
 EXPERIMENTS = os.environ.get("PSAM_BUILD_EXPERIMENTS", "0") == "1"
@@ -30,7 +30,8 @@ SOURCES = [
     ("rowops.hip", []),
     ("blocks.hip", []),
     ("error.cpp", ["-x", "hip"]),
-] + ([("gemm_f16x3q.hip", []), ("gemm_f16x3s.hip", []), ("gemm_f16x3c.hip", []), ("twoway.hip", [])] if EXPERIMENTS else [])
+] + ([("experiments/gemm_f16x3q.hip", ["-I" + CSRC]), ("experiments/gemm_f16x3s.hip", ["-I" + CSRC]), ("experiments/gemm_f16x3c.hip", ["-I" + CSRC]),
+        ("experiments/twoway.hip", ["-I" + CSRC])] if EXPERIMENTS else [])
 if EXPERIMENTS:
     COMMON = COMMON + ["-DPSAM_BUILD_EXPERIMENTS"]
 FLAGS_STAMP = os.path.join(CSRC, ".build_flags")

@@ -725,7 +725,7 @@ PSAM_API int32_t psam_attention_f16x3(const float* q, int64_t ldq, int64_t sq, c
 //   * one workgroup = 8 waves = 256 query rows of one (cloud, head): a K/V tile is fetched once for all of them;
 //   * online softmax in the log2 domain per lane (= per query row), P produced scaled by 2^14 and split in registers.
 // The output leaves g8-packed for the projection GEMM with the constant scale f16_row_scale(v_bound) (attention outputs are convex
-// combinations of V rows).  47 -> see profiles/r03_attention.txt.
+// combinations of V rows).  47 -> see profiles/r03/r03_attention.txt.
 struct PackedAttnArgs {
     const unsigned char* qkv;      // packed rows: [B * L][ld containers]; q at column 0, k at column D, v at column 2 D (containers)
     const float* sc;               // the rows' (common) scale: sc[b * L] is read

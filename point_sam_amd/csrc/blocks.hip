@@ -629,12 +629,12 @@ int32_t tw_lin(const TwLin& l, const float* x, int64_t M, float* y, int act, flo
 // (a captured call on a stream that has none yet runs the serial sequence).
 // MEASURED SLOWER, so OFF by default (PSAM_TWOWAY_FORK=1 / psam_twoway_decoder_force_fork(1) switch it on): the event hand-overs cost more than the
 // six short launches they take off the critical path -- eager two-way stage 0.43 -> 0.43 ms (no gain), and inside captured graphs every fork / join
-// splits the graph into segments: cfg #2 792 -> 704 clouds/s, cfg #5 131 -> 94 sessions/s, a replayed click 0.61 -> 1.27 ms (profiles/r04_twoway_fork.txt).
+// splits the graph into segments: cfg #2 792 -> 704 clouds/s, cfg #5 131 -> 94 sessions/s, a replayed click 0.61 -> 1.27 ms (profiles/r04/r04_twoway_fork.txt).
 struct TwSide { hipStream_t side; hipEvent_t fork, join1, join2; };
 static int g_tw_fork = -1;
 static bool tw_fork_enabled() {
 #ifndef PSAM_BUILD_EXPERIMENTS
-    return false;      // the forked form lost (profiles/r04_twoway_fork.txt): reachable in experiments builds only
+    return false;      // the forked form lost (profiles/r04/r04_twoway_fork.txt): reachable in experiments builds only
 #endif
     if (g_tw_fork >= 0) return g_tw_fork != 0;
     static int on = -1;
@@ -806,7 +806,7 @@ PSAM_API int32_t psam_twoway_decoder(const psam_twoway_plan_t* plan, const void*
                                          Lk, hd, 1.0f / std::sqrt((float)hd), stream);
         return r;
     };
-    // ---- Round 5: the short sequence (36 launches for depth 2 against 50; profiles/r05_click_kernels_*.txt).  Same operators, regrouped along their
+    // ---- Round 5: the short sequence (36 launches for depth 2 against 50; profiles/r05/r05_click_kernels_*.txt).  Same operators, regrouped along their
     // data dependences:
     //  * every `queries = norm(queries + Linear(..))` of the token side is ONE launch (psam_linear_skinny_ln: the last workgroup of the Linear
     //    normalises the rows; lin2 of the MLP, K = 2048, split over 8 workgroup rows instead of walking K in 16 dependent rounds);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
     sk_f32x4 xa[SK_CH], wb[SK_CH], xn[SK_CH], wn[SK_CH];
     // Loads are UNCONDITIONAL (rows / columns past the end read a clamped row and are never stored; a 16-k slot past K -- K % 16 == 0: inside or outside
     // as a whole -- reads slot 0 and gets a zero weight): a load under a branch costs a full wait at the join, and the sixteen loads of a round became
-    // sixteen round trips (round 5: linear_skinny 5.6 -> see profiles/r05_click_kernels_*.txt).
+    // sixteen round trips (round 5: linear_skinny 5.6 -> see profiles/r05/r05_click_kernels_*.txt).
     auto load = [&](sk_f32x4 (&xr)[SK_CH], sk_f32x4 (&wr)[SK_CH], int kc) {
 #pragma unroll
         for (int s = 0; s < SK_CH; ++s) {

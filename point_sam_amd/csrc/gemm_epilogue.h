@@ -27,7 +27,7 @@ __device__ __forceinline__ float ep_act(float v, int act) { return act == 1 ? ge
 // Every DS operation in flight completes here.  Added in round 3 as the presumed cure of 1e-2 wrong fc2 outputs in multi-stream runs (a DS
 // ordering hazard was suspected); round 4 bisected the failure at ISA level to something else: the pass loop's packed multiply
 // `v_pk_mul_f32 .. op_sel:[0,1]`, which returns wrong lanes 48-63 while another stream's GEMM workgroups are launched on the CU -- the code change
-// merely made hipcc pick another instruction form (profiles/r04_hazard.txt; point_sam_amd/isa_lint.py now rejects a library that contains one).
+// merely made hipcc pick another instruction form (profiles/r04/r04_hazard.txt; point_sam_amd/isa_lint.py now rejects a library that contains one).
 // The drains stay: they cost nothing measurable and keep the loop's DS traffic simple.
 __device__ __forceinline__ void ep_lgkm_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Sum over aligned groups of W = 4, 8 or 16 consecutive lanes, every lane ending with the group's sum, in the order of the xor butterfly
@@ -55,7 +55,7 @@ __device__ __forceinline__ void ep_wave_sync() {
 // LayerNorm, the row's mean and rstd.  Loaded ONCE per wave tile with coalesced loads and fetched per pass with a lane shuffle; together
 // with the lane's column constants (bias, inverse weight-row scales, folded-LayerNorm c) they form the epilogue's PREFETCH, which a
 // kernel issues BEFORE its K loop: the epilogue then starts with every operand it needs except the accumulators (and the residual rows)
-// already in registers.  (Measured on the 256x256 ping-pong tile, profiles/r03_epi_pmc.txt: 2 500 instructions per wave took 52 k cycles,
+// already in registers.  (Measured on the 256x256 ping-pong tile, profiles/r03/r03_epi_pmc.txt: 2 500 instructions per wave took 52 k cycles,
 // 33 k of them parked at s_waitcnt -- dependent 4-byte global loads inside every pass and one LDS round trip at a time.)
 template <int TM>
 struct EpRows {
@@ -257,7 +257,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
         if (interior) {
             // ---- the passes of the stripe, as a ROLLED loop (one copy of the code per stripe, resident in the instruction cache after its first
             // pass) that is SPECIALISED on what the launch asks of the epilogue.  History (256x256 ping-pong tile, qkv shape, 32 passes per wave;
-            // profiles/r03_epi_*.txt): fully unrolled with every option a run-time branch, 31 us of an 95 us kernel (each pass a separate cold copy
+            // profiles/r03/r03_epi_*.txt): fully unrolled with every option a run-time branch, 31 us of an 95 us kernel (each pass a separate cold copy
             // of the code); rolled, 20 us -- of which 12 us were the ~110 instructions and ~15 scalar branches of ONE generic pass body and 5 us
             // the stores.  The option set of a launch is fixed, so the loop is instantiated for the combinations the model's GEMMs use (F >= 0:
             // every option test folds at compile time) and once generically (F < 0).
@@ -334,7 +334,7 @@ __device__ __forceinline__ void gemm_store_tile(const ArgsT& p, ep_f32x16 (&acc)
 #pragma unroll 1
                 for (int q = 0; q < np_run; ++q) {
                     // (the round-3 version fetched pass q+1 here, one pass ahead; that form of the loop compiled to `v_pk_mul_f32 .. op_sel:[0,1]` for
-                    // lnc * mean, the instruction behind the 1e-2 multi-stream errors -- see ep_lgkm_drain() and profiles/r04_hazard.txt;
+                    // lnc * mean, the instruction behind the 1e-2 multi-stream errors -- see ep_lgkm_drain() and profiles/r04/r04_hazard.txt;
                     // tests/test_gpu_kernels.py::test_fused_mlp_bitwise_stable_beside_other_streams and the ISA lint hold the line.)
                     const PassIn cur = fetch(q);
                     const int rl = q * rpp + rl0;

@@ -10,7 +10,7 @@
 //     swap with lanes 0-31 of the second) per packed register turns runs (g, h = 0 | 1) into column groups 8 (2 g' + h) .. + 7;
 //   * the LayerNorm partials of a gated row (32 columns) are in-lane sums plus three half-wave exchanges.
 // gemm_epilogue.h's LDS transposition (ds_write x 16 per tile, rolled pass loop of LDS reads + ds_bpermute row scalars + parked rows) is not
-// used at all: 11-12 us of a 75 us 256x256 tile there (profiles/r03_epi_ablation.txt).  The arithmetic per element -- and the summation order of the row statistics -- is the same as in
+// used at all: 11-12 us of a 75 us 256x256 tile there (profiles/r03/r03_epi_ablation.txt).  The arithmetic per element -- and the summation order of the row statistics -- is the same as in
 // gemm_epilogue.h, so both epilogues give the same bits (tests/test_gpu_kernels.py::test_gemm_f16x3_register_epilogue_bitwise).
 //
 // Options covered (what the encoder / decoder hot path launches): bias, alpha, GELU / ReLU, SwiGLU gate (act == 3, column tiles (2q, 2q+1)),

@@ -549,7 +549,7 @@ static int f16x3p_epilogue_mode() {
 // Whether psam_gemm_f16x3p_ex takes psam_gemm_fuse_t.row_ln_* (Linear -> LayerNorm -> activation in one GEMM) for N output columns: 256 always
 // (full-row wave tiles, LDS epilogue), 512 with the register epilogue (128x512 workgroup tiles).
 // N == 512 is OFF by default (environment PSAM_GEMM_ROWLN512=1 turns it on): measured SLOWER than the two launches it replaces at the benchmark's
-// size -- PatchEncoder 1.27 ms against 1.05 ms (profiles/r04_rowln512.txt): one 8-wave workgroup per CU runs its K loop (8 steps), the three row
+// size -- PatchEncoder 1.27 ms against 1.05 ms (profiles/r04/r04_rowln512.txt): one 8-wave workgroup per CU runs its K loop (8 steps), the three row
 // passes (128 erf-GELUs per lane) and 256 KiB of stores back to back with nothing to overlap them, where GEMM + LayerNorm kernel overlap across
 // many resident workgroups.  Kept reachable, parity-tested (tests/test_gpu_kernels.py::test_gemm_row_ln_512).
 PSAM_API int32_t psam_gemm_f16x3p_fused_row_ln(int32_t N) {
@@ -572,7 +572,7 @@ bool f16x3p_use_register_epilogue(const F16PArgs& p) {
     if (p.gmax_out || p.row_ln_g || (p.no_store && !p.hyper)) return false;      // options only gemm_epilogue.h implements
     // per-group row bias: implemented, bitwise equal, but only when forced -- its one user (PatchEncoder conv2.0, K = 128, 512 MB of fp32 output)
     // is bound by the stores, and one-row-per-lane 16-byte stores lose against the LDS epilogue's full rows (247 vs 235 us,
-    // profiles/r04_gemm_experiments.txt)
+    // profiles/r04/r04_gemm_experiments.txt)
     if (p.rowbias && (g_f16x3p_tr <= 0 || (p.ldrb & 3) != 0 || (((uintptr_t)p.rowbias) & 15) != 0 || p.act == 3)) return false;
     if (p.hyper && (p.hyper_rows % 32 != 0 || (((uintptr_t)p.hyper) & 15) != 0 || (p.N & 3) != 0)) return false;
     if ((((uintptr_t)p.scaleW | (uintptr_t)p.bias | (uintptr_t)p.ln_c) & 15) != 0) return false;      // float4 loads of the column constants
@@ -580,7 +580,7 @@ bool f16x3p_use_register_epilogue(const F16PArgs& p) {
 }
 
 // Tile configuration for a shape.  Measured per-CU rates of the configurations are within ~15 % of each other once a CU is busy
-// (profiles/r02_gemm_p_sweep_*.log; the kernel is power-limited, profiles/r02_gemm_power_limit.txt); what differs is how many rounds
+// (profiles/r02/r02_gemm_p_sweep_*.log; the kernel is power-limited, profiles/r02/r02_gemm_power_limit.txt); what differs is how many rounds
 // of workgroups a launch needs, how full the last one is -- and how a launch behaves when a few CUs are NOT available: the tokenizer
 // of the next batch (FPS: one 1024-thread workgroup per cloud, a whole CU each, ~2 ms per step) runs beside the dense stage, and a
 // launch of exactly #CU one-per-CU workgroups then needs a second round for the last few tiles (twice the time).  So the rounds are
@@ -695,7 +695,7 @@ PSAM_API int32_t psam_gemm_f16x3p_splitk(int32_t M, int32_t N, int32_t K, int32_
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     const int64_t tiles = psam_cdiv(M, bm) * psam_cdiv(N, bn), slots = (int64_t)(ncu - 8) * per_cu;
-    // Measured per shape, alone on the chip (profiles/r06_small_m.txt): splitting pays for 44 tiles on 248 slots (giant proj 24.7 -> 18.6 us, fc2 82.6 -> 38.7)
+    // Measured per shape, alone on the chip (profiles/r06/r06_small_m.txt): splitting pays for 44 tiles on 248 slots (giant proj 24.7 -> 18.6 us, fc2 82.6 -> 38.7)
     // and LOSES for 132 and 192 tiles (giant qkv 27.9 -> 41.2 us with two splits, fc1 30.1 -> 44.1 with three: 8.6 - 12.6 MB of partial planes per split
     // through the fabric and a serial fix-up for a K loop that was only 44 slabs long).  Until round 5 the limit was 0.55 of the slots.
     static int frac_pct = -1;
@@ -887,7 +887,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
 #endif
     if (cfg >= 80 && cfg < 90) cfg = f16x3p_pick(M, N, K, act, true);      // (unit-ring configurations: experiments builds only)
 #ifdef PSAM_BUILD_EXPERIMENTS
-    // persistent forms of cfg 21, both measured and not adopted (profiles/r05_continuous_sweep.txt, r05_streamk_sweep.txt): 94 = whole tiles from per-XCD
+    // persistent forms of cfg 21, both measured and not adopted (profiles/r05/r05_continuous_sweep.txt, r05_streamk_sweep.txt): 94 = whole tiles from per-XCD
     // queues, one continuous slab stream per workgroup (gemm_f16x3c.hip: the same bits as cfg 21, the same time; 95: one workgroup per CU; PSAM_GEMM_CONTINUOUS=1
     // switches it in for the batch-sized launches), 90 .. 93 = even shares of the K slabs (stream-K, gemm_f16x3s.hip: slower)
     if (cfg == 94 || cfg == 95 || (cfg == 21 && g_f16x3p_cfg < 0 && M >= 2048 && f16x3p_continuous_enabled())) {
@@ -930,7 +930,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
 #undef ABL_CASE
     }
 #endif
-    switch (cfg) {   // the configurations that won somewhere in the sweeps (profiles/r02_gemm_p_sweep_*.log); numbering kept from the sweeps
+    switch (cfg) {   // the configurations that won somewhere in the sweeps (profiles/r02/r02_gemm_p_sweep_*.log); numbering kept from the sweeps
         case 0: return launch_f16x3p<2, 2, 2, 2, 2, 0>(p, stream);            // 128x128, 4 waves of 64x64, 2 stages (64 KiB): 2 workgroups per CU
         case 4: return launch_f16x3p<4, 2, 2, 2, 3, 0>(p, stream);            // 256x128, 8 waves, 3 stages (144 KiB)
         case 9: return launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);            // 128x128, 8 waves of 32x64, 4 stages + look-ahead fragments (128 KiB)
@@ -943,7 +943,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         case 29: return f16x3p_use_register_epilogue(p) ? launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 0, 1>(p, stream)      // cfg 9 with the register epilogue (round 6)
                                                         : launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);
         // 30 / 31: three workgroups per CU.  Alone they win on the short launches (proj 38.4 -> 32.3 us, up.3 233 -> 205 us), in the pipelined
-        // bench (two batches' kernels co-scheduled) they lose 1.5 % (profiles/r02_gemm_tri_tile.txt): reachable through force_config only
+        // bench (two batches' kernels co-scheduled) they lose 1.5 % (profiles/r02/r02_gemm_tri_tile.txt): reachable through force_config only
         case 30: return launch_f16x3p<2, 2, 2, 1, 2, 0, 0, 2>(p, stream);     // 128x64, 4 waves of 64x32, 48 KiB (no SwiGLU / fused extras)
         case 31: return launch_f16x3p<2, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 64x128, 4 waves of 32x64, 48 KiB: 3 workgroups per CU
         case 40: return launch_f16x3p<4, 1, 1, 8, 2, 0, 0, 2>(p, stream);     // 128x256, 4 waves of 32x256 (whole rows per wave: row epilogues), 133 KiB

@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned long long gemm_now() {
 // keeps about 2.5 MiB of operands in its L2: with panels of P column tiles the XCD's W panel (P * BN * K * 4 B) is fetched once per panel
 // it touches if it fits, once per group of concurrently running row bands if it does not; every A row band (BM * K * 4 B) of the panel
 // is fetched once.  The P with the least modelled traffic wins (ties: the widest).  PSAM_GEMM_PANEL overrides (0: plain row-major).
-// Measured (profiles/r02_gemm_panel_sweep.log): qkv 81.7 -> 79.6 us, fc1 143.4 -> 138.2 us, two-stream layer 303.9 -> 292 us.
+// Measured (profiles/r02/r02_gemm_panel_sweep.log): qkv 81.7 -> 79.6 us, fc1 143.4 -> 138.2 us, two-stream layer 303.9 -> 292 us.
 static inline int f16x3p_panel(int tiles_m, int tiles_n, int BM, int BN, int K) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("PSAM_GEMM_PANEL"); forced = e ? atoi(e) : -1; }

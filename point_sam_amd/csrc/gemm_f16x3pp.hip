@@ -2,7 +2,7 @@
 // (C = act(alpha A W^T + bias + rowbias) + residual on g8-packed row-scaled hi|lo fp16 operands, hi*lo + lo*hi + hi*hi on
 // v_mfma_f32_32x32x16_f16, fp32 accumulation in the same order => bit-identical results), a different execution structure.
 //
-// Why (profiles/r02_gemm_clock_counters.txt): in the lock-step ring kernel every wave of a CU reads fragments at the same time, issues
+// Why (profiles/r02/r02_gemm_clock_counters.txt): in the lock-step ring kernel every wave of a CU reads fragments at the same time, issues
 // its MFMAs at the same time and waits at the slab barrier at the same time -- the matrix pipe idles while the data path runs (busy
 // 0.44), and with two 128x128 workgroups per CU the L2 -> LDS path carries 42 B/clk/CU at full MFMA rate against ~32 B/clk/CU measured.
 // Here ONE workgroup of 8 waves owns a CU and a tile of up to 256x256 (half the operand bytes per flop), and its waves form two groups
@@ -305,7 +305,7 @@ bool f16x3pp_supports(int cfg, int act, bool stats, bool gmax, bool hyper) {
     return true;
 }
 
-// Where the ping-pong kernel replaces the lock-step one.  Measured (profiles/r03_gemm_pp_bench.log, r03_bench_ab.log): alone it wins on fc1
+// Where the ping-pong kernel replaces the lock-step one.  Measured (profiles/r03/r03_gemm_pp_bench.log, r03_bench_ab.log): alone it wins on fc1
 // (256x128 tile: 128 vs 132 us), on the mini-PointNet's conv2.3 (256x256: 416 vs 431 us) and, as 128x128, on proj / fc2 (30 vs 31, 65.5 vs
 // 67.5 us); in three-stream layer loops the 256x256 tile is the fastest arrangement measured (268 vs 281 us per layer).  In the pipelined
 // benchmark (two dense streams + the tokenizer stream, HIP graphs) none of it shows: 751 clouds/s with and without it, 736 / 722 when every

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float* __re
                                                                int64_t* __restrict__ idx_out, float* __restrict__ centers_out) {
     // xcd_stride == 8: the grid is 8 W wide and only the workgroups whose id is congruent to the cloud's XCD (ids are dealt to the eight
     // XCDs round-robin) take part, the others leave at once -- all W workgroups of a cloud then share one XCD and the hand-over is
-    // ~0.3 us shorter (scripts/exp/fabric_probe.hip, profiles/r03_fabric_probe.txt).  Placement is a speed matter only: the keys are
+    // ~0.3 us shorter (scripts/exp/fabric_probe.hip, profiles/r03/r03_fabric_probe.txt).  Placement is a speed matter only: the keys are
     // agent-scope atomics either way.
     const int b = blockIdx.y;
     int w = blockIdx.x;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void fps_cell_scatter_kernel(const float* __re
 
 // (Tried and dropped, round 5: publishing the candidate's COORDINATES with the key -- four self-validating 64-bit words per slot -- so that nobody fetches
 // the winner's point after the exchange: exact, but four polled loads and four stores per hand-over cost more than the three scalar loads they replace,
-// cfg #3 FPS 4.18 -> 4.91 ms, one cloud of 32768 points 0.97 -> 1.12 ms; profiles/r05_fps_pruned.txt.)
+// cfg #3 FPS 4.18 -> 4.91 ms, one cloud of 32768 points 0.97 -> 1.12 ms; profiles/r05/r05_fps_pruned.txt.)
 template <int PPT4>
 __global__ __launch_bounds__(FPS_THREADS) void fps_coop_pruned_kernel(const float* __restrict__ xyz, const float* __restrict__ psoa, int N, int64_t npad,
                                                                       int G, int W, int xcd_stride, unsigned long long* __restrict__ cand,
@@ -622,8 +622,8 @@ static int fps_num_cus() {
 }
 
 // cooperative layout: groups of 4096 points, PPT4 of them per workgroup, W <= 64 workgroups per cloud, all B*W resident.  The hand-over
-// gets slower with W (1.0 us per iteration up to 16 workgroups on one XCD, 1.7 us at 32: profiles/r03_fabric_probe.txt), the scan with
-// PPT4 (16 waves share four SIMDs).  Measured per iteration (profiles/r03_fps_coop.txt, N = 131072): W = 16 x 8 points per thread 1.98 us,
+// gets slower with W (1.0 us per iteration up to 16 workgroups on one XCD, 1.7 us at 32: profiles/r03/r03_fabric_probe.txt), the scan with
+// PPT4 (16 waves share four SIMDs).  Measured per iteration (profiles/r03/r03_fps_coop.txt, N = 131072): W = 16 x 8 points per thread 1.98 us,
 // W = 8 x 16 points 2.57 us, W = 32 x 4 points 2.98 us; N = 65536: W = 16 x 4 points 1.64 us, W = 8 x 8 points 1.85 us.  So: the fewest
 // points per thread that bring W down to 16, else as few workgroups as the registers allow (PPT4 <= 4).
 static int fps_coop_ppt4(int B, int N, int* W) {
@@ -637,7 +637,7 @@ static int fps_coop_ppt4(int B, int N, int* W) {
     if (groups == 8) {
         // N = 32768 (cfg #2 / #5): the single-workgroup kernel scans 32 points per thread (2.6 us per iteration).  Eight workgroups of 4 points
         // per thread: 1.72 us (0.88 instead of 1.3 ms for G = 512) -- but eight CUs per cloud instead of one, which a batch running beside the
-        // dense stage of the previous one cannot afford (two workgroups of 16 points: 2.55 us, no gain; profiles/r03_fps_coop.txt).  So
+        // dense stage of the previous one cannot afford (two workgroups of 16 points: 2.55 us, no gain; profiles/r03/r03_fps_coop.txt).  So
         // only for one or two clouds (the interactive case).
         if (B > 2 || ppt4_max < 1) return 0;
         *W = 8;

@@ -4,7 +4,7 @@ On gfx950 `v_pk_mul_f32` / `v_pk_add_f32` / `v_pk_fma_f32` whose op_sel bits dif
 source pair and the low register of another, e.g. `v_pk_mul_f32 v[52:53], v[74:75], v[42:43] op_sel:[0,1]`) return a result computed from a wrong (zero)
 operand in lanes 48-63 while workgroups with a large LDS / register allocation (the LDS-DMA GEMM kernels of another stream) are being launched on the
 same CU: 1e7 wrong results of 1.6e10 beside the f16x3 GEMM, 0 alone, 0 for the uniform forms, for `v_pk_mov_b32` and for the scalar `v_mul_f32`
-(scripts/exp/r04_pk_opsel.hip, profiles/r04_hazard.txt).  That was round 3's "cross-lane hazard" (1e-2 wrong fc2 outputs in multi-stream runs).  hipcc
+(scripts/exp/r04_pk_opsel.hip, profiles/r04/r04_hazard.txt).  That was round 3's "cross-lane hazard" (1e-2 wrong fc2 outputs in multi-stream runs).  hipcc
 selects these forms by itself when a packed operation broadcasts element 1 of a 64-bit value, so the library is checked after every build:
 
     python -m point_sam_amd.isa_lint [path/to/libpointsam_hip.so]

@@ -88,8 +88,8 @@ class PointCloudSAM:
         self.precision = precision
         self.c_blocks = True      # "f16x3", EVA02 blocks: one psam_eva_block call per layer (csrc/blocks.hip: the same eight launches, sequenced and
                                   # packed by the library) instead of sequencing them here; False: the Python sequence below (tests A/B both)
-        self.fuse_tokens = False  # the decoder's token side as one launch per two-way layer (csrc/twoway.hip) instead of ~22: parity-green but
-                                  # slower (0.56 vs 0.48 ms at cfg #2, profiles/r03_twoway.txt), so off; tests A/B both
+        self.fuse_tokens = False  # the decoder's token side as one launch per two-way layer (csrc/experiments/twoway.hip) instead of ~22: parity-green but
+                                  # slower (0.56 vs 0.48 ms at cfg #2, profiles/r03/r03_twoway.txt), so off; tests A/B both
         self._tw = None
         self.row_bounds = True    # "f16x3": the fused MLP's packed rows are scaled by a per-row bound from ||h||_2 (False: the (k1 / scale + k2)^2 form)
         self.fuse_mlp = True      # "f16x3": EVA02 MLP as two GEMMs with nothing in between (False = separate inner LayerNorm; tests A/B both)
@@ -104,7 +104,7 @@ class PointCloudSAM:
         self.fuse_upscale = True  # "f16x3": the 3-NN interpolation hands its rows to the upscaling MLP packed (no pack pass)
         # "f16x3": the upscaling MLP's LayerNorm/GELU and the hyper-network products inside two full-row GEMM epilogues.  Parity-tested,
         # but OFF: the 128x256 one-wave-per-SIMD tile it needs runs 383 us against 188 us for the 128x128 tile at [262144, 256, 256],
-        # so the chain measured 1146 us fused against 853 us (scripts/exp/upscale_bench.py, profiles/r02_upscale_chain.log).
+        # so the chain measured 1146 us fused against 853 us (scripts/exp/upscale_bench.py, profiles/r02/r02_upscale_chain.log).
         self.fuse_upscale_rows = False
         self.fuse_patch = True    # "f16x3": mini-PointNet hand-overs packed, max-pools in the GEMM epilogues (False = separate kernels)
         self.cfg = cfg
@@ -198,7 +198,7 @@ class PointCloudSAM:
                     # |silu(g_n) x_n| <= (a_n t + b_n)(c_n t + d_n) with a, c the fc1_g / fc1_x weight row norms and b, d the |biases|;
                     # the maximum over n of the quadratic is bounded coefficient-wise.  Outlier rows of fc1_g and fc1_x rarely share an n,
                     # and ||h||_2 is far below sqrt(D) max|h| when h has outlier channels: the (k1 / scale + k2)^2 form lost 10+ bits on
-                    # heavy-tailed weights (tests/test_gpu_e2e.py::test_heavy_tailed_weights_against_oracle, profiles/r03_heavy_diag.txt)
+                    # heavy-tailed weights (tests/test_gpu_e2e.py::test_heavy_tailed_weights_against_oracle, profiles/r03/r03_heavy_diag.txt)
                     a_n, c_n = w[blk.p + ".mlp.fc1_g.weight"].double().norm(dim=1), w[blk.p + ".mlp.fc1_x.weight"].double().norm(dim=1)
                     b_n, d_n = w[blk.p + ".mlp.fc1_g.bias"].double().abs(), w[blk.p + ".mlp.fc1_x.bias"].double().abs()
                     blk.u_bound = (1.002 * float((a_n * c_n).max()), 1.002 * float((a_n * d_n + b_n * c_n).max()), 1.002 * float((b_n * d_n).max()) + 1e-30)
@@ -461,7 +461,7 @@ class PointCloudSAM:
         return ops.attention_small(q, k, v, o, Z, H, Lq, Lk, hd, 1.0 / math.sqrt(hd))
 
     def _two_way_fused(self, src, pos, tokens, Z, G, T, rep):
-        """_two_way with the token side of every layer in one launch (csrc/twoway.hip): per layer the image-side k / v projections, the token
+        """_two_way with the token side of every layer in one launch (csrc/experiments/twoway.hip): per layer the image-side k / v projections, the token
         kernel, then the image -> token attention and its projection + norm4 on the patch tokens."""
         cfg, E, eps, H = self.cfg, self.cfg.embed_dim, self.cfg.ln_eps, self.cfg.dec_heads
         P = "mask_decoder.transformer"

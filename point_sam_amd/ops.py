@@ -860,7 +860,7 @@ class CTwoWay:
 
 class TwoWayLayerWeights:
     """The weight pointers of one TwoWayAttentionBlock's token side (or of the final token -> image attention: final=True) as a
-    psam_twoway_tokens_t skeleton (csrc/twoway.hip); keeps the tensors alive.  w: name -> fp32 tensor; prefix: e.g.
+    psam_twoway_tokens_t skeleton (csrc/experiments/twoway.hip); keeps the tensors alive.  w: name -> fp32 tensor; prefix: e.g.
     'mask_decoder.transformer.layers.0' or, with final=True, 'mask_decoder.transformer' (final_attn_token_to_image / norm_final_attn)."""
 
     def __init__(self, w, prefix: str, final: bool = False):
@@ -909,7 +909,7 @@ def twoway_tokens_ws(mlp: int, device) -> torch.Tensor:
 
 
 def twoway_tokens(lw: TwoWayLayerWeights, queries, pe, kimg, vimg, Z, T, G, heads, eps, ws, ktok=None, vtok=None, skip_pe=False):
-    """One launch for the token side of a two-way layer (csrc/twoway.hip; transformer.py:144-175): queries [Z*T, 256] updated in place; pe the
+    """One launch for the token side of a two-way layer (csrc/experiments/twoway.hip; transformer.py:144-175): queries [Z*T, 256] updated in place; pe the
     token embeddings (query_pe); kimg / vimg [Z*G, 128] row views of the patch tokens' k / v projections; ktok / vtok [Z*T, 128] receive the
     k / v projections for the image -> token attention (not for the final attention)."""
     import ctypes

@@ -111,7 +111,7 @@ def tokenizer_metrics(stage_ms: dict, B: int, N: int, G: int, K: int, traffic: d
                            {"us_per_iteration": round(stage_ms["fps"] * 1e3 / G, 3), "iterations": G,
                             "bound": "dependent iterations: distance update (VALU) + workgroup arg-max (DPP / LDS / barrier latency) per iteration; the multi-workgroup kernel (N > 32768, or "
                                      "one or two clouds) adds one store + one polled load across the fabric (~1.0 us) and prunes the scan exactly (distance_evals counts the un-pruned "
-                                     "algorithm's evaluations): its iteration is a latency chain, profiles/r05_fps_pruned.txt"})
+                                     "algorithm's evaluations): its iteration is a latency chain, profiles/r05/r05_fps_pruned.txt"})
     if stage_ms.get("knn"):
         out["knn"] = entry(stage_ms["knn"], float(B) * G * N * 2, CHIP_CUS, model_bytes=float(B) * (G * N * 12 + G * K * 8), pmc_key="knn_band_kernel" if N == 32768 and B == 8 else None, extra=
                            {"bound": "VALU + L2 stream: one histogram sweep + one collection sweep over the cloud per center (2 distance evaluations per point-center pair; "

@@ -1,6 +1,6 @@
 """The process-wide HIP streams of the pipelines, chosen by PROBING how the runtime mapped them onto the hardware.
 
-What round 6 found (profiles/r06_inproc.txt, r06_stream_alias.txt, r06_pipe_probe.txt, r06_same_pipe_probe.txt; scripts/exp/r06_*.py):
+What round 6 found (profiles/r06/r06_inproc.txt, r06_stream_alias.txt, r06_pipe_probe.txt, r06_same_pipe_probe.txt; scripts/exp/r06_*.py):
 
 * ROCm (ROCclr, 7.x) folds the HIP streams of a process onto at most GPU_MAX_HW_QUEUES (default 4) hardware queues per priority, in order of FIRST USE,
   and the hardware queues onto the four pipes of the compute command processor, in order of creation.  torch.cuda.Stream() hands out the streams of a

@@ -89,7 +89,7 @@ int main() {
         for (int stride : {1, 8}) {
             if (W * stride > 256) continue;
             if (run<0>("agent-scope atomics (sc1)", W, stride, slots, xcc, cyc)) return 1;
-            // sc0 alone (bypass the CU's L1 only) never becomes visible to the pollers, not even on one XCD: measured, see profiles/r03_fabric_probe.txt
+            // sc0 alone (bypass the CU's L1 only) never becomes visible to the pollers, not even on one XCD: measured, see profiles/r03/r03_fabric_probe.txt
             if (W == 8 && getenv("PROBE_SC0") && run<1>("sc0 (L2 of the XCD)", W, stride, slots, xcc, cyc)) return 1;
         }
     }

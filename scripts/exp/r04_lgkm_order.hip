@@ -1,5 +1,5 @@
 // Round 4, VERDICT item 2: does a COUNTED s_waitcnt lgkmcnt(1) cover ds_bpermute / ds_read results when a ds_write was issued behind them?
-// The round-3 failure (gemm_epilogue.h pass loop at 1179a69, ISA in profiles/r04_hazard_isa.txt) consumed three ds_bpermute results and a
+// The round-3 failure (gemm_epilogue.h pass loop at 1179a69, ISA in profiles/r04/r04_hazard_isa.txt) consumed three ds_bpermute results and a
 // ds_read_b128 after `ds_write_b128 ; s_waitcnt lgkmcnt(1)` -- correct only if DS operations retire in issue order.  Victim: that exact
 // instruction mix in a loop, every result checked against its closed form.  Aggressor (other stream, co-resident on every CU): LDS-DMA
 // (buffer_load ... lds) + ds_read traffic, the data path of the GEMM main loop that shared the CU when the failure was seen.

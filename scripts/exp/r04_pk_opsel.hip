@@ -1,4 +1,4 @@
-// Reproducer for the round-3 "cross-lane hazard" (VERDICT r03 item 2), bisected at ISA level in round 4 (profiles/r04_hazard.txt): on gfx950 a packed-FP32
+// Reproducer for the round-3 "cross-lane hazard" (VERDICT r03 item 2), bisected at ISA level in round 4 (profiles/r04/r04_hazard.txt): on gfx950 a packed-FP32
 // VOP3P instruction whose op_sel makes the LOW result read the HIGH register of a source pair -- e.g. `v_pk_mul_f32 v[52:53], v[74:75], v[42:43] op_sel:[0,1]` --
 // returns results computed from a wrong operand in lanes 48-63 while a wave of the LDS-DMA GEMM kernel (another stream) is resident on the SIMD.  Alone, or
 // beside pure MFMA waves, it never fails.  Each form below runs the bare instruction on fixed registers and compares with v_mul_f32 / v_add_f32 / v_fma_f32.

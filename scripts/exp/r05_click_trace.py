@@ -2,7 +2,7 @@
 list of one decode with its durations.  A torch.cumsum launch separates the decodes in the trace.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/click -o t -- python scripts/exp/r05_click_trace.py run
-    python scripts/exp/r05_click_trace.py report gpurun_out/click/**/t_kernel_trace.csv > profiles/r05_click_kernels.txt"""
+    python scripts/exp/r05_click_trace.py report gpurun_out/click/**/t_kernel_trace.csv > profiles/r05/r05_click_kernels.txt"""
 import sys, os, csv, glob
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 

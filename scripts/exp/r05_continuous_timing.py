@@ -1,4 +1,4 @@
-"""Where the persistent continuous-stream GEMM's cycles go (csrc/gemm_f16x3c.hip, TIMING instance of the measurement build
+"""Where the persistent continuous-stream GEMM's cycles go (csrc/experiments/gemm_f16x3c.hip, TIMING instance of the measurement build
 PSAM_HIP_LIB=scripts/exp/libpointsam_abl.so): per wave the cycles in the K loops (incl. drawing tiles) and in the epilogues, per encoder shape, next to
 the plain kernels' times (HIP events): cfg 21 = one workgroup per tile, 94 = continuous (two resident workgroups per CU), 95 = continuous, one per CU."""
 import ctypes, os, sys

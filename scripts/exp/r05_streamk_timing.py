@@ -1,4 +1,4 @@
-"""Where the persistent stream-K GEMM's cycles go (csrc/gemm_f16x3s.hip, TIMING instance of the measurement build PSAM_HIP_LIB=scripts/exp/libpointsam_abl.so):
+"""Where the persistent stream-K GEMM's cycles go (csrc/experiments/gemm_f16x3s.hip, TIMING instance of the measurement build PSAM_HIP_LIB=scripts/exp/libpointsam_abl.so):
 per wave the cycles in the K loops, in issuing the next piece's first slabs, parking a part, counting in, combining, epilogues; per shape and mode
 (90 = even shares, 91 = whole tiles round-robin, 92 = even shares on one workgroup per CU), next to the plain kernels' times (HIP events)."""
 import ctypes, os, sys

@@ -155,7 +155,7 @@ def test_heavy_tailed_weights_against_oracle(gpu, name, B, fc1_shift, gain, mass
 
 @pytest.mark.parametrize("precision,B,clicks,rep", [("f32", 2, 1, 1), ("f16x3", 2, 3, 2), ("f16x3", 1, 9, 1)])
 def test_fused_token_decoder_matches_unfused(gpu, precision, B, clicks, rep):
-    """One launch per two-way layer for the token side (csrc/twoway.hip: team of workgroups, counter barriers between the stages) against the
+    """One launch per two-way layer for the token side (csrc/experiments/twoway.hip: team of workgroups, counter barriers between the stages) against the
     ~22 separate launches it replaces: same arithmetic, so the logits agree to fp32 round-off; repeated runs are bitwise equal (no stage reads
     a row before the barrier that publishes it); with and without a dense prompt mask."""
     _needs_experiments()

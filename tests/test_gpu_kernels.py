@@ -613,7 +613,7 @@ def test_interp3_bitwise_stable_beside_gemm_stream(ops):
     BITS alone and while another stream launches GEMM workgroups.  Until round 4 the kernel multiplied by its second weight with
     `v_pk_mul_f32 .. op_sel:[1,0]`, one of the packed forms that return wrong lanes 48-63 beside such workgroups in the probe
     (point_sam_amd/isa_lint.py, scripts/exp/r04_pk_opsel.hip).  The pre-fix build also passes this test (the kernel's short-lived waves were never
-    caught, profiles/r04_hazard.txt) -- the ISA lint is what keeps the form out; this holds the line on the behaviour."""
+    caught, profiles/r04/r04_hazard.txt) -- the ISA lint is what keeps the form out; this holds the line on the behaviour."""
     g = torch.Generator().manual_seed(0)
     Z, G, C, N = 8, 512, 256, 32768
     src = cu(torch.randn(Z, G, C, generator=g))
@@ -789,14 +789,14 @@ def test_gemm_f16x3_register_epilogue_bitwise(ops):
 
 @pytest.mark.parametrize("M,D,H", [(4096, 1024, 2730), (2048, 1024, 2730), (2048, 512, 4090), (8192, 1024, 2730)])
 def test_gemm_f16x3_continuous(ops, M, D, H):
-    """The persistent kernel of the batch-sized encoder GEMMs (csrc/gemm_f16x3c.hip: resident workgroups draw whole tiles from per-XCD queues and run one
+    """The persistent kernel of the batch-sized encoder GEMMs (csrc/experiments/gemm_f16x3c.hip: resident workgroups draw whole tiles from per-XCD queues and run one
     continuous stream of K slabs across tile boundaries -- the next tile's first slabs are in LDS before the finished tile's epilogue runs) against the
     one-workgroup-per-tile kernel on the encoder's fused GEMMs -- packed q|k|v, projection + residual, fc1 (SwiGLU gate + row statistics + packed
     output), fc2 with the folded LayerNorm, a GELU (timm Eva block shapes, pc_encoder.py:138-139): the SAME BITS (same products, same order per tile),
     from launch to launch and while another stream keeps the CUs busy (which workgroup draws which tile must not matter).  Shapes: 1.5 tiles per
     resident workgroup (4096 rows), fewer tiles than workgroups, an odd number of K slabs per tile (the K = 1056 launch: the ring parity flips at every
     tile boundary), several tiles per workgroup (8192 rows).  (Measured the same time as the one-workgroup-per-tile kernel -- the GEMM is power-bound,
-    profiles/r05_power_gemm.txt -- hence an experiments-build kernel.)"""
+    profiles/r05/r05_power_gemm.txt -- hence an experiments-build kernel.)"""
     if not ops._lib.has_experiments():
         pytest.skip("measured-and-not-adopted path: the library was built without PSAM_BUILD_EXPERIMENTS=1")
     L = ops._lib.load()
@@ -858,7 +858,7 @@ def test_gemm_f16x3_continuous(ops, M, D, H):
 def test_gemm_row_ln_512(ops):
     """Linear (+ per-group row bias) -> LayerNorm -> GELU -> packed rows as ONE GEMM on full-row 128x512 tiles (register epilogue, two-pass row
     statistics across the row band's waves): PatchEncoder's conv2.0 / conv2.1 (common.py:493-496).  Against fp64; the packed rows decode to
-    fp32-grade values under the a-priori LayerNorm bound.  (Off in the model by default: measured slower, profiles/r04_rowln512.txt.)"""
+    fp32-grade values under the a-priori LayerNorm bound.  (Off in the model by default: measured slower, profiles/r04/r04_rowln512.txt.)"""
     if not ops._lib.has_experiments():
         pytest.skip("measured-and-rejected path: the library was built without PSAM_BUILD_EXPERIMENTS=1")
     L = ops._lib.load()

@@ -1,6 +1,6 @@
 """The process-wide pipeline streams (point_sam_amd/streams.py) and what they are for: a SECOND and THIRD pipeline in one process must run at the rate
 of a fresh process (until round 5 they ran 1.3 - 2 x slower: their streams landed on hardware queues that shared a command-processor pipe --
-profiles/r06_inproc.txt).  VERDICT r05 item 1."""
+profiles/r06/r06_inproc.txt).  VERDICT r05 item 1."""
 import json
 import os
 import subprocess
@@ -58,7 +58,7 @@ def test_pool_is_shared_probed_and_overlapping():
 @pytest.mark.parametrize("app_streams", [1, 2, 3, 6])
 def test_pool_survives_an_application_that_used_streams_first(app_streams):
     """A host application's own streams change which hardware queue / pipe every later stream gets; with unprobed streams 6 of 8 such start-ups gave a
-    pipeline at half rate (profiles/r06_inproc_fixed.txt).  The probed pool must still come out un-compromised and overlapping."""
+    pipeline at half rate (profiles/r06/r06_inproc_fixed.txt).  The probed pool must still come out un-compromised and overlapping."""
     _need_gpu()
     code = f"""
 import sys, json, torch

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_has_no_packed_fp32_instruction_with_nonuniform_op_sel():
-    """The instruction forms behind round 3's multi-stream corruption (point_sam_amd/isa_lint.py, profiles/r04_hazard.txt) must not ship."""
+    """The instruction forms behind round 3's multi-stream corruption (point_sam_amd/isa_lint.py, profiles/r04/r04_hazard.txt) must not ship."""
     from point_sam_amd import isa_lint
     from point_sam_amd.build import build_library
     assert isa_lint.hazardous("v_pk_mul_f32 v[52:53], v[74:75], v[42:43] op_sel:[0,1]")
