@@ -1022,6 +1022,7 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
     const int64_t wg4 = (int64_t)psam_cdiv(L, PA_BQ / 2) * H * B;
     if (variant == 1 && !force_nw && L > PA_BQ / 2 && wg4 <= (int64_t)4 * ncu) {      // (a forced workgroup shape -- PSAM_ATTN_PACKED_NW -- names the kernel: it wins)
         hipLaunchKernelGGL((flash_attn_packed_kernel<4, 2>), dim3((unsigned)wg4), dim3(256), 2 * 2 * PA_TILE, stream, p);
+        if (psam_ablate_repeat() & 1) hipLaunchKernelGGL((flash_attn_packed_kernel<4, 2>), dim3((unsigned)wg4), dim3(256), 2 * 2 * PA_TILE, stream, p);
         return psam_launch_status("psam_attention_packed: launch failed");
     }
     if (small) hipLaunchKernelGGL(flash_attn_packed_kernel<4>, dim3((unsigned)(psam_cdiv(L, PA_BQ / 2) * H * B)), dim3(256), lds, stream, p);

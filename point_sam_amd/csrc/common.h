@@ -15,6 +15,7 @@
 // compile error (C linkage cannot be overloaded), and the structs that cross the ABI exist once.
 #pragma GCC visibility push(default)
 #include "../../include/pointsam_hip.h"
+#include <cstdlib>
 #pragma GCC visibility pop
 
 void psam_set_error(const char* msg);
@@ -126,6 +127,19 @@ __device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float
     const float u = dz * dz;
     s = s + u;
     return s;
+}
+
+// Experiments builds only: PSAM_ABLATE_REPEAT (bit mask, environment, read once) makes an idempotent kernel launch TWICE -- the throughput lost to the second
+// launch is the kernel's exposed time in the pipeline (profiles/r06/r06_refill.txt): 1 = psam_attention_packed, 2 = psam_layernorm (out of place),
+// 4 = psam_ln_stats_finalize.
+static inline int psam_ablate_repeat() {
+#ifdef PSAM_BUILD_EXPERIMENTS
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("PSAM_ABLATE_REPEAT"); m = e ? atoi(e) : 0; }
+    return m;
+#else
+    return 0;
+#endif
 }
 
 // Layout of the caller's arrival-counter block (PSAM_COUNTER_BYTES = 16384 ints, include/pointsam_hip.h), in ints.  Launches that use one block are ordered,

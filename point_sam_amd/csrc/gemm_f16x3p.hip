@@ -1004,5 +1004,6 @@ PSAM_API int32_t psam_ln_stats_finalize(const float* stats, int32_t rows, int32_
     PSAM_REQUIRE(stats && mean && rstd, PSAM_EINVAL, "psam_ln_stats_finalize: null pointer");
     PSAM_REQUIRE(rows > 0 && cols > 0 && segs * 32 >= cols, PSAM_EINVAL, "psam_ln_stats_finalize: bad shape");
     hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, stats, rows, segs, cols, eps, mean, rstd);
+    if (psam_ablate_repeat() & 4) hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)psam_cdiv(rows, 4)), dim3(256), 0, stream, stats, rows, segs, cols, eps, mean, rstd);
     return psam_launch_status("psam_ln_stats_finalize: launch failed");
 }

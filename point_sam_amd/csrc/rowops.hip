@@ -232,6 +232,13 @@ PSAM_API int32_t psam_layernorm_ex2(const float* x, int64_t ldx, const float* re
         else if (span <= 1024) LNV_LAUNCH(4);
         else if (span <= 2048) LNV_LAUNCH(8);
         else LNV_LAUNCH(16);
+        if ((psam_ablate_repeat() & 2) && x != y && res != y) {
+            if (span <= 256) LNV_LAUNCH(1);
+            else if (span <= 512) LNV_LAUNCH(2);
+            else if (span <= 1024) LNV_LAUNCH(4);
+            else if (span <= 2048) LNV_LAUNCH(8);
+            else LNV_LAUNCH(16);
+        }
 #undef LNV_LAUNCH
         return psam_launch_status("psam_layernorm: launch failed");
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# socket power / clocks while the default bench runs (evidence for the power-wall argument, DESIGN.md section 11)
+# socket power / clocks while the default bench runs (evidence for the power-wall argument, DESIGN.md section 4.2)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 rocm-smi --showmaxpower --showpower 2>&1 | grep -v "^=\|^$" | head -8
