@@ -764,11 +764,15 @@ constexpr int PA_TILE = FA_BKV * 256;      // bytes of one K (or V) tile: 64 key
 // RING: K/V tiles in LDS.  3 (96 KiB): tile t + 2 is issued at the barrier of tile t -- two tile times for the data, one workgroup per CU.
 // 2 (64 KiB; NW = 4): tile t + 1 is issued at the barrier of tile t -- one tile time for the data, TWO independent workgroups per CU, whose
 // phases (S^T products, softmax, PV products) drift apart and cover each other instead of idling the matrix pipe together (round 4).
-template <int NW, int RING = 3>
+// QB = 2 (round 6): every wave owns TWO 32-query blocks.  The K and V^T fragments of a sub-tile are read from LDS once and feed both blocks' products
+// (half the LDS bytes per MFMA), and the softmax arithmetic of one block is independent of the other block's MFMAs: an in-order wave can put them under each
+// other.  Four waves x 64 queries = 256-row workgroups, one per CU, up to 512 registers per lane.
+template <int NW, int RING = 3, int QB = 1>
 __global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_kernel(const PackedAttnArgs p) {
     constexpr int HD = 64, KS = 4, DT = 2, ROWB = 256;
     static_assert(RING == 3 || (RING == 2 && NW == 4), "ring of three tiles, or two tiles with four waves (two workgroups per CU)");
-    constexpr int BQ = NW * 32, NPC = 32 / NW;      // query rows per workgroup; DMA pieces (of the 16 K + 16 V per tile) per wave
+    constexpr int BQ = NW * 32 * QB, NPC = 32 / NW;      // query rows per workgroup; DMA pieces (of the 16 K + 16 V per tile) per wave
+    static_assert(QB == 1 || (QB == 2 && NW == 4 && RING == 3), "two query blocks per wave: four waves, three-tile ring");
     static_assert(NW == 8 || NW == 4, "waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [3][K tile | V tile]: ring of three tiles, ONE barrier per tile
     const int tid = threadIdx.x, lane = tid & 63;
@@ -813,26 +817,32 @@ __global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_
     if (RING == 3 && nt > 1) issue_tile(1, 1);
 
     // ---- this lane's query row: the hi / lo chunks of channels 16 s + 8 h .. + 7, as stored
-    const int q0 = qb * BQ + wave * 32;
-    const int qrow = q0 + r32;
-    fa_f16x8 qh[KS], ql[KS];
-    {
-        const unsigned char* qp = base + (int64_t)(qrow < p.L ? qrow : p.L - 1) * rowb;
+    const int q0 = qb * BQ + wave * 32 * QB;
+    int qrow[QB];
+    fa_f16x8 qh[QB][KS], ql[QB][KS];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        qrow[u] = q0 + 32 * u + r32;
+        const unsigned char* qp = base + (int64_t)(qrow[u] < p.L ? qrow[u] : p.L - 1) * rowb;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qh[s] = *reinterpret_cast<const fa_f16x8*>(qp + (2 * s + h) * 32);
-            ql[s] = *reinterpret_cast<const fa_f16x8*>(qp + (2 * s + h) * 32 + 16);
+            qh[u][s] = *reinterpret_cast<const fa_f16x8*>(qp + (2 * s + h) * 32);
+            ql[u][s] = *reinterpret_cast<const fa_f16x8*>(qp + (2 * s + h) * 32 + 16);
         }
     }
     const float inv_su = fa_inv_pow2(s_u);
     const float c_s = p.scale_log2e * inv_su * inv_su;          // scaled-domain S -> log2-domain logits
 
-    f32x16 oacc[DT];
+    f32x16 oacc[QB][DT];
+    float m_run[QB], l_run[QB];   // l_run sums the 2^14-scaled probabilities
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+    for (int u = 0; u < QB; ++u) {
+        m_run[u] = -INFINITY; l_run[u] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;   // l_run sums the 2^14-scaled probabilities
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[u][d][r] = 0.f;
+    }
 
     // transposing V reads: this lane as SOURCE lane s = lane & 15 of its group g = lane >> 4: key (s >> 2) of the quad of keys, channels
     // (g & 1) * 16 + 4 (s & 3) .. + 3 of the 32-channel tile; as RESULT lane it is channel (g & 1) * 16 + s = r32, half h = g >> 1
@@ -856,12 +866,14 @@ __global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_
         // operation: the scheduler is free to put the S^T products of sub-tile 1 under the softmax arithmetic of sub-tile 0, and the PV
         // products of sub-tile 0 under the softmax of sub-tile 1 -- an in-order wave overlaps matrix and vector work only instruction by
         // instruction.
-        f32x16 st[2];
+        f32x16 st[QB][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            f32x16 sa, sb;        // two accumulation chains (k16 steps 0,1 and 2,3): consecutive MFMAs never wait for one another's result
+            f32x16 sa[QB], sb[QB];        // two accumulation chains (k16 steps 0,1 and 2,3): consecutive MFMAs never wait for one another's result
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sa[u][r] = 0.f; sb[u][r] = 0.f; }
             const int krow = kt * 32 + r32;
             const unsigned char* kb = kt0 + krow * ROWB;
 #pragma unroll
@@ -873,15 +885,26 @@ __global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_
                     kh[u] = *reinterpret_cast<const fa_f16x8*>(kb + (((c) ^ (krow & 15)) << 4));
                     kl[u] = *reinterpret_cast<const fa_f16x8*>(kb + (((c + 1) ^ (krow & 15)) << 4));
                 }
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0], ql[sp], sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1], ql[sp + 2], sb, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[0], qh[sp], sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[1], qh[sp + 2], sb, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0], qh[sp], sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1], qh[sp + 2], sb, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    sa[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0], ql[u][sp], sa[u], 0, 0, 0);
+                    sb[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1], ql[u][sp + 2], sb[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    sa[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[0], qh[u][sp], sa[u], 0, 0, 0);
+                    sb[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[1], qh[u][sp + 2], sb[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    sa[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0], qh[u][sp], sa[u], 0, 0, 0);
+                    sb[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1], qh[u][sp + 2], sb[u], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kt][r] = sa[r] + sb[r];
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[u][kt][r] = sa[u][r] + sb[u][r];
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -904,69 +927,75 @@ __global__ __launch_bounds__(64 * NW, RING == 2 ? 2 : 1) void flash_attn_packed_
                     vh[s2][d] = __builtin_bit_cast(fa_f16x8, fa_s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
                     vl[s2][d] = __builtin_bit_cast(fa_f16x8, fa_s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
                 }
-            // ---- online softmax for this lane's query row (keys (r&3)+8*(r>>2)+4*h of the sub-tile)
+            // ---- online softmax for this lane's query row(s) (keys (r&3)+8*(r>>2)+4*h of the sub-tile)
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
             if (key_base + 32 > p.L) {   // uniform: only a ragged last tile masks
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (key_base + (r & 3) + 8 * (r >> 2) + 4 * h >= p.L) st[kt][r] = -INFINITY;
+                    if (key_base + (r & 3) + 8 * (r >> 2) + 4 * h >= p.L) st[u][kt][r] = -INFINITY;
             }
-            float mxa = fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])), mxb = fmaxf(fmaxf(st[kt][4], st[kt][5]), fmaxf(st[kt][6], st[kt][7]));
-            float mxc = fmaxf(fmaxf(st[kt][8], st[kt][9]), fmaxf(st[kt][10], st[kt][11])), mxd = fmaxf(fmaxf(st[kt][12], st[kt][13]), fmaxf(st[kt][14], st[kt][15]));
+            float mxa = fmaxf(fmaxf(st[u][kt][0], st[u][kt][1]), fmaxf(st[u][kt][2], st[u][kt][3])), mxb = fmaxf(fmaxf(st[u][kt][4], st[u][kt][5]), fmaxf(st[u][kt][6], st[u][kt][7]));
+            float mxc = fmaxf(fmaxf(st[u][kt][8], st[u][kt][9]), fmaxf(st[u][kt][10], st[u][kt][11])), mxd = fmaxf(fmaxf(st[u][kt][12], st[u][kt][13]), fmaxf(st[u][kt][14], st[u][kt][15]));
             float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c_s;        // c_s > 0: max commutes with the scaling
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float m_new = fmaxf(m_run[u], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
             const float m14 = m_new - 14.f;
             float psum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c_s, -m14));   // probability * 2^14, in [0, 2^14]
-                psum[r & 3] += st[kt][r];
+                st[u][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][kt][r], c_s, -m14));   // probability * 2^14, in [0, 2^14]
+                psum[r & 3] += st[u][kt][r];
             }
-            l_run = l_run * alpha + ((psum[0] + psum[1]) + (psum[2] + psum[3]));
-            m_run = m_new;
+            l_run[u] = l_run[u] * alpha + ((psum[0] + psum[1]) + (psum[2] + psum[3]));
+            m_run[u] = m_new;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) oacc[u][d][r] *= alpha;
             }
             // ---- split P (registers 0-7 = k-slots of step 0, 8-15 = step 1) and O^T += V_sub^T P^T
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 unsigned hi[4], lo[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fa_split2(fa_f32x2{st[kt][8 * s2 + 2 * e], st[kt][8 * s2 + 2 * e + 1]}, hi[e], lo[e]);
+                for (int e = 0; e < 4; ++e) fa_split2(fa_f32x2{st[u][kt][8 * s2 + 2 * e], st[u][kt][8 * s2 + 2 * e + 1]}, hi[e], lo[e]);
                 const fa_f16x8 ph = __builtin_bit_cast(fa_f16x8, fa_u32x4{hi[0], hi[1], hi[2], hi[3]});
                 const fa_f16x8 pl = __builtin_bit_cast(fa_f16x8, fa_u32x4{lo[0], lo[1], lo[2], lo[3]});
 #pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], pl, oacc[d], 0, 0, 0);      // the two channel tiles alternate
+                for (int d = 0; d < DT; ++d) oacc[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], pl, oacc[u][d], 0, 0, 0);      // the two channel tiles alternate
 #pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[s2][d], ph, oacc[d], 0, 0, 0);
+                for (int d = 0; d < DT; ++d) oacc[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[s2][d], ph, oacc[u][d], 0, 0, 0);
 #pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], ph, oacc[d], 0, 0, 0);
+                for (int d = 0; d < DT; ++d) oacc[u][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[s2][d], ph, oacc[u][d], 0, 0, 0);
+            }
             }
         }
         buf = RING == 2 ? (buf ^ 1) : (buf == 2 ? 0 : buf + 1);
     }
 
-    if (FA_ABL(256)) { if (l_run == 123.f) p.o_scale[0] = oacc[0][0] + oacc[1][5]; return; }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);          // 2^14 * sum of probabilities
-    const float inv = inv_su / l_tot;                               // (oacc / (2^14 s_u)) / (l_tot / 2^14)
+    if (FA_ABL(256)) { if (l_run[0] == 123.f) p.o_scale[0] = oacc[0][0][0] + oacc[0][1][5]; return; }
     const float out_scale = f16_row_scale(p.v_bound);
-    if (head == 0 && h == 0 && qrow < p.L) p.o_scale[(int64_t)b * p.L + qrow] = out_scale;
-    float* op = p.o + ((int64_t)b * p.L + (qrow < p.L ? qrow : 0)) * p.ldo + head * HD;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+    for (int u = 0; u < QB; ++u) {
+        const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);          // 2^14 * sum of probabilities
+        const float inv = inv_su / l_tot;                               // (oacc / (2^14 s_u)) / (l_tot / 2^14)
+        if (head == 0 && h == 0 && qrow[u] < p.L) p.o_scale[(int64_t)b * p.L + qrow[u]] = out_scale;
+        float* op = p.o + ((int64_t)b * p.L + (qrow[u] < p.L ? qrow[u] : 0)) * p.ldo + head * HD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = d * 32 + 8 * g + 4 * h;
-            unsigned h0, l0, h1, l1;
-            fa_split2(fa_f32x2{oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv} * out_scale, h0, l0);
-            fa_split2(fa_f32x2{oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv} * out_scale, h1, l1);
-            const unsigned r0 = __shfl_xor(h ? h0 : l0, 32, 64), r1 = __shfl_xor(h ? h1 : l1, 32, 64);
-            if (qrow < p.L) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
-        }
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = d * 32 + 8 * g + 4 * h;
+                unsigned h0, l0, h1, l1;
+                fa_split2(fa_f32x2{oacc[u][d][4 * g] * inv, oacc[u][d][4 * g + 1] * inv} * out_scale, h0, l0);
+                fa_split2(fa_f32x2{oacc[u][d][4 * g + 2] * inv, oacc[u][d][4 * g + 3] * inv} * out_scale, h1, l1);
+                const unsigned r0 = __shfl_xor(h ? h0 : l0, 32, 64), r1 = __shfl_xor(h ? h1 : l1, 32, 64);
+                if (qrow[u] < p.L) *reinterpret_cast<fa_u32x4*>(op + d0) = h ? fa_u32x4{r0, r1, l0, l1} : fa_u32x4{h0, h1, r0, r1};
+            }
+    }
 }
 
 static int g_attn_variant = -1;
@@ -976,7 +1005,7 @@ static int attn_variant_env() {
     return v;
 }
 // tuning hook: -1 = default (environment PSAM_ATTN_VARIANT, else 1), 0 = one 256-row workgroup per CU on a three-tile ring, 1 = two 128-row
-// workgroups per CU on a two-tile ring
+// workgroups per CU on a two-tile ring, 2 = 256-row workgroups of four waves with two query blocks per wave
 PSAM_API void psam_attention_packed_force_variant(int32_t v) { g_attn_variant = v; }
 
 // qkv: g8-packed rows [B * L, ld] (containers of 4 bytes: q | k | v column blocks of D = H * 64 each, one scale for all rows in
@@ -1005,7 +1034,11 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
         if (!(__atomic_load_n(&attr_done, __ATOMIC_ACQUIRE) & bit)) {
             PSAM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                          hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-                         hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * PA_TILE) == hipSuccess,
+                         hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * PA_TILE) == hipSuccess
+#ifdef PSAM_BUILD_EXPERIMENTS
+                         && hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_packed_kernel<4, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
+#endif
+                         ,
                          PSAM_EINVAL, "psam_attention_packed: cannot reserve LDS");
             __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
         }
@@ -1020,6 +1053,15 @@ PSAM_API int32_t psam_attention_packed(const void* qkv, int64_t ld, const float*
     // two 128-row workgroups per CU on a two-tile ring where the 256-row grid is about one workgroup per CU (B = 8 clouds x 16 heads x 512 tokens: 256)
     const int variant = g_attn_variant >= 0 ? g_attn_variant : attn_variant_env();
     const int64_t wg4 = (int64_t)psam_cdiv(L, PA_BQ / 2) * H * B;
+#ifdef PSAM_BUILD_EXPERIMENTS
+    // two query blocks per wave (QB = 2): 256-row workgroups of four waves, one per CU.  Bitwise equal to the other variants and SLOWER (44.3 vs 35.8 us at
+    // B = 8, L = 512; 124.5 vs 109-121 us at B = 2, L = 2048 -- profiles/r06/r06_attn_qb2.txt): at 254 + 192 registers the compiler parks values in AGPRs (576
+    // v_accvgpr moves per tile) and the rescale branches split the two blocks' instruction streams instead of interleaving them.  Experiments builds only.
+    if (variant == 2 && !force_nw && L > PA_BQ / 2) {
+        hipLaunchKernelGGL((flash_attn_packed_kernel<4, 3, 2>), dim3((unsigned)wg8), dim3(256), lds, stream, p);
+        return psam_launch_status("psam_attention_packed: launch failed");
+    }
+#endif
     if (variant == 1 && !force_nw && L > PA_BQ / 2 && wg4 <= (int64_t)4 * ncu) {      // (a forced workgroup shape -- PSAM_ATTN_PACKED_NW -- names the kernel: it wins)
         hipLaunchKernelGGL((flash_attn_packed_kernel<4, 2>), dim3((unsigned)wg4), dim3(256), 2 * 2 * PA_TILE, stream, p);
         if (psam_ablate_repeat() & 1) hipLaunchKernelGGL((flash_attn_packed_kernel<4, 2>), dim3((unsigned)wg4), dim3(256), 2 * 2 * PA_TILE, stream, p);

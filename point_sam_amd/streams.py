@@ -245,6 +245,12 @@ def pipeline_streams(device, dense: int):
             ent["unadmitted"] += 1
             ent["dense"].append(torch.cuda.Stream(device=device))
     ent["probe_s"] += time.perf_counter() - t0
+    if ent["compromised"] and not ent.get("warned"):
+        import warnings
+        ent["warned"] = True
+        warnings.warn("point_sam_amd: no set of HIP streams on this process's hardware queues lets the pipeline's stages overlap (GPU_MAX_HW_QUEUES too small, or "
+                      "every queue shares a command-processor pipe with another): pipelines will run, at up to 2x the time per batch -- pipeline_streams_report()",
+                      RuntimeWarning, stacklevel=2)
     return ent["tok"], list(ent["dense"][:dense])
 
 
