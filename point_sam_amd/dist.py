@@ -74,7 +74,12 @@ class SideStreamGather:
     def __init__(self, device=None):
         self.enabled = dist.is_initialized() and dist.get_world_size() > 1
         # GPU tensors: the collective gets its own HIP stream.  CPU tensors (gloo, tests): the gather runs in place, synchronously.
-        self.stream = torch.cuda.Stream(device=device) if (self.enabled and device is not None and torch.cuda.is_available()) else None
+        # (a stream chosen by probing: beside the pipelines' streams a fresh one usually lands on the hardware queue the tokenizer stream starves, streams.py)
+        if self.enabled and device is not None and torch.cuda.is_available():
+            from .streams import side_stream
+            self.stream = side_stream(device)
+        else:
+            self.stream = None
 
     def start(self, tensors, total: int):
         if not self.enabled:

@@ -20,11 +20,13 @@ the first pipeline no cure, GPU_MAX_HW_QUEUES=8 no cure.  Hence: ONE set of stre
 in-order, so sharing is ordered, never wrong), each stream admitted only after the probes below; candidates that fail are passed over.
 """
 import os
+import threading
 import time
 
 import torch
 
 _POOL = {}
+_LOCK = threading.Lock()      # pipelines may be built from several host threads (a server): the probes must not interleave
 
 
 def _timed_on(streams, fn, device):
@@ -182,8 +184,13 @@ def pipeline_streams(device, dense: int):
     the one with the best miniature-pipeline ratio is kept and the pool is marked `compromised` (`pipeline_streams_report`).  More than two dense
     streams: a third is admitted by the same probes if the hardware queues allow it, otherwise taken unprobed (counted, not `compromised`).
     PSAM_PRIVATE_STREAMS=1: every call returns fresh, unprobed streams (the behaviour until round 5, kept for the A/B)."""
-    if os.environ.get("PSAM_PRIVATE_STREAMS", "0") == "1":
+    if os.environ.get("PSAM_PRIVATE_STREAMS", "0") == "1" or not hasattr(torch.cuda, "_sleep"):      # (no spin kernel to probe with: unprobed streams)
         return torch.cuda.Stream(device=device, priority=-1), [torch.cuda.Stream(device=device) for _ in range(dense)]
+    with _LOCK:
+        return _pipeline_streams_locked(device, dense)
+
+
+def _pipeline_streams_locked(device, dense: int):
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _POOL.setdefault((dev.type, idx), {"tok": None, "dense": [], "cands": [], "passed_over": 0, "compromised": False, "unadmitted": 0, "probe_s": 0.0, "mini_ratio": None})
@@ -254,9 +261,44 @@ def pipeline_streams(device, dense: int):
     return ent["tok"], list(ent["dense"][:dense])
 
 
+def side_stream(device):
+    """A normal-priority stream for work beside the pipelines (the per-step RCCL gather of the results, dist.SideStreamGather): not on a dense stream's
+    hardware queue and NOT starved by the tokenizer stream.  With four hardware queues per priority the one queue left beside the default stream's and the two
+    dense streams' is, as a rule, exactly the tokenizer queue's pipe partner -- a collective on it would sit until the tokenizer stream's pending wait resolves
+    (an earlier batch's dense stage: ~10 ms) -- so a candidate that shares the DEFAULT stream's queue is accepted: the gather is ordered after the caller's wait
+    for the batch it gathers anyway.  Falls back to a fresh stream when nothing better is found or no pipeline streams exist yet."""
+    if os.environ.get("PSAM_PRIVATE_STREAMS", "0") == "1" or not hasattr(torch.cuda, "_sleep"):
+        return torch.cuda.Stream(device=device)
+    with _LOCK:
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ent = _POOL.get((dev.type, idx))
+        if ent is None or ent["tok"] is None:
+            return torch.cuda.Stream(device=device)
+        if ent.get("side") is not None:
+            return ent["side"]
+        t0 = time.perf_counter()
+        with torch.cuda.device(idx):
+            null = torch.cuda.default_stream(idx)
+            last = None
+            for _ in range(10):
+                c = last = torch.cuda.Stream(device=device)
+                if any(streams_alias(c, d) for d in ent["dense"]):
+                    continue
+                if streams_alias(c, null) or not stream_starved_by(c, ent["tok"]):
+                    ent["side"] = c
+                    break
+            else:
+                ent["side"] = last
+                ent["side_unprobed"] = True
+        ent["probe_s"] += time.perf_counter() - t0
+        return ent["side"]
+
+
 def pipeline_streams_report():
     """What the pool holds and what admission cost, per device (bench line: `config.streams`)."""
     return {f"{k[0]}:{k[1]}": {"tokenizer_stream_id": v["tok"].stream_id if v["tok"] is not None else None, "dense_stream_ids": [d.stream_id for d in v["dense"]],
                                "tokenizer_candidates_passed_over": v["passed_over"], "dense_candidates_seen": len(v["cands"]), "compromised": v["compromised"], "dense_streams_beyond_the_probed_set": v["unadmitted"],
-                               "mini_pipeline_ratio": None if v["mini_ratio"] is None else round(v["mini_ratio"], 3), "probe_seconds": round(v["probe_s"], 3)}
+                               "mini_pipeline_ratio": None if v["mini_ratio"] is None else round(v["mini_ratio"], 3), "probe_seconds": round(v["probe_s"], 3),
+                               "side_stream_id": v["side"].stream_id if v.get("side") is not None else None}
             for k, v in _POOL.items()}

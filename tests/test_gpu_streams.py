@@ -44,6 +44,13 @@ def test_pool_is_shared_probed_and_overlapping():
     assert not streams_alias(dense[0], dense[1])
     per, alone = mini_pipeline_ms(tok, dense)
     assert per < 0.8 * alone, (per, alone)      # the two dense graphs of the miniature pipeline overlap (0.63 - 0.65 measured)
+    # the stream of the per-step gather (dist.SideStreamGather): never on a dense stream's hardware queue (a fresh torch stream that landed there cost
+    # 12 % of the cfg #2 rate and 21 ms of gather latency, profiles/r06/r06_side_stream.txt); the default stream's queue is fine
+    from point_sam_amd.streams import side_stream
+    side = side_stream("cuda:0")
+    assert side_stream("cuda:0").cuda_stream == side.cuda_stream
+    assert not any(streams_alias(side, d) for d in dense)
+    assert streams_alias(side, null) or not stream_starved_by(side, tok)
     # the pipelines take their streams from the pool
     from point_sam_amd import get_config
     from point_sam_amd.model import BatchPipeline, PointCloudSAM
