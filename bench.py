@@ -163,6 +163,11 @@ class HipHarness:
             batch = (batch[0], batch[1], batch[2], labels)
         self.batch = tuple(t.to(self.dev) for t in batch)
         self.use_graphs = args.graphs and not args.no_pipeline
+        # N ranks on one host: the pipelines' streams are chosen by TIMING probes (point_sam_amd/streams.py); let every rank finish its host-heavy set-up
+        # (seeded weights: seconds of all cores) before any rank probes
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
         # a session (several decodes on one cached encoder state) runs as a captured graph or inline; the eager stream pipeline issues single decodes
         self.pipe = BatchPipeline(self.model, dense_streams=args.streams) if (not args.no_pipeline and not (self.session and not self.use_graphs)) else None
         self.gpipe = GraphPipeline(self.model, *self.batch, None, True, slots=args.slots, dense_streams=args.streams, session=self.session) if self.use_graphs else None
