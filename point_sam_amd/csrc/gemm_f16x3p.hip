@@ -607,19 +607,29 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
     }
     const int ncu_eff = ncu > 2 * reserve ? ncu - reserve : ncu;
     struct Cand { int cfg, bm, bn, per_cu; bool swiglu, two_wide; double pen; };
+    // 41 = the eight-wave 128x128 tile on a FIVE-stage ring (exactly 160 KiB), 42 = 128x96 on five stages (140 KiB; single-cloud launches of one round): the same
+    // bits as cfg 9, and ALONE on the chip faster where the K loop is bound by the slabs in flight (giant qkv at one cloud 28.1 -> 25.5 -> 23.8 us, ViT-L fc2 at
+    // M = 2048 42.7 -> 41.0 us; profiles/r06/r06_small_m.txt) -- but in the two-stream pipelines they LOSE 4 % (cfg #5 146.3 -> 140.4 sessions/s, cfg #3 102.8 ->
+    // 98.6 clouds/s, profiles/r06/r06_small_m_ring.txt): a workgroup that holds all of a CU's LDS keeps the other stream's kernels off that CU.  OFF by default
+    // (PSAM_GEMM_SMALL_M_RING=1 / force_config 41, 42 switch them in: a single stream of work, e.g. an interactive predictor, gains).
     static const Cand cands[] = {{14, 256, 256, 1, true, false, 1.0}, {23, 256, 192, 1, false, false, 1.0}, {4, 256, 128, 1, true, true, 1.05},
-                                 {9, 128, 128, 1, true, true, 1.15},  {21, 128, 128, 2, true, true, 1.15},  {28, 128, 128, 2, true, true, 1.2}};
-    int best = 9;
+                                 {41, 128, 128, 1, true, true, 1.15}, {21, 128, 128, 2, true, true, 1.15},  {28, 128, 128, 2, true, true, 1.2},
+                                 {42, 128, 96, 1, false, false, 1.15}};
+    static int small_ring = -1;
+    if (small_ring < 0) { const char* e = getenv("PSAM_GEMM_SMALL_M_RING"); small_ring = e ? atoi(e) : 0; }
+    int best = 41;
     double best_cost = 1e300;
     for (const Cand& c : cands) {
         if (act == 3 && !c.swiglu) continue;
         if (two_wide_only && !c.two_wide) continue;
         const int64_t tiles = psam_cdiv(M, c.bm) * psam_cdiv(N, c.bn);
         const double rounds = (double)psam_cdiv(tiles, (int64_t)ncu_eff * c.per_cu);
+        if (c.cfg == 42 && (!small_ring || M > 1024 || rounds > 1.0)) continue;
         const double share = (c.per_cu == 2 && tiles * 2 > (int64_t)ncu_eff * 3) ? share2 : 1.0;
-        const double cost = rounds * c.bm * c.bn * (K + 300.0) * (c.cfg == 9 ? pen9 : c.pen) * share;
+        const double cost = rounds * c.bm * c.bn * (K + 300.0) * (c.cfg == 41 ? pen9 : c.pen) * share;
         if (cost < best_cost) { best_cost = cost; best = c.cfg; }
     }
+    if (best == 41 && !small_ring) best = 9;
     return best;
 }
 
@@ -658,7 +668,8 @@ static void f16x3p_cfg_tile(int cfg, int& bm, int& bn, int& per_cu) {
         case 4: bm = 256; bn = 128; per_cu = 1; break;
         case 14: bm = 256; bn = 256; per_cu = 1; break;
         case 12: case 23: bm = 256; bn = 192; per_cu = 1; break;
-        case 9: case 29: bm = 128; bn = 128; per_cu = 1; break;
+        case 9: case 29: case 41: bm = 128; bn = 128; per_cu = 1; break;
+        case 42: bm = 128; bn = 96; per_cu = 1; break;
         default: bm = 128; bn = 128; per_cu = 2; break;      // 0, 21, 28
     }
 }
@@ -785,6 +796,8 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
             case 23: rc = launch_f16x3p<4, 2, 2, 3, 2, 0, 0, 2>(p, stream); break;
             case 28: rc = launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream); break;
             case 29: rc = launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 0, 1>(p, stream); break;
+            case 41: rc = launch_f16x3p<4, 2, 1, 2, 5, 1>(p, stream); break;
+            case 42: rc = launch_f16x3p<4, 1, 1, 3, 5, 1>(p, stream); break;
             default: psam_set_error("psam_gemm_f16x3p_ex: split-K has no such tile configuration"); return PSAM_EINVAL;
         }
         if (rc != PSAM_OK || counters) return rc;
@@ -805,7 +818,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         // The register epilogue sums a row's products in another order than the LDS epilogue (same accuracy, other rounding): ONE configuration for every
         // M, so that a cloud's logits do not depend on how many clouds share the launch (tests/test_gpu_e2e.py::test_properties_full_size).
         if (g_f16x3p_cfg < 0 && f16x3p_use_register_epilogue(p)) cfg = 21;
-        else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
+        else if (cfg != 4 && cfg != 9 && cfg != 41 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
 #ifdef PSAM_BUILD_EXPERIMENTS
     } else if (fuse && fuse->row_ln_g && N == 512) {
         // full-row tile 128x512 on the ping-pong kernel with the register epilogue: Linear (+ row bias per group) -> LayerNorm -> activation -> packed rows
@@ -861,7 +874,7 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         // group maximum: wave tiles of 64 rows (two stripes): 256x128 (cfg 4), 256x256 (cfg 14, N % 256 == 0), 128x128 of four waves (cfg 21);
         // row statistics / everything else: wave tiles two 32-column tiles wide (cfg 4, 9, 21, 28)
         if (fuse->gmax_out) { if (cfg != 4 && cfg != 14 && cfg != 21) cfg = (N % 256 == 0 && !fuse->stats) ? 14 : 4; }
-        else if (cfg != 4 && cfg != 9 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
+        else if (cfg != 4 && cfg != 9 && cfg != 41 && cfg != 21 && cfg != 28) cfg = f16x3p_pick(M, N, K, act, true);
     }
     {   // ping-pong kernel (gemm_f16x3pp.hip) where it measured faster (f16x3pp_pick), or where a forced configuration names it
         const bool w_stats = p.stats != nullptr, w_gmax = p.gmax_out != nullptr, w_hyper = p.hyper != nullptr;
@@ -942,6 +955,9 @@ PSAM_API int32_t psam_gemm_f16x3p_ex(const void* A, int64_t lda, const float* sc
         case 28: return launch_f16x3p<4, 2, 1, 2, 2, 0, 0, 2>(p, stream);     // 128x128, 8 waves of 32x64, 2 stages, mid-slab release (70 KiB): 2 per CU
         case 29: return f16x3p_use_register_epilogue(p) ? launch_f16x3p<4, 2, 1, 2, 4, 1, 0, 0, 1>(p, stream)      // cfg 9 with the register epilogue (round 6)
                                                         : launch_f16x3p<4, 2, 1, 2, 4, 1>(p, stream);
+        // deeper rings for single-cloud shapes, whose K loop is bound by the LDS-DMA round trip / slabs in flight (round 6, profiles/r06/r06_small_m.txt)
+        case 41: return launch_f16x3p<4, 2, 1, 2, 5, 1>(p, stream);           // cfg 9 with FIVE stages (exactly 160 KiB): four slabs in flight instead of three
+        case 42: return launch_f16x3p<4, 1, 1, 3, 5, 1>(p, stream);           // 128x96, 4 waves of 32x96, five stages (140 KiB); no SwiGLU epilogue
         // 30 / 31: three workgroups per CU.  Alone they win on the short launches (proj 38.4 -> 32.3 us, up.3 233 -> 205 us), in the pipelined
         // bench (two batches' kernels co-scheduled) they lose 1.5 % (profiles/r02/r02_gemm_tri_tile.txt): reachable through force_config only
         case 30: return launch_f16x3p<2, 2, 2, 1, 2, 0, 0, 2>(p, stream);     // 128x64, 4 waves of 64x32, 48 KiB (no SwiGLU / fused extras)
