@@ -630,6 +630,14 @@ static int f16x3p_pick(int M, int N, int K, int act, bool two_wide_only) {
         if (cost < best_cost) { best_cost = cost; best = c.cfg; }
     }
     if (best == 41 && !small_ring) best = 9;
+    // The eight-wave 128x128 tile comes as cfg 9 (four stages, 128 KiB: one workgroup per CU) and cfg 28 (two stages with the mid-slab release, 70 KiB: two
+    // per CU) -- the same wave tiles, the same bits.  Alone cfg 9 is 5-10 % faster on every single-cloud shape; in the two-stream pipelines the answer depends on
+    // the rows (profiles/r06/r06_sub9.txt): at M = 512 (giant, one cloud) cfg 9 wins (145.9 vs 138.4 sessions/s), at M = 2048 (ViT-L, N = 131072) cfg 28 wins
+    // (106.1 vs 103.2 clouds/s: with several rounds of tiles the LDS it leaves free lets the other stream's workgroups onto the CU).  PSAM_GEMM_SUB9=<cfg>
+    // overrides (A/B; 9 = always cfg 9).
+    static int sub9 = -1;
+    if (sub9 < 0) { const char* e = getenv("PSAM_GEMM_SUB9"); sub9 = e ? atoi(e) : 0; }
+    if (best == 9) best = sub9 > 0 ? sub9 : (M >= 2048 ? 28 : 9);
     return best;
 }
 
