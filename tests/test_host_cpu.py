@@ -231,3 +231,31 @@ def test_gemm_mode_is_per_context():
     import pytest
     with pytest.raises(ValueError):
         ops.gemm_mode("fp8")
+
+
+def test_library_keeps_no_stream_state_and_allocates_only_in_prepare():
+    """VERDICT r05 item 7 / the boundary's own contract ("no allocation inside ... thread-safe given distinct streams/workspaces"): the product
+    sources create no streams or events, allocate device memory only in a *_prepare entry (a staging buffer it frees), and keep no (device, stream) tables;
+    the arrival counters of the in-kernel fix-ups are the caller's (PSAM_COUNTER_BYTES), and the entry points that used to manage them are gone."""
+    from point_sam_amd import ops
+    csrc = os.path.join(ROOT, "point_sam_amd", "csrc")
+    hdr = open(os.path.join(ROOT, "include", "pointsam_hip.h")).read()
+    assert int(re.search(r"#define PSAM_COUNTER_BYTES (\d+)", hdr).group(1)) == ops.COUNTER_BYTES
+    for gone in ("psam_stream_has_arrival_counters", "psam_gemm_f16x3p_reset_splitk_state", "psam_attention_f16x3_reset_keysplit_state"):
+        assert gone not in hdr and gone not in _lib.SIGNATURES
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        default = re.sub(r"#ifdef PSAM_BUILD_EXPERIMENTS.*?#endif", "", src, flags=re.S)      # what a default build compiles
+        default = re.sub(r"#ifndef PSAM_BUILD_EXPERIMENTS(.*?)#else.*?#endif", r"\1", default, flags=re.S)
+        assert "hipStreamCreate" not in default and "hipEventCreate" not in default, f
+        assert "std::map" not in default and "std::mutex" not in default, f
+        for m in re.finditer(r"hipMalloc\w*\(", default):
+            fn = re.findall(r"PSAM_API \w+ (psam_\w+)\(", default[:m.start()])[-1]
+            assert fn.endswith("_prepare"), (f, fn)
+    # the host's blocks: one per use_counters scope, validated
+    with pytest.raises(ValueError):
+        ops.use_counters(torch.zeros(4, dtype=torch.int32))
+    from point_sam_amd.streams import pipeline_streams_report
+    assert isinstance(pipeline_streams_report(), dict)
