@@ -1,6 +1,6 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv (separate passes) -> per-kernel HBM bytes per launch (profiles/*_traffic.json).
 The derived counters are in KiB (bytes = value * 1024); FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of the
-wide coalesced reads).  Usage: python scripts/pmc_to_traffic.py TAG profiles/TAG_traffic.json (after scripts/gpu_pmc.sh TAG)."""
+wide coalesced reads).  Usage: python scripts/pmc_to_traffic.py TAG profiles/TAG_traffic.json (called by scripts/gpu_round_evidence.sh TAG)."""
 import csv, json, sys, collections, glob, os
 def per_kernel(path):
     acc = collections.defaultdict(lambda: [0.0, 0])
