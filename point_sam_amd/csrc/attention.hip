@@ -263,11 +263,16 @@ __device__ __forceinline__ void fa_split2(const fa_f32x2 xs, unsigned& hi, unsig
 }
 __device__ __forceinline__ float fa_inv_pow2(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
 
-template <int HD>   // head dim: 64 or 128
+// HD: head dim of the LDS layout, 64 or 128.  HDA <= HD (a multiple of 32): the channels that can be non-zero -- a head dim of 88 runs on the 128-wide layout
+// (power-of-two index maps) but issues the MFMAs, fragment reads and conversions of 96 channels only (round 6: the products with the zero padding add exact
+// zeros, so the results are the same bits as the full 128-channel instance; 6 of 8 k16 steps of S^T, 3 of 4 channel tiles of O^T).
+template <int HD, int HDA = HD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 2 : 1))) void flash_attn_f16x3_kernel(const FlashArgs p) {
     static_assert(HD == 64 || HD == 128, "head dim");
+    static_assert(HDA % 32 == 0 && HDA > 0 && HDA <= HD, "active channels");
     constexpr int KS = HD / 16;                         // k16 steps of S^T = K Q^T
     constexpr int DT = HD / 32;                         // 32-channel tiles of O^T
+    constexpr int KSA = HDA / 16, DTA = HDA / 32;       // ... that can hold non-zero channels
     constexpr int ROWB = 128;                           // bytes per LDS row (64 fp16)
     constexpr int KROW = HD * 2;                        // bytes per K-plane row
     constexpr int KSW = (KROW / 16 - 1) < 7 ? (KROW / 16 - 1) : 7;   // swizzle mask: stays inside the row's chunks
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         for (int i = 0; i < NF4; ++i) {
             const int f = i * 256 + tid;
             const int row = f / ROW4, c4 = f % ROW4;
+            if (HDA < HD && c4 * 4 >= HDA) continue;      // padding channels: never read (the k16 steps beyond HDA are not issued)
             unsigned h0, l0, h1, l1;
             // K planes: row-major, chunk (c4>>1) of the row swizzled
             fa_split2(fa_f32x2{rk[i][0], rk[i][1]} * sk, h0, l0);
@@ -363,6 +369,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
             *reinterpret_cast<fa_u32x2*>(st + KPLANE + koff) = fa_u32x2{l0, l1};
         }
         // V planes: transposed; keys 4g..4g+3 go to slots pos..pos+3 with pos = (4g & ~12) | swap of bits 2,3 (see header)
+        if (HDA == HD || vc4 * 4 < HDA)
 #pragma unroll
         for (int ps = 0; ps < NF4 / 4; ++ps) {
             const int key0 = 4 * (vj + VJ * ps);
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         f32x4 t[KS][2];
         float amax = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KSA; ++s)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 t[s][e] = (ok && s * 16 + h * 8 + e * 4 < hd) ? *reinterpret_cast<const f32x4*>(qp + s * 16 + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         const float sq = f16_row_scale(amax);
         q_inv = fa_inv_pow2(sq);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s = 0; s < KSA; ++s) {
             unsigned hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
             const int krow = kt * 32 + r32;
             const unsigned char* kb = st_base + krow * KROW;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < KSA; ++s) {
                 const int off = ((2 * s + h) ^ ((krow >> 1) & KSW)) << 4;
                 const fa_f16x8 kh = *reinterpret_cast<const fa_f16x8*>(kb + off);
                 const fa_f16x8 kl = *reinterpret_cast<const fa_f16x8*>(kb + KPLANE + off);
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
+                for (int d = 0; d < DTA; ++d) {
                     const int vrow = d * 32 + r32;
                     const unsigned char* vb = st_base + 2 * KPLANE + vrow * ROWB + (((kt * 4 + s2 * 2 + h) ^ ((vrow >> 1) & 7)) << 4);
                     const fa_f16x8 vh = *reinterpret_cast<const fa_f16x8*>(vb);
@@ -630,6 +637,12 @@ static bool fa_keysplit_enabled() {
     return on != 0;
 }
 PSAM_API void psam_attention_f16x3_force_keysplit(int32_t mode) { g_fa_keysplit = mode; }
+// A/B hook: PSAM_ATTN_FULL_WIDTH=1 runs head dims in (64, 96] on the full 128-channel instance (the round-5 kernel; same bits)
+static bool fa_full_width() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PSAM_ATTN_FULL_WIDTH"); on = e ? (atoi(e) != 0) : 0; }
+    return on != 0;
+}
 // the split factor the launch would use, given unlimited scratch (0 / 1: unsplit)
 static int fa_keysplit_factor(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t hd, int32_t max_keysplit) {
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || hd <= 64) return 1;      // (head dim 64 at this size runs on the packed-operand kernel)
@@ -688,6 +701,7 @@ PSAM_API int32_t psam_attention_f16x3_ex2(const float* q, int64_t ldq, int64_t s
     }
     const dim3 grid((unsigned)(units * p.ksplit)), block(256);      // 1-D over (key split, query block, head, batch), see the kernel
     if (hd == 64) hipLaunchKernelGGL((flash_attn_f16x3_kernel<64>), grid, block, 0, stream, p);
+    else if (hd > 64 && hd <= 96 && (hd & 7) == 0 && !fa_full_width()) hipLaunchKernelGGL((flash_attn_f16x3_kernel<128, 96>), grid, block, 0, stream, p);   // 128-wide layout, 96 active channels (the giant encoder's 88)
     else if (hd > 64 && hd <= 128 && (hd & 7) == 0) hipLaunchKernelGGL((flash_attn_f16x3_kernel<128>), grid, block, 0, stream, p);   // zero-padded to 128
     else {
         psam_set_error("psam_attention_f16x3: head_dim must be 64 or a multiple of 8 in (64, 128]");
